@@ -1,0 +1,69 @@
+// Internal device-side structures shared by the gfx950 kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "marinenav_hip.h"
+
+#define MN_WAVE 64
+#define MN_TAB_ROWS (3 * MN_MAX_CORES + 3 * MN_MAX_OBS)
+
+// Device-resident state.  Everything is struct-of-arrays with the env index fastest, padded to a
+// multiple of 64 envs (one wavefront tile), so lane i of a wave touches element base+i of every
+// array: each load/store instruction of the step kernel moves one contiguous 256/512-byte run.
+struct MnArrays {
+    int32_t n, npad;
+    // robot pose (robot.py:40-44); kept in float64 in both precisions
+    double *x, *y, *theta, *speed, *vx, *vy;
+    // per-env episode constants
+    double *start_x, *start_y, *goal_x, *goal_y, *init_theta, *init_speed;
+    int32_t *ep_t;    // marinenav_env.py:70 episode_timesteps
+    int64_t *tot_t;   // marinenav_env.py:71 total_timesteps
+    int32_t *counts;  // placed cores | placed obstacles << 8
+    // world tables, [k][npad], generation order (order matters for the sonar `break` quirk)
+    double *cx, *cy, *cg;    // cg = +Gamma if clockwise else -Gamma
+    double *ox, *oy, *orad;
+    // numpy RandomState streams: [n][624] key words + position in the block
+    uint32_t *mt;
+    int32_t *mt_pos;
+    // float64 copy of the observations (parity precision only), [npad][26]
+    double *obs64;
+    // done-queue filled by the step kernel, drained by the reset kernel
+    uint32_t *queue_count;  // [2], alternating per step
+    int32_t *queue;         // [npad]
+};
+
+// Host-derived constants (computed once in double with the host libm so that the generated world
+// tables are bit-identical to the numpy reference).
+struct MnDev {
+    double width, height, core_r, v_rel_max, p, v_lo, v_span, or_lo, or_span, clear_r, goal_dis;
+    double timestep_penalty, collision_penalty, goal_reward;
+    double min_start_goal_dis, init_theta, init_speed;
+    double dt, robot_r, max_speed, k_drag, a[3], w[3];
+    double sonar_range;
+    double beam_rel[MN_NUM_BEAMS], beam_cos[MN_NUM_BEAMS], beam_sin[MN_NUM_BEAMS];
+    double two_pi;          // 2*pi as python computes it
+    double two_pi_r;        // (2*pi)*r              -> Gamma = two_pi_r * v_edge
+    double two_pi_vrel;     // (2*pi)*v_rel_max      -> check_core same-direction boundary
+    double two_pi_r_r;      // ((2*pi)*r)*r          -> compute_speed inside the core
+    double binom_q;         // exp(1*log(1-0.5))     -> binomial(1,.5) == (U > binom_q)
+    double sg_lo_x, sg_span_x, sg_lo_y, sg_span_y;  // start/goal uniform: 2 + (w-2-2)*U
+    double c_span_x, c_span_y;                      // core centre: 0 + w*U
+    double o_lo, o_span_x, o_span_y;                // obstacle centre: 5 + (w-5-5)*U
+    double timestep_scale;
+    int32_t num_cores, num_obs, reset_start_and_goal, random_reset_state, set_boundary, max_episode_steps, N;
+    int32_t n_stages;
+    int64_t sched_t[MN_MAX_STAGES];
+    int32_t sched_nc[MN_MAX_STAGES], sched_no[MN_MAX_STAGES];
+    double sched_md[MN_MAX_STAGES];
+};
+
+// kernels (defined in mn_step.hip / mn_reset.hip)
+void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, const int32_t *actions, float *obs, float *reward,
+                    uint8_t *done, uint8_t *info, int parity, hipStream_t s);
+// mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
+void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
+                     const int32_t *list_dev, int mode, float *obs, hipStream_t s);
+void mn_launch_seed(const MnArrays &A, const uint32_t *seeds_dev, hipStream_t s);
+void mn_launch_mask_to_queue(const MnArrays &A, const uint8_t *mask, uint32_t *count, int32_t *list, hipStream_t s);
+void mn_launch_peek(const MnArrays &A, int first, int count, double *out_dev, hipStream_t s);

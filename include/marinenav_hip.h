@@ -1,0 +1,184 @@
+/*
+ * marinenav_hip.h -- C-ABI of libmarinenav_hip.so, the MI355X (gfx950) batched marinenav_env.
+ *
+ * The reference (RobustFieldAutonomyLab/Distributional_RL_Navigation) is pure Python and has no
+ * FFI layer; its boundary for this path is the Python class MarineNavEnv
+ * (marinenav_env/envs/marinenav_env.py:25-627).  Each entry point below names the reference
+ * method(s) it replaces for a batch of `n_envs` independent environments.  A reference
+ * maintainer binds these with ctypes; the package's own binding is
+ * distributional_rl_navigation_amd/_capi.py.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative mn_status; mn_last_error() gives text.
+ *    No C++ exceptions cross the boundary.
+ *  - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. torch.Tensor.data_ptr());
+ *    `*_host` pointers are host memory.  The library never frees caller memory and never
+ *    allocates in mn_step / mn_reset_done / mn_reset.
+ *  - Environment state (robot pose, world tables, MT19937 streams) lives in device memory
+ *    owned by the handle (allocated in mn_create, released in mn_destroy).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are launched
+ *    on it with no implicit synchronisation; host<->device accessors (get / set / load) are
+ *    synchronous with respect to that handle's previous work on the NULL stream only, so call
+ *    them after synchronising your stream.
+ *  - One handle per GPU per process; a handle is not re-entrant across threads.
+ */
+#ifndef MARINENAV_HIP_H
+#define MARINENAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MN_MAX_CORES 8      /* curriculum maximum, train_IQN_model.py:86-90 */
+#define MN_MAX_OBS 10       /* curriculum maximum, train_IQN_model.py:86-90 */
+#define MN_NUM_BEAMS 11     /* robot.py:9 */
+#define MN_OBS_DIM 26       /* 2 + 2 + 2*11, marinenav_env.py:80-81 */
+#define MN_NUM_ACTIONS 9    /* robot.py:55-56 */
+#define MN_MAX_STAGES 8     /* curriculum stages held on device */
+
+typedef enum mn_status {
+    MN_OK = 0,
+    MN_ERR_INVALID = -1,   /* bad argument */
+    MN_ERR_HIP = -2,       /* a HIP runtime call failed (text in mn_last_error) */
+    MN_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
+    MN_ERR_ALLOC = -4
+} mn_status;
+
+/* info codes written by mn_step; strings at marinenav_env.py:243,246,250,254,257 */
+enum { MN_INFO_NORMAL = 0, MN_INFO_OUT_OF_BOUNDARY = 1, MN_INFO_TOO_LONG = 2, MN_INFO_COLLISION = 3, MN_INFO_REACH_GOAL = 4 };
+
+/* arithmetic of the step/observation kernels */
+enum {
+    MN_PRECISION_F64 = 0,   /* everything float64: whole-episode parity with the reference */
+    MN_PRECISION_MIXED = 1  /* f64 pose integration + f64->f32 relative geometry, f32 field/sonar:
+                               single-step outputs within 1e-5 of the reference */
+};
+
+/* Scalar attributes of MarineNavEnv.__init__ (marinenav_env.py:40-73), Robot.__init__
+ * (robot.py:25-50) and Sonar.__init__ (robot.py:5-12).  Uniform over the batch. */
+typedef struct mn_params {
+    double width, height;            /* :40-41 */
+    double core_r;                   /* :42 self.r */
+    double v_rel_max, p;             /* :43-44 */
+    double v_range[2];               /* :45 */
+    double obs_r_range[2];           /* :46 */
+    double clear_r;                  /* :47 */
+    double goal_dis;                 /* :54 */
+    double timestep_penalty;         /* :55 */
+    double collision_penalty;        /* :59 */
+    double goal_reward;              /* :60 */
+    double discount;                 /* :61 (host-side only) */
+    double min_start_goal_dis;       /* :64 */
+    double init_theta, init_speed;   /* :51-52, used when random_reset_state == 0 */
+    double dt;                       /* robot.py:28 */
+    double robot_r;                  /* robot.py:33 */
+    double max_speed;                /* robot.py:34 */
+    double a[3], w[3];               /* robot.py:35-36 */
+    double sonar_range, sonar_angle; /* robot.py:7-8 */
+    int32_t num_cores, num_obs;      /* :62-63, requested world size when no schedule is set */
+    int32_t reset_start_and_goal;    /* :48 */
+    int32_t random_reset_state;      /* :50 */
+    int32_t set_boundary;            /* :73 */
+    int32_t max_episode_steps;       /* 1000, :244 */
+    int32_t N;                       /* robot.py:29 sub-steps per action */
+    int32_t num_beams;               /* robot.py:9, must equal MN_NUM_BEAMS */
+    int32_t precision;               /* MN_PRECISION_* */
+    int32_t reserved;
+} mn_params;
+
+typedef struct mn_handle mn_handle;
+
+/* Fills *p with the reference defaults (marinenav_env.py:40-73, robot.py:5-50). */
+int mn_default_params(mn_params *p);
+
+/* MarineNavEnv.__init__ for n_envs environments (marinenav_env.py:27-73).  RNG streams are
+ * seeded with seed 0..n_envs-1 until mn_seed is called. */
+int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out);
+int mn_destroy(mn_handle *h);
+const char *mn_last_error(const mn_handle *h); /* h may be NULL for create-time errors */
+int32_t mn_num_envs(const mn_handle *h);
+
+/* Attribute writes such as `env.num_cores = 4`, `env.set_boundary = True`, `env.robot.N = 5`
+ * (train_IQN_model.py:131-140, run_experiments.py:197-207). */
+int mn_set_params(mn_handle *h, const mn_params *p);
+int mn_get_params(const mn_handle *h, mn_params *p);
+
+/* MarineNavEnv.seed (marinenav_env.py:75-78): env i <- np.random.RandomState(seeds_host[i])
+ * (MT19937, legacy init_genrand seeding). */
+int mn_seed(mn_handle *h, const uint32_t *seeds_host, void *stream);
+
+/* Curriculum `schedule` constructor argument (marinenav_env.py:27,89-98;
+ * train_IQN_model.py:86-90).  n_stages == 0 clears it.  The stage is looked up with
+ * floor(total_timesteps[i] * timestep_scale): scale 1 reproduces the reference for one env,
+ * scale n_envs makes the curriculum advance with aggregate experience. */
+int mn_set_schedule(mn_handle *h, int32_t n_stages, const int64_t *timesteps, const int32_t *num_cores,
+                    const int32_t *num_obstacles, const double *min_start_goal_dis, double timestep_scale);
+
+/* env.start / env.goal attribute writes (train_IQN_model.py:133-134); env_idx < 0 = all envs. */
+int mn_set_start_goal(mn_handle *h, int32_t env_idx, const double start[2], const double goal[2]);
+
+/* MarineNavEnv.reset (marinenav_env.py:86-186) for the envs with mask_dev[i] != 0 (NULL = all):
+ * curriculum lookup, start/goal, vortex cores, obstacles by bounded rejection sampling from the
+ * env's own MT19937 stream (bit-exact draw order), robot pose, first observation.
+ * Writes obs rows [i][26] (float32) of the reset envs into obs_dev (other rows untouched). */
+int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
+
+/* MarineNavEnv.step (marinenav_env.py:199-262) for all envs: N sub-steps of
+ * get_velocity (:422-465) + Robot.update_state (robot.py:102-123), get_observation (:273-326,
+ * robot.py:125-198), reward and termination ladder (:220-257), counters (:259-260).
+ * actions_dev[n] int32 in [0,9); obs_dev [n][26] f32 (terminal observation for finished envs);
+ * reward_dev [n] f32; done_dev [n] u8; info_dev [n] u8 (MN_INFO_*).  No auto-reset. */
+int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+            uint8_t *info_dev, void *stream);
+
+/* The caller-side `if done: state = train_env.reset()` (thirdparty/IQN/agent.py:152-170), batched:
+ * resets exactly the envs the LAST mn_step flagged done and overwrites their rows of obs_dev
+ * (which may or may not be the buffer given to mn_step). */
+int mn_reset_done(mn_handle *h, float *obs_dev, void *stream);
+
+/* MarineNavEnv.reset_with_eval_config (marinenav_env.py:467-555), world + pose fields, for `count`
+ * consecutive envs starting at first_env.  Host arrays, row-major:
+ *   n_cores[count], cores_xy[count][MN_MAX_CORES][2], clockwise[count][MN_MAX_CORES],
+ *   gamma[count][MN_MAX_CORES], n_obs[count], obs_xy[count][MN_MAX_OBS][2], obs_r[count][MN_MAX_OBS],
+ *   start[count][2], goal[count][2], init_theta[count], init_speed[count].
+ * Does not touch the RNG streams.  Resets episode_timesteps, places the robot at `start` and
+ * writes the first observation rows into obs_dev if it is not NULL. */
+int mn_load_worlds(mn_handle *h, int32_t first_env, int32_t count, const int32_t *n_cores, const double *cores_xy,
+                   const int32_t *clockwise, const double *gamma, const int32_t *n_obs, const double *obs_xy,
+                   const double *obs_r, const double *start, const double *goal, const double *init_theta,
+                   const double *init_speed, float *obs_dev, void *stream);
+
+/* MarineNavEnv.episode_data (marinenav_env.py:557-622), world + pose fields; same layouts. */
+int mn_get_worlds(mn_handle *h, int32_t first_env, int32_t count, int32_t *n_cores, double *cores_xy,
+                  int32_t *clockwise, double *gamma, int32_t *n_obs, double *obs_xy, double *obs_r, double *start,
+                  double *goal, double *init_theta, double *init_speed);
+
+/* Robot pose and counters (robot.py:40-44, marinenav_env.py:70-71).  state[count][6] =
+ * x, y, theta, speed, velocity_x, velocity_y (float64).  NULL pointers are skipped. */
+int mn_get_state(mn_handle *h, int32_t first_env, int32_t count, double *state, int32_t *episode_timesteps,
+                 int64_t *total_timesteps);
+int mn_set_state(mn_handle *h, int32_t first_env, int32_t count, const double *state,
+                 const int32_t *episode_timesteps, const int64_t *total_timesteps);
+
+/* Float64 copy of the last observation each env produced (the reference returns float64,
+ * marinenav_env.py:326).  Only kept when precision == MN_PRECISION_F64; out[count][26]. */
+int mn_get_obs64(mn_handle *h, int32_t first_env, int32_t count, double *out);
+
+/* Next double each env's RandomState would return, without consuming it (test hook pinning the
+ * RNG stream position; cf. np.random.RandomState.random_sample). */
+int mn_peek_next_double(mn_handle *h, int32_t first_env, int32_t count, double *out);
+
+/* Number of envs the last mn_step flagged done (synchronises the stream). */
+int mn_last_done_count(mn_handle *h, void *stream, int32_t *out);
+
+/* Timing hook for benchmarks: records hipEvents on `stream` around the dominant kernel of the
+ * next mn_step calls.  mn_step_kernel_ms returns the mean over the recorded launches. */
+int mn_profile_begin(mn_handle *h, int32_t max_launches);
+int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARINENAV_HIP_H */
