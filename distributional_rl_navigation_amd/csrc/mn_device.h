@@ -22,17 +22,24 @@ struct MnMath<float> {
 };
 
 // One beam against one obstacle (robot.py:147-198 restated in ray-parametric form, SURVEY App. A
-// S2).  m = obstacle centre - robot position, (dx,dy) = unit beam direction (snapped to exactly
-// vertical by the caller when within 1e-3 rad of +-pi/2, robot.py:150-162).
-//   h2 = r^2 - (m x d)^2 < 0          -> no real solution          (robot.py:156,175 `continue`)
+// S2), in the ROBOT frame: (mrx,mry) = R(theta)^T (obstacle centre - robot position), (bx,by) = unit
+// beam direction in the robot frame -- the constant (cos rel, sin rel), or +-(sin theta, cos theta)
+// when the beam is snapped to exactly vertical (robot.py:150-162).
+// The geometry (t_c, perpendicular offset, h^2) is always float64: a grazing hit amplifies an error
+// in the perpendicular offset by r/h, which float32 cannot hold to 1e-5; the 5 f64 FMAs per pair are
+// cheaper than any float32 compensation.  Everything after h^2 runs in M.
+__device__ __forceinline__ void mn_beam_geom(double mrx, double mry, double r2, double bx, double by, double &tc, double &h2) {
+    tc = bx * mrx + by * mry;
+    const double perp = mrx * by - mry * bx;
+    h2 = r2 - perp * perp;
+}
+
+//   h2 < 0                             -> no real solution          (robot.py:156,175 `continue`)
 //   nearer root t = t_c -/+ h          (robot.py:184 picks the root with the smaller |t|)
 //   |t| > range or t < 0               -> `continue`               (robot.py:185,188)
 //   already hit and t >= best          -> `break`: later obstacles are never examined (:192-195)
 template <typename M>
-__device__ __forceinline__ void mn_beam_obstacle(M mx, M my, M r, M dx, M dy, M range, bool &hit, M &dist, bool &stopped) {
-    M tc = dx * mx + dy * my;
-    M perp = mx * dy - my * dx;
-    M h2 = r * r - perp * perp;
+__device__ __forceinline__ void mn_beam_update(M tc, M h2, M range, bool &hit, M &dist, bool &stopped) {
     M h = MnMath<M>::sqrt_(h2 > M(0) ? h2 : M(0));
     M t = tc > M(0) ? tc - h : tc + h;
     bool cand = (!stopped) && (h2 >= M(0)) && (t >= M(0)) && (t <= range);

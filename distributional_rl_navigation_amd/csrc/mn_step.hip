@@ -101,24 +101,28 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
     const double dis_after = sqrt(dax * dax + day * day);
 
     // ---- observation (marinenav_env.py:273-326) ------------------------------------------------
-    M sn, cs;
-    MnMath<M>::sincos_((M)theta, &sn, &cs);
+    // Final-heading rotation in float64 (one sincos per step): the goal vector (|g| up to 70 m) and
+    // the sonar geometry cancel too much for float32 sin/cos.
+    double sn, cs;
+    sincos(theta, &sn, &cs);
     M ob[MN_OBS_DIM];
-    ob[0] = cs * velx + sn * vely;  // R(theta)^T * velocity: lagged velocity, final heading (App. A K5)
-    ob[1] = -sn * velx + cs * vely;
     {
-        const M gdx = (M)dax, gdy = (M)day;
-        ob[2] = cs * gdx + sn * gdy;
-        ob[3] = -sn * gdx + cs * gdy;
+        const M c = (M)cs, s_ = (M)sn;
+        ob[0] = c * velx + s_ * vely;  // R(theta)^T * velocity: lagged velocity, final heading (App. A K5)
+        ob[1] = -s_ * velx + c * vely;
     }
+    ob[2] = (M)(cs * dax + sn * day);  // R(theta)^T (goal - p)
+    ob[3] = (M)(-sn * dax + cs * day);
     const M range = (M)P.sonar_range;
-    // obstacle centres relative to the robot, once per obstacle (f64 subtraction, then M)
-    M omx[MN_MAX_OBS], omy[MN_MAX_OBS], orr[MN_MAX_OBS];
+    // obstacle centres in the robot frame, once per obstacle
+    double mrx[MN_MAX_OBS], mry[MN_MAX_OBS], orr2[MN_MAX_OBS];
 #pragma unroll
     for (int k = 0; k < MN_MAX_OBS; ++k) {
-        omx[k] = (M)(tab[OB + k][lane] - x);
-        omy[k] = (M)(tab[OB + MN_MAX_OBS + k][lane] - y);
-        orr[k] = (M)tab[OB + 2 * MN_MAX_OBS + k][lane];
+        const double mx = tab[OB + k][lane] - x, my = tab[OB + MN_MAX_OBS + k][lane] - y;
+        const double r = tab[OB + 2 * MN_MAX_OBS + k][lane];
+        mrx[k] = cs * mx + sn * my;
+        mry[k] = -sn * mx + cs * my;
+        orr2[k] = r * r;
     }
     const double half_pi = 0.5 * 3.141592653589793, three_half_pi = 3 * 3.141592653589793 / 2;
 #pragma unroll
@@ -126,24 +130,25 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
         const double angle = theta + P.beam_rel[b];  // robot.py:134, not wrapped
         const bool up = fabs(angle - half_pi) < 1e-03;
         const bool down = fabs(angle - three_half_pi) < 1e-03;
-        // beam direction in the robot frame is the constant (cos rel, sin rel); world = R(theta) * that
-        const M brc = (M)P.beam_cos[b], brs = (M)P.beam_sin[b];
-        M dx = cs * brc - sn * brs, dy = sn * brc + cs * brs;
-        // hit point in the robot frame = t * R^T d ; for a snapped beam R^T (0,+-1) = +-(sin, cos)
-        M rx = brc, ry = brs;
+        // beam direction in the robot frame: the constant (cos rel, sin rel); a snapped beam points
+        // along world (0,+-1), i.e. R^T (0,+-1) = +-(sin theta, cos theta)
+        double bx = P.beam_cos[b], by = P.beam_sin[b];
         if (up || down) {
-            const M sg = up ? M(1) : M(-1);
-            dx = M(0); dy = sg;
-            rx = sg * sn; ry = sg * cs;
+            const double sg = up ? 1.0 : -1.0;
+            bx = sg * sn; by = sg * cs;
         }
         bool hit = false, stopped = false;
         M dist = M(0);
 #pragma unroll
         for (int k = 0; k < MN_MAX_OBS; ++k) {
-            if (k < no) mn_beam_obstacle<M>(omx[k], omy[k], orr[k], dx, dy, range, hit, dist, stopped);
+            if (k < no) {
+                double tc, h2;
+                mn_beam_geom(mrx[k], mry[k], orr2[k], bx, by, tc, h2);
+                mn_beam_update<M>((M)tc, (M)h2, range, hit, dist, stopped);
+            }
         }
-        ob[4 + 2 * b] = hit ? dist * rx : M(0);  // misses are (0,0): marinenav_env.py:315-316
-        ob[5 + 2 * b] = hit ? dist * ry : M(0);
+        ob[4 + 2 * b] = hit ? dist * (M)bx : M(0);  // misses are (0,0): marinenav_env.py:315-316
+        ob[5 + 2 * b] = hit ? dist * (M)by : M(0);
     }
 
     // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
