@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/sec of the batched marinenav_env + IQN training loop on MI355X.
+
+One "step" = one vector step of the hot path on one GPU: IQN act (K = 32 quantile samples) for
+65 536 envs -> HIP step kernel -> replay append -> HIP reset of finished envs -> (every 4th vector
+step) one IQN grad step (batch 256, 8 quantiles, replay 100 000).  This is BASELINE.json configs[2],
+the configuration its metric is quoted on.  With --gpus N every rank runs the same per-GPU workload
+on its own env shard (weak scaling; no data-path collective; --shared-learner adds the RCCL gradient
+all-reduce of configs[4]).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the HIP step kernel (HBM-bound by north-star):
+achieved = 406 B/env-step (SURVEY 8d, 8 cores + 10 obstacles) x envs per launch / mean launch
+duration, measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` is
+the scalar C oracle (oracle/, a port) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ENV_STEP = {(8, 10): 406, (8, 5): 346, (4, 6): 310}   # 190 + 12 * (n_cores + n_obs)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_steps, world):
+    """Scalar float64 oracle (oracle/marinenav_oracle.c), one host thread, resets included."""
+    import numpy as np
+    from oracle.oracle import OracleEnv
+    env = OracleEnv(0)
+    env.set_world_size(*world)
+    env.reset()
+    actions = np.random.RandomState(1000).randint(9, size=n_steps).astype(np.int32)
+    t0 = time.perf_counter()
+    env.rollout(actions)
+    dt = time.perf_counter() - t0
+    return n_steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--replay", type=int, default=100_000)
+    ap.add_argument("--cores", type=int, default=8)
+    ap.add_argument("--obstacles", type=int, default=10)
+    ap.add_argument("--shared-learner", action="store_true", help="one IQN, RCCL grad all-reduce (configs[4])")
+    ap.add_argument("--cvar", type=float, default=1.0)
+    ap.add_argument("--no-learner", action="store_true", help="random policy, step kernel only (configs[1])")
+    ap.add_argument("--cpu-steps", type=int, default=4_000_000, help="oracle sample for cpu_baseline (0 = skip)")
+    ap.add_argument("--act-chunk", type=int, default=8192)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.envs
+    min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
+    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed")
+    env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis)
+    obs = env.reset()
+    agent = None
+    if not args.no_learner:
+        agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device=device,
+                         seed=100 if args.shared_learner else 100 + rank, learning_starts=0,
+                         distributed=args.shared_learner and world > 1, act_chunk=args.act_chunk)
+    total_timesteps = 3_000_000 * n * world      # eps stays on the reference's initial 10 % ramp
+    gen = torch.Generator(device=device)
+    gen.manual_seed(rank)
+
+    def one_step(o):
+        if agent is None:
+            a = torch.randint(0, 9, (n,), device=device, dtype=torch.int32, generator=gen)
+            env.step(a)
+            return env.reset_done()
+        eps = agent.linear_eps(total_timesteps)
+        return agent.vec_step(env, o, eps, args.cvar, per_iter=n * world)[0]
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        obs = one_step(obs)
+    g0 = agent.grad_steps if agent else 0
+    fence()
+    env.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obs = one_step(obs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    step_kernel_ms, launches = env.profile_end()
+    grad_steps = (agent.grad_steps - g0) if agent else 0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        env_steps = n * world * args.steps
+        bytes_per = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
+        achieved = bytes_per * n / (step_kernel_ms * 1e-3) / 1e9 if step_kernel_ms > 0 else 0.0
+        out = {
+            "metric": "env steps/sec (whole node) at 65 536 envs; IQN grad-steps/sec",
+            "value": env_steps / elapsed,
+            "unit": "env steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 pose + f32 field/sonar (env kernel), f32 (IQN)",
+            "data": "synthetic (seeded random worlds, random-init IQN)",
+            "config": {
+                "workload": ("step kernel only, random policy" if agent is None else
+                             f"{n} envs/GPU + IQN training (act K=32, 8 quantiles, replay {args.replay}, batch {args.batch}, "
+                             f"train every 4 vector steps)"),
+                "envs_per_gpu": n, "n_cores": args.cores, "n_obstacles": args.obstacles,
+                "learner": "none" if agent is None else ("shared, RCCL grad all-reduce" if args.shared_learner else "independent per GPU"),
+                "cvar": args.cvar,
+            },
+            "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
+            "roofline": {
+                "kernel": "mn_step_kernel<float,false>",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_env_step": bytes_per,
+                "launch_ms": step_kernel_ms,
+                "launches_timed": launches,
+                "kernel_only_env_steps_per_sec": n / (step_kernel_ms * 1e-3) if step_kernel_ms > 0 else None,
+            },
+        }
+        if args.cpu_steps > 0:
+            v, dt = cpu_baseline(args.cpu_steps, (args.cores, args.obstacles, min_dis))
+            out["cpu_baseline"] = {
+                "value": v, "unit": "env steps/s", "cores": 1, "kind": "port",
+                "sample": f"{args.cpu_steps} steps of one env (oracle/marinenav_oracle.c, float64 scalar), "
+                          f"{args.cores} cores / {args.obstacles} obstacles, random actions, resets included, {dt:.1f} s",
+                "host_cpus": os.cpu_count(),
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,7 @@ SIGNATURES = [
     ("mn_get_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
     ("mn_set_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
     ("mn_get_obs64", C.c_int, [_vp, _i32, _i32, _pd]),
+    ("mn_get_reward64", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_peek_next_double", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_last_done_count", C.c_int, [_vp, _vp, _pi32]),
     ("mn_profile_begin", C.c_int, [_vp, _i32]),

@@ -151,7 +151,7 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     ALLOC(ox, np * MN_MAX_OBS) ALLOC(oy, np * MN_MAX_OBS) ALLOC(orad, np * MN_MAX_OBS)
     ALLOC(mt, np * 624) ALLOC(mt_pos, np)
     ALLOC(queue_count, 2) ALLOC(queue, np)
-    if (p->precision == MN_PRECISION_F64) { ALLOC(obs64, np * MN_OBS_DIM) }
+    if (p->precision == MN_PRECISION_F64) { ALLOC(obs64, np * MN_OBS_DIM) ALLOC(rew64, np) }
 #undef ALLOC
     if ((rc = dev_alloc(h, &h->seeds_dev, np)) || (rc = dev_alloc(h, &h->mask_count, 1)) ||
         (rc = dev_alloc(h, &h->list_scratch, np)) || (rc = dev_alloc(h, &h->peek_scratch, np))) {
@@ -424,6 +424,16 @@ extern "C" int mn_get_obs64(mn_handle *h, int32_t first, int32_t count, double *
     if (!h->A.obs64) return fail(h, MN_ERR_INVALID, "float64 observations are kept only with MN_PRECISION_F64");
     MN_HIP(h, hipDeviceSynchronize());
     MN_HIP(h, hipMemcpy(out, h->A.obs64 + (size_t)first * MN_OBS_DIM, (size_t)count * MN_OBS_DIM * 8, hipMemcpyDeviceToHost));
+    return MN_OK;
+}
+
+extern "C" int mn_get_reward64(mn_handle *h, int32_t first, int32_t count, double *out) {
+    int rc = range_ok(h, first, count);
+    if (rc) return rc;
+    if (!out) return MN_ERR_INVALID;
+    if (!h->A.rew64) return fail(h, MN_ERR_INVALID, "float64 rewards are kept only with MN_PRECISION_F64");
+    MN_HIP(h, hipDeviceSynchronize());
+    MN_HIP(h, hipMemcpy(out, h->A.rew64 + first, (size_t)count * 8, hipMemcpyDeviceToHost));
     return MN_OK;
 }
 

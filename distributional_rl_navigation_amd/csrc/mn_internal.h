@@ -28,6 +28,7 @@ struct MnArrays {
     int32_t *mt_pos;
     // float64 copy of the observations (parity precision only), [npad][26]
     double *obs64;
+    double *rew64;  // float64 copy of the last reward (parity precision only), [npad]
     // done-queue filled by the step kernel, drained by the reset kernel
     uint32_t *queue_count;  // [2], alternating per step
     int32_t *queue;         // [npad]

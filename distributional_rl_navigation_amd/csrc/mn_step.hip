@@ -184,6 +184,7 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
         done_out[e] = (uint8_t)done;
         info_out[e] = (uint8_t)info;
         if (PARITY) {
+            A.rew64[e] = reward;
 #pragma unroll
             for (int j = 0; j < MN_OBS_DIM; ++j) A.obs64[(size_t)e * MN_OBS_DIM + j] = (double)ob[j];
         }

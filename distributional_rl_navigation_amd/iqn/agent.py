@@ -1,0 +1,413 @@
+"""IQN agent: batched act / learn around the HIP vector env.
+
+Keeps the reference's `IQNAgent` surface (thirdparty/IQN/agent.py:10-407: constructor keywords,
+act / act_eval / act_adaptive / adjust_cvar / train / soft_update / evaluation / load_model /
+learn) and adds the batched counterparts that the MI355X path actually runs:
+`act_batch`, `learn_vec`, `evaluation_vec`.  Optional data-parallel training over RCCL:
+one flat 35 785-float gradient bucket, one all_reduce per grad step.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from .model import ObsEncoder
+from .replay_buffer import ReplayBuffer
+
+
+def calculate_huber_loss(td_errors, k=1.0):
+    """agent.py:401-407, element-wise Huber with threshold k."""
+    return torch.where(td_errors.abs() <= k, 0.5 * td_errors.pow(2), k * (td_errors.abs() - 0.5 * k))
+
+
+class IQNAgent:
+    def __init__(self, state_size, action_size, layer_size=64, n_step=1, BATCH_SIZE=32, BUFFER_SIZE=1_000_000,
+                 LR=1e-4, TAU=1.0, GAMMA=0.99, UPDATE_EVERY=4, learning_starts=10000, target_update_interval=10000,
+                 exploration_fraction=0.1, initial_eps=1.0, final_eps=0.05, device="cpu", seed=0,
+                 distributed=False, act_chunk=8192):
+        self.state_size = state_size
+        self.action_size = action_size
+        self.device = torch.device(device)
+        self.LR, self.TAU, self.GAMMA = LR, TAU, GAMMA
+        self.UPDATE_EVERY = UPDATE_EVERY
+        self.BATCH_SIZE = BATCH_SIZE
+        self.n_step = n_step
+        self.learning_starts = learning_starts
+        self.target_update_interval = target_update_interval
+        self.exploration_fraction = exploration_fraction
+        self.initial_eps, self.final_eps = initial_eps, final_eps
+        self.N = 8                                   # train-time quantile samples (agent.py:286,290)
+        self.act_chunk = act_chunk
+
+        self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
+        self.qnetwork_target = ObsEncoder(state_size, action_size, seed, device)   # identical init (App. A A1)
+        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR)
+        self.memory = ReplayBuffer(BUFFER_SIZE, BATCH_SIZE, device, seed, GAMMA, n_step, state_size)
+        random.seed(seed)                            # replay_buffer.py:21 seeds python `random` (eps-greedy)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) + 12345)
+
+        self.current_timestep = 0
+        self.learning_timestep = 0
+        self.grad_steps = 0
+        self.distributed = bool(distributed)
+        self._flat = None
+
+        self.eval_timesteps = dict(greedy=[], adaptive=[])
+        self.eval_actions = dict(greedy=[], adaptive=[])
+        self.eval_rewards = dict(greedy=[], adaptive=[])
+        self.eval_successes = dict(greedy=[], adaptive=[])
+        self.eval_times = dict(greedy=[], adaptive=[])
+        self.eval_energies = dict(greedy=[], adaptive=[])
+
+    # ---- checkpoints ---------------------------------------------------------------------------
+    def load_model(self, path, device="cpu"):
+        """agent.py:86-92."""
+        self.qnetwork_local = ObsEncoder.load(path, device)
+        self.qnetwork_target = ObsEncoder.load(path, device)
+        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR)
+        self.device = torch.device(device)
+
+    # ---- schedules -----------------------------------------------------------------------------
+    def linear_eps(self, total_timesteps):
+        """agent.py:176-183."""
+        progress = self.current_timestep / total_timesteps
+        if progress < self.exploration_fraction:
+            r = progress / self.exploration_fraction
+            return self.initial_eps + r * (self.final_eps - self.initial_eps)
+        return self.final_eps
+
+    def adjust_cvar(self, state):
+        """agent.py:249-267: cvar = min(1, closest sonar return / 10)."""
+        sonar_points = state[4:]
+        closest_d = np.inf
+        for i in range(0, len(sonar_points), 2):
+            x, y = sonar_points[i], sonar_points[i + 1]
+            if np.abs(x) < 1e-3 and np.abs(y) < 1e-3:
+                continue
+            closest_d = min(closest_d, np.linalg.norm(sonar_points[i:i + 2]))
+        cvar = 1.0
+        if closest_d < 10.0:
+            cvar = closest_d / 10.0
+        return cvar
+
+    def adjust_cvar_batch(self, states):
+        """Batched adjust_cvar on device: states [n, 26] -> cvar [n]."""
+        p = states[:, 4:].view(states.shape[0], -1, 2)
+        skip = (p[:, :, 0].abs() < 1e-3) & (p[:, :, 1].abs() < 1e-3)
+        d = torch.linalg.vector_norm(p, dim=2).masked_fill(skip, float("inf"))
+        closest = d.min(dim=1).values
+        return torch.where(closest < 10.0, closest / 10.0, torch.ones_like(closest))
+
+    # ---- acting --------------------------------------------------------------------------------
+    def act(self, state, eps, cvar=1.0):
+        """agent.py:186-205, one state (numpy) -> python int."""
+        state = torch.from_numpy(np.asarray(state)).float().unsqueeze(0).to(self.device)
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            action_values = self.qnetwork_local.get_qvals(state, cvar)
+        self.qnetwork_local.train()
+        if random.random() > eps:
+            return int(np.argmax(action_values.cpu().data.numpy()))
+        return int(random.choice(np.arange(self.action_size)))
+
+    def act_adaptive(self, state, eps):
+        cvar = self.adjust_cvar(state)
+        return self.act(state, eps, cvar), cvar
+
+    def act_eval(self, state, eps=0.0, cvar=1.0):
+        """agent.py:217-236: action + the K quantiles and taus behind it."""
+        state = torch.from_numpy(np.asarray(state)).float().unsqueeze(0).to(self.device)
+        self.qnetwork_local.eval()
+        with torch.no_grad():
+            quantiles, taus = self.qnetwork_local.forward(state, self.qnetwork_local.K, cvar)
+            action_values = quantiles.mean(dim=1)
+        self.qnetwork_local.train()
+        if random.random() > eps:
+            action = int(np.argmax(action_values.cpu().data.numpy()))
+        else:
+            action = int(random.choice(np.arange(self.action_size)))
+        return action, quantiles.cpu().data.numpy(), taus.cpu().data.numpy()
+
+    def act_adaptive_eval(self, state, eps=0.0):
+        cvar = self.adjust_cvar(state)
+        return self.act_eval(state, eps, cvar), cvar
+
+    @torch.no_grad()
+    def qvals_batch(self, states, cvar=1.0):
+        """Q(s, .) = mean over K = 32 quantile samples, for a whole vector of states (device tensor).
+        Chunked over envs so the [chunk*K, 208] activations stay cache-resident."""
+        n = states.shape[0]
+        out = torch.empty(n, self.action_size, dtype=torch.float32, device=states.device)
+        step = self.act_chunk
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            c = cvar[lo:hi] if torch.is_tensor(cvar) else cvar
+            out[lo:hi] = self.qnetwork_local.get_qvals(states[lo:hi], c)
+        return out
+
+    @torch.no_grad()
+    def act_batch(self, states, eps, cvar=1.0):
+        """Batched eps-greedy act (agent.py:186-205 per row): states [n,26] f32 on device ->
+        actions [n] int32 on device.  Exploration draws come from a device generator."""
+        q = self.qvals_batch(states, cvar)
+        greedy = q.argmax(dim=1).to(torch.int32)
+        if eps <= 0.0:
+            return greedy
+        n = states.shape[0]
+        u = torch.rand(n, device=states.device, generator=self.gen)
+        rnd = torch.randint(0, self.action_size, (n,), device=states.device, dtype=torch.int32, generator=self.gen)
+        return torch.where(u > eps, greedy, rnd)
+
+    # ---- learning ------------------------------------------------------------------------------
+    def _allreduce_grads(self):
+        import torch.distributed as dist
+        params = [p for p in self.qnetwork_local.parameters() if p.grad is not None]
+        grads = [p.grad for p in params]
+        if self._flat is None or self._flat.numel() != sum(g.numel() for g in grads):
+            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
+        torch.cat([g.reshape(-1) for g in grads], out=self._flat)
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)       # one 143 KB bucket over RCCL/xGMI
+        self._flat.div_(dist.get_world_size())
+        off = 0
+        for g in grads:
+            g.copy_(self._flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def compute_loss(self, experiences, taus_target=None, taus_local=None):
+        """Quantile-Huber TD loss of agent.py:276-295 (taus can be injected for tests)."""
+        states, actions, rewards, next_states, dones = experiences
+        B = states.shape[0]
+        with torch.no_grad():
+            Q_targets_next, _ = self.qnetwork_target(next_states, self.N, taus=taus_target)
+            Q_targets_next = Q_targets_next.max(2)[0].unsqueeze(1)                          # (B, 1, N)
+            Q_targets = rewards.unsqueeze(-1) + (self.GAMMA ** self.n_step * Q_targets_next * (1. - dones.unsqueeze(-1)))
+        Q_expected, taus = self.qnetwork_local(states, self.N, taus=taus_local)
+        Q_expected = Q_expected.gather(2, actions.unsqueeze(-1).expand(B, self.N, 1))
+        td_error = Q_targets - Q_expected                                                   # (B, N, N)
+        huber_l = calculate_huber_loss(td_error, 1.0)
+        quantil_l = abs(taus - (td_error.detach() < 0).float()) * huber_l / 1.0
+        loss = quantil_l.sum(dim=1).mean(dim=1)
+        return loss.mean()
+
+    def train(self, experiences, taus_target=None, taus_local=None):
+        """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor)."""
+        self.optimizer.zero_grad(set_to_none=False)
+        loss = self.compute_loss(experiences, taus_target, taus_local)
+        loss.backward()
+        if self.distributed:
+            self._allreduce_grads()          # average first, then clip: same as one big-batch learner
+        torch.nn.utils.clip_grad_norm_(self.qnetwork_local.parameters(), 0.5)
+        self.optimizer.step()
+        self.grad_steps += 1
+        return loss.detach()
+
+    def soft_update(self, local_model, target_model):
+        """agent.py:307-317 (TAU = 1.0 -> hard copy)."""
+        with torch.no_grad():
+            for tp, lp in zip(target_model.parameters(), local_model.parameters()):
+                tp.data.copy_(self.TAU * lp.data + (1.0 - self.TAU) * tp.data)
+
+    # ---- reference-shaped single-env loop (drop-in for train_IQN_model.py) -------------------------
+    def learn(self, total_timesteps, train_env, eval_env, eval_config, eval_freq, eval_log_path, verbose=True):
+        """agent.py:94-173 with a gym-shaped single env (the facade MarineNavEnv or the reference's)."""
+        state = train_env.reset()
+        ep_reward, ep_length, ep_num = 0.0, 0, 0
+        while self.current_timestep <= total_timesteps:
+            eps = self.linear_eps(total_timesteps)
+            action = self.act(state, eps)
+            next_state, reward, done, info = train_env.step(action)
+            ep_reward += train_env.discount ** ep_length * reward
+            ep_length += 1
+            self.memory.add(state, action, reward, next_state, done)
+            state = next_state
+            if self.current_timestep >= self.learning_starts:
+                if self.learning_timestep % self.UPDATE_EVERY == 0 and len(self.memory) > self.BATCH_SIZE:
+                    self.train(self.memory.sample())
+                if self.learning_timestep % self.target_update_interval == 0:
+                    self.soft_update(self.qnetwork_local, self.qnetwork_target)
+                if self.learning_timestep % eval_freq == 0 and eval_env is not None:
+                    self.evaluation(eval_env, eval_config=eval_config, eval_log_path=eval_log_path)
+                    self.evaluation(eval_env, eval_config=eval_config, greedy=False, eval_log_path=eval_log_path)
+                    if eval_log_path is not None:
+                        self.qnetwork_local.save(eval_log_path)
+                self.learning_timestep += 1
+            if done:
+                ep_num += 1
+                if verbose:
+                    print("======== training info ========")
+                    print("current ep_length: ", ep_length)
+                    print("current ep_reward: ", ep_reward)
+                    print("current ep_result: ", info["state"])
+                    print("episodes_num: ", ep_num)
+                    print("exploration_rate: ", eps)
+                    print("current_timesteps: ", self.current_timestep)
+                    print("total_timesteps: ", total_timesteps)
+                    print("======== training info ========\n")
+                ep_reward, ep_length = 0.0, 0
+                state = train_env.reset()
+            self.current_timestep += 1
+
+    def evaluation(self, eval_env, eval_config, greedy=True, eval_log_path=None):
+        """agent.py:319-398 with a gym-shaped single env."""
+        action_data, reward_data, success_data, time_data, energy_data = [], [], [], [], []
+        for idx, config in enumerate(eval_config.values()):
+            observation = eval_env.reset_with_eval_config(config)
+            actions, cumulative_reward, length, energy, done = [], 0.0, 0, 0.0, False
+            info = {"state": "normal"}
+            while not done and length < 1000:
+                if greedy:
+                    action = self.act(observation, eps=0.0)
+                else:
+                    action, _ = self.act_adaptive(observation, eps=0.0)
+                observation, reward, done, info = eval_env.step(action)
+                cumulative_reward += eval_env.discount ** length * reward
+                length += 1
+                energy += eval_env.robot.compute_action_energy_cost(int(action))
+                actions.append(int(action))
+            action_data.append(actions)
+            reward_data.append(cumulative_reward)
+            success_data.append(info["state"] == "reach goal")
+            time_data.append(eval_env.robot.dt * eval_env.robot.N * length)
+            energy_data.append(energy)
+        self._log_evaluation(greedy, action_data, reward_data, success_data, time_data, energy_data, eval_log_path)
+
+    # ---- batched loop on the HIP vector env ----------------------------------------------------------
+    def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,
+                  eval_log_path=None, total_timesteps=None, world_size=1, cvar=1.0, verbose=True,
+                  train_every=None, on_step=None):
+        """Vectorised agent.py:94-173.  One iteration = one vector step of `train_env` (n_envs env
+        steps): act_batch -> mn_step -> replay.add_batch -> mn_reset_done -> (every UPDATE_EVERY vector
+        steps) sample + train.  `current_timestep` counts env steps over all ranks, so eps, the
+        learning_starts gate and the curriculum keep the reference's meaning of "timesteps";
+        `learning_timestep` counts vector steps after learning_starts (UPDATE_EVERY,
+        target_update_interval and eval_freq are applied to it)."""
+        n = train_env.n_envs
+        per_iter = n * world_size
+        if total_timesteps is None:
+            total_timesteps = total_vector_steps * per_iter
+        train_every = self.UPDATE_EVERY if train_every is None else train_every
+        obs = train_env.reset()
+        ep_ret = torch.zeros(n, device=self.device)
+        ep_len = torch.zeros(n, device=self.device)
+        stats = dict(episodes=0, successes=0, collisions=0, timeouts=0, loss=None)
+        for it in range(total_vector_steps):
+            eps = self.linear_eps(total_timesteps)
+            prev_learning = self.learning_timestep
+            obs, reward, done, info, loss = self.vec_step(train_env, obs, eps, cvar, train_every, per_iter)
+            if loss is not None:
+                stats["loss"] = loss
+            if verbose:
+                ep_ret += (train_env.discount ** ep_len) * reward
+                ep_len += 1
+                d = done.bool()
+                stats["episodes"] += int(d.sum())
+                stats["successes"] += int((info == 4).sum())
+                stats["collisions"] += int((info == 3).sum())
+                stats["timeouts"] += int((info == 2).sum())
+                ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
+            if (eval_env is not None and eval_freq and self.learning_timestep != prev_learning
+                    and prev_learning % eval_freq == 0):
+                self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
+                self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
+                if eval_log_path is not None:
+                    self.qnetwork_local.save(eval_log_path)
+            if on_step is not None:
+                on_step(it, stats)
+        return stats
+
+    def vec_step(self, train_env, obs, eps, cvar=1.0, train_every=None, per_iter=None):
+        """One iteration of the vectorised loop: act_batch -> mn_step -> replay.add_batch ->
+        mn_reset_done -> (cadence permitting) sample + train + target sync.  Everything is enqueued on
+        the current HIP stream; nothing synchronises with the host.
+        Returns (obs for the next act, reward, done, info, loss or None)."""
+        train_every = self.UPDATE_EVERY if train_every is None else train_every
+        per_iter = train_env.n_envs if per_iter is None else per_iter
+        actions = self.act_batch(obs, eps, cvar)
+        next_obs, reward, done, info = train_env.step(actions)          # other half of the double buffer
+        self.memory.add_batch(obs, actions, reward, next_obs, done.float())   # terminal obs, before the reset
+        obs = train_env.reset_done()                                    # first observations where done
+        loss = None
+        if self.current_timestep >= self.learning_starts:
+            if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
+                loss = self.train(self.memory.sample())
+            if self.learning_timestep % self.target_update_interval == 0:
+                self.soft_update(self.qnetwork_local, self.qnetwork_target)
+            self.learning_timestep += 1
+        self.current_timestep += per_iter
+        return obs, reward, done, info, loss
+
+    @torch.no_grad()
+    def evaluation_vec(self, eval_env, eval_config, greedy=True, eval_log_path=None, max_steps=1000):
+        """agent.py:319-398 with all evaluation worlds stepped side by side on the GPU.
+        `eval_env` is a VecMarineNavEnv with n_envs == len(eval_config); the npz schema is unchanged."""
+        from ..marinenav_env.vec_env import VecMarineNavEnv
+        cfgs = list(eval_config.values())
+        n = len(cfgs)
+        assert eval_env.n_envs == n
+        r0 = cfgs[0]["robot"]
+        eval_env.set_attrs(N=r0["N"], dt=r0["dt"])
+        obs = eval_env.load_worlds([VecMarineNavEnv.world_from_eval_config(c) for c in cfgs]).clone()
+        a_tab = torch.tensor(r0["a"], device=self.device); w_tab = torch.tensor(r0["w"], device=self.device)
+        e_a = (a_tab / a_tab.max()).abs(); e_w = (w_tab / w_tab.max()).abs()
+        energy_tab = (e_a.view(3, 1) + e_w.view(1, 3)).reshape(-1)      # robot.py:72-77
+        alive = torch.ones(n, dtype=torch.bool, device=self.device)
+        ret = torch.zeros(n, dtype=torch.float64, device=self.device)
+        length = torch.zeros(n, dtype=torch.int64, device=self.device)
+        energy = torch.zeros(n, dtype=torch.float64, device=self.device)
+        last_info = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        acts = torch.full((max_steps, n), -1, dtype=torch.int32, device=self.device)
+        self.qnetwork_local.eval()
+        for t in range(max_steps):
+            cv = 1.0 if greedy else self.adjust_cvar_batch(obs)
+            a = self.act_batch(obs, 0.0, cv)
+            obs, reward, done, info = eval_env.step(a)
+            ret += torch.where(alive, (eval_env.discount ** t) * reward.double(), torch.zeros_like(ret))
+            length += alive.long()
+            energy += torch.where(alive, energy_tab[a.long()].double(), torch.zeros_like(energy))
+            acts[t] = torch.where(alive, a, torch.full_like(a, -1))
+            last_info = torch.where(alive, info, last_info)
+            alive = alive & ~done.bool()
+            if not bool(alive.any()):
+                break
+        self.qnetwork_local.train()
+        acts_h = acts.cpu().numpy(); length_h = length.cpu().numpy()
+        action_data = [[int(x) for x in acts_h[:length_h[i], i]] for i in range(n)]
+        reward_data = [float(x) for x in ret.cpu().numpy()]
+        success_data = [bool(x) for x in (last_info == 4).cpu().numpy()]
+        time_data = [float(r0["dt"] * r0["N"] * l) for l in length_h]
+        energy_data = [float(x) for x in energy.cpu().numpy()]
+        self._log_evaluation(greedy, action_data, reward_data, success_data, time_data, energy_data, eval_log_path)
+        return dict(rewards=reward_data, successes=success_data, times=time_data, energies=energy_data, actions=action_data)
+
+    def _log_evaluation(self, greedy, action_data, reward_data, success_data, time_data, energy_data, eval_log_path,
+                        verbose=True):
+        """agent.py:367-398: summary print + append + npz with the reference's keys."""
+        policy = "greedy" if greedy else "adaptive"
+        if verbose:
+            idx = np.where(np.array(success_data) == 1)[0]
+            avg_t = np.mean(np.array(time_data)[idx]) if len(idx) else float("nan")
+            avg_e = np.mean(np.array(energy_data)[idx]) if len(idx) else float("nan")
+            print(f"++++++++ Evaluation info ({policy} IQN) ++++++++")
+            print(f"Avg cumulative reward: {np.mean(reward_data):.2f}")
+            print(f"Success rate: {np.sum(success_data) / len(success_data):.2f}")
+            print(f"Avg time: {avg_t:.2f}")
+            print(f"Avg energy: {avg_e:.2f}")
+            print(f"++++++++ Evaluation info ({policy} IQN) ++++++++\n")
+        self.eval_timesteps[policy].append(self.current_timestep)
+        self.eval_actions[policy].append(action_data)
+        self.eval_rewards[policy].append(reward_data)
+        self.eval_successes[policy].append(success_data)
+        self.eval_times[policy].append(time_data)
+        self.eval_energies[policy].append(energy_data)
+        if eval_log_path is not None:
+            filename = "greedy_evaluations.npz" if greedy else "adaptive_evaluations.npz"
+            np.savez(os.path.join(eval_log_path, filename),
+                     timesteps=np.array(self.eval_timesteps[policy]),
+                     actions=np.array(self.eval_actions[policy], dtype=object),
+                     rewards=np.array(self.eval_rewards[policy]),
+                     successes=np.array(self.eval_successes[policy]),
+                     times=np.array(self.eval_times[policy]),
+                     energies=np.array(self.eval_energies[policy]))

@@ -1,0 +1,64 @@
+"""Device-resident replay memory (counterpart of thirdparty/IQN/replay_buffer.py:6-59).
+
+The reference keeps a deque of python tuples and stacks a batch on every sample; here the
+transitions live in HBM as a ring of tensors and a whole vector step (n_envs transitions) is
+appended with one indexed copy.  n_step = 1 only (the only value the reference ever uses).
+"""
+import torch
+
+
+class ReplayBuffer:
+    def __init__(self, buffer_size, batch_size, device, seed, gamma, n_step=1, state_size=26):
+        if n_step != 1:
+            raise NotImplementedError("n_step > 1 is never used by the reference training scripts")
+        self.device = torch.device(device)
+        self.capacity = int(buffer_size)
+        self.batch_size = int(batch_size)
+        self.gamma = gamma
+        self.n_step = n_step
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        c = self.capacity
+        self.states = torch.zeros(c, state_size, dtype=torch.float32, device=self.device)
+        self.next_states = torch.zeros(c, state_size, dtype=torch.float32, device=self.device)
+        self.actions = torch.zeros(c, 1, dtype=torch.int64, device=self.device)
+        self.rewards = torch.zeros(c, 1, dtype=torch.float32, device=self.device)
+        self.dones = torch.zeros(c, 1, dtype=torch.float32, device=self.device)
+        self.size = 0
+        self.ptr = 0
+
+    def add(self, state, action, reward, next_state, done):
+        """One transition (replay_buffer.py:26-34)."""
+        as_t = lambda x, dt: torch.as_tensor(x, dtype=dt, device=self.device)
+        self.add_batch(as_t(state, torch.float32).view(1, -1), as_t([action], torch.int64),
+                       as_t([reward], torch.float32), as_t(next_state, torch.float32).view(1, -1),
+                       as_t([float(done)], torch.float32))
+
+    def add_batch(self, states, actions, rewards, next_states, dones):
+        """n transitions at once; FIFO eviction like deque(maxlen)."""
+        n = states.shape[0]
+        if n > self.capacity:   # only the newest `capacity` survive
+            states, actions, rewards, next_states, dones = (t[-self.capacity:] for t in (states, actions, rewards, next_states, dones))
+            n = self.capacity
+        end = self.ptr + n
+        if end <= self.capacity:
+            sl = slice(self.ptr, end)
+            self.states[sl].copy_(states); self.next_states[sl].copy_(next_states)
+            self.actions[sl, 0].copy_(actions.view(-1)); self.rewards[sl, 0].copy_(rewards.view(-1))
+            self.dones[sl, 0].copy_(dones.view(-1))
+        else:
+            k = self.capacity - self.ptr
+            self.add_batch(states[:k], actions[:k], rewards[:k], next_states[:k], dones[:k])
+            self.add_batch(states[k:], actions[k:], rewards[k:], next_states[k:], dones[k:])
+            return
+        self.ptr = end % self.capacity
+        self.size = min(self.capacity, self.size + n)
+
+    def sample(self, batch_size=None):
+        """Uniform without replacement (random.sample, replay_buffer.py:47) -> float32 / int64 tensors."""
+        b = self.batch_size if batch_size is None else batch_size
+        idx = torch.randperm(self.size, device=self.device, generator=self.gen)[:b]
+        return (self.states[idx], self.actions[idx], self.rewards[idx], self.next_states[idx], self.dones[idx])
+
+    def __len__(self):
+        return self.size

@@ -62,7 +62,12 @@ class VecMarineNavEnv:
         if schedule is not None:
             self.set_schedule(schedule, timestep_scale)
         dev = self.device
-        self.obs = torch.zeros(self.n_envs, OBS_DIM, dtype=torch.float32, device=dev)
+        # observations are double-buffered: step() writes the half that does NOT hold the
+        # observations returned by the previous step()/reset(), so (obs_t, obs_t+1) are both
+        # resident for the replay append without a copy
+        self._obs_bufs = [torch.zeros(self.n_envs, OBS_DIM, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._cur = 0
+        self.obs = self._obs_bufs[0]
         self.reward = torch.zeros(self.n_envs, dtype=torch.float32, device=dev)
         self.done = torch.zeros(self.n_envs, dtype=torch.uint8, device=dev)
         self.info = torch.zeros(self.n_envs, dtype=torch.uint8, device=dev)
@@ -152,7 +157,9 @@ class VecMarineNavEnv:
     def step(self, actions):
         """MarineNavEnv.step for every env; no auto-reset (like the reference).
         Returns (obs [n,26] f32, reward [n] f32, done [n] u8, info [n] u8 code) -- device tensors
-        owned by the env and overwritten by the next call."""
+        owned by the env; reward/done/info are overwritten by the next call, obs by the one after."""
+        self._cur ^= 1
+        self.obs = self._obs_bufs[self._cur]
         a = actions
         if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device:
             a = a.to(device=self.device, dtype=torch.int32).contiguous()
@@ -269,6 +276,13 @@ class VecMarineNavEnv:
         out = np.zeros((cnt, OBS_DIM))
         torch.cuda.synchronize(self.device)
         self._check(self.L.mn_get_obs64(self.h, int(first_env), cnt, _np_ptr(out, C.c_double)))
+        return out
+
+    def get_reward64(self, first_env=0, count=None):
+        cnt = self.n_envs - first_env if count is None else count
+        out = np.zeros(cnt)
+        torch.cuda.synchronize(self.device)
+        self._check(self.L.mn_get_reward64(self.h, int(first_env), cnt, _np_ptr(out, C.c_double)))
         return out
 
     def peek_next_double(self, first_env=0, count=None):

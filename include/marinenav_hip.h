@@ -165,6 +165,8 @@ int mn_set_state(mn_handle *h, int32_t first_env, int32_t count, const double *s
 /* Float64 copy of the last observation each env produced (the reference returns float64,
  * marinenav_env.py:326).  Only kept when precision == MN_PRECISION_F64; out[count][26]. */
 int mn_get_obs64(mn_handle *h, int32_t first_env, int32_t count, double *out);
+/* Float64 copy of the last reward (marinenav_env.py:220-255 computes it in float64); same rule. */
+int mn_get_reward64(mn_handle *h, int32_t first_env, int32_t count, double *out);
 
 /* Next double each env's RandomState would return, without consuming it (test hook pinning the
  * RNG stream position; cf. np.random.RandomState.random_sample). */

@@ -133,6 +133,7 @@ def test_free_running_f64_vs_oracle(torch, size):
         env.step(torch.from_numpy(a).to(env.device))
         obs64 = env.get_obs64()
         rew = env.reward.cpu().numpy(); done = env.done.cpu().numpy(); info = env.info.cpu().numpy()
+        rew64 = env.get_reward64()
         st, ep, tot = env.get_state()
         env.reset_done()
         robs = env.get_obs64()
@@ -141,15 +142,14 @@ def test_free_running_f64_vs_oracle(torch, size):
             assert d == bool(done[i]) and inf == info[i], (t, i)
             s, oep, otot = o.get_state()
             assert oep == ep[i] and otot == tot[i]
-            worst = max(worst, np.abs(oo - obs64[i]).max(), abs(r - rew[i]) / 8.0, np.abs(s - st[i]).max())
+            worst = max(worst, np.abs(oo - obs64[i]).max(), abs(r - rew64[i]), np.abs(s - st[i]).max())
+            assert abs(r - rew[i]) <= 1e-5     # float32 copy of the reward
             if d:
                 n_done += 1
                 ro = o.reset()
                 worst = max(worst, np.abs(ro - robs[i]).max())
-        assert worst < 1e-6, (t, worst)   # reward is emitted as f32: |r| <= ~110 -> 8e-6 abs, scaled above
+        assert worst < 1e-8, (t, worst)
     assert n_done > 5
-    # the obs64 / pose error after whole episodes
-    assert worst < 1e-6
     # worlds after all those resets are still bit-identical (RNG streams never drifted)
     worlds = env.get_worlds()
     peek = env.peek_next_double()
@@ -255,7 +255,7 @@ def test_g6_pretrained_replay_on_device(torch, policy):
     for t in range(int(L.max())):
         a = np.where(acts[:, t] >= 0, acts[:, t], 0).astype(np.int32)
         env.step(torch.from_numpy(a).to(env.device))
-        r = env.reward.cpu().numpy().astype(np.float64); d = env.done.cpu().numpy().astype(bool)
+        r = env.get_reward64(); d = env.done.cpu().numpy().astype(bool)
         inf = env.info.cpu().numpy()
         live = alive & (t < L)
         ret[live] += 0.99 ** t * r[live]
@@ -265,8 +265,10 @@ def test_g6_pretrained_replay_on_device(torch, policy):
     assert np.array_equal(length, L)
     assert np.array_equal(last_info == 4, z[f"{policy}_success"])
     np.testing.assert_allclose(0.1 * 10 * length, z[f"{policy}_time"], atol=1e-9)
-    # rewards leave the kernel as float32 (|r| <= 110): 1e-3 on a <=1000-term discounted sum
-    np.testing.assert_allclose(ret, z[f"{policy}_reward"], rtol=0, atol=2e-3)
+    # float64 rewards: the reference's stored returns come back to 1e-9 (1e-6 on the 1000-step
+    # episodes, where libm-level differences are amplified by the chaotic flow -- SURVEY section 4)
+    tol = np.where(L > 600, 1e-6, 1e-9)
+    assert (np.abs(ret - z[f"{policy}_reward"]) <= tol).all(), np.abs(ret - z[f"{policy}_reward"]).max()
     env.close()
 
 
