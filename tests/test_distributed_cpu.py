@@ -1,0 +1,71 @@
+"""World-size-2 gloo tests (CPU) of the N>1 path: the flat-bucket gradient all-reduce of the shared
+learner, and the env-shard index arithmetic."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _batch(seed, B=32):
+    g = np.random.RandomState(seed)
+    return (torch.from_numpy(g.normal(0, 5, (B, 26)).astype(np.float32)),
+            torch.from_numpy(g.randint(9, size=(B, 1)).astype(np.int64)),
+            torch.from_numpy(g.normal(0, 3, (B, 1)).astype(np.float32)),
+            torch.from_numpy(g.normal(0, 5, (B, 26)).astype(np.float32)),
+            torch.from_numpy((g.uniform(size=(B, 1)) < 0.2).astype(np.float32)))
+
+
+def _taus(seed, B=32):
+    g = np.random.RandomState(1000 + seed)
+    return torch.from_numpy(g.uniform(size=(B, 8)).astype(np.float32)), torch.from_numpy(g.uniform(size=(B, 8)).astype(np.float32))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, seed=3, distributed=True)
+    for step in range(3):
+        tt, tl = _taus(10 * step + rank)
+        agent.train(_batch(10 * step + rank), taus_target=tt, taus_local=tl)
+    flat = torch.cat([p.detach().reshape(-1) for p in agent.qnetwork_local.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1]))), out)
+    dist.destroy_process_group()
+
+
+def test_shared_learner_allreduce_equals_big_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["same"], "ranks diverged: all-reduced gradients must keep shared learners identical"
+    # single-process equivalent: loss = mean over the union of both ranks' batches = mean of the two
+    # per-rank mean losses, so averaged per-rank gradients == gradients of the 64-row batch
+    ref = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=64, seed=3)
+    for step in range(3):
+        b0, b1 = _batch(10 * step), _batch(10 * step + 1)
+        (t0, l0), (t1, l1) = _taus(10 * step), _taus(10 * step + 1)
+        exp = tuple(torch.cat([a, b]) for a, b in zip(b0, b1))
+        ref.train(exp, taus_target=torch.cat([t0, t1]), taus_local=torch.cat([l0, l1]))
+    flat = torch.cat([p.detach().reshape(-1) for p in ref.qnetwork_local.parameters()])
+    np.testing.assert_allclose(res["params"].numpy(), flat.numpy(), rtol=0, atol=2e-6)
+
+
+def test_shard_seed_arithmetic():
+    """Rank r owns global env indices [r*n, (r+1)*n): its default seeds are that slice of a 1-GPU run."""
+    n, world, base = 8, 4, 5
+    full = (np.arange(n * world, dtype=np.uint64) + np.uint64(base)) & np.uint64(0xFFFFFFFF)
+    for r in range(world):
+        shard = (np.arange(n, dtype=np.uint64) + np.uint64(base) + np.uint64(r * n)) & np.uint64(0xFFFFFFFF)
+        assert np.array_equal(shard, full[r * n:(r + 1) * n])
