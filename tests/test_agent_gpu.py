@@ -75,7 +75,7 @@ def test_pretrained_policy_batched_evaluation(torch, tmp_path):
         assert sum(res["successes"]) >= 22, res["successes"]
         assert np.mean(res["rewards"]) > 40.0
     z = np.load(os.path.join(tmp_path, "greedy_evaluations.npz"), allow_pickle=True)
-    assert sorted(z.files) == ["actions", "energies", "rewards", "successes", "timesteps", "times"]
+    assert sorted(z.files) == ["actions", "energies", "rewards", "successes", "times", "timesteps"]
     assert z["rewards"].shape == (1, 30) and z["actions"].shape == (1, 30)
     L = len(z["actions"][0][0])
     assert abs(z["times"][0][0] - 0.1 * 10 * L) < 1e-9
