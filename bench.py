@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--no-learner", action="store_true", help="random policy, step kernel only (configs[1])")
     ap.add_argument("--cpu-steps", type=int, default=4_000_000, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
+    ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per env in the step kernel (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -75,8 +77,8 @@ def main():
 
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
-    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed")
-    env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis)
+    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed", step_lanes=args.lanes)
+    env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
     obs = env.reset()
     agent = None
     if not args.no_learner:

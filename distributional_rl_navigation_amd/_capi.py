@@ -26,7 +26,7 @@ class MnParams(C.Structure):
         ("sonar_angle", C.c_double), ("num_cores", C.c_int32), ("num_obs", C.c_int32),
         ("reset_start_and_goal", C.c_int32), ("random_reset_state", C.c_int32), ("set_boundary", C.c_int32),
         ("max_episode_steps", C.c_int32), ("N", C.c_int32), ("num_beams", C.c_int32), ("precision", C.c_int32),
-        ("reserved", C.c_int32),
+        ("step_lanes", C.c_int32),
     ]
 
 

@@ -1,6 +1,7 @@
 // mn_capi.hip -- C-ABI host side of libmarinenav_hip.so (see include/marinenav_hip.h).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -68,6 +69,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     if (p.num_obs < 0 || p.num_obs > MN_MAX_OBS) return fail(h, MN_ERR_INVALID, "num_obs out of [0, 10]");
     if (p.N < 1 || p.N > 1000) return fail(h, MN_ERR_INVALID, "robot N out of range");
     if (p.precision != MN_PRECISION_F64 && p.precision != MN_PRECISION_MIXED) return fail(h, MN_ERR_INVALID, "bad precision");
+    if (p.step_lanes != 0 && p.step_lanes != 1 && p.step_lanes != 2 && p.step_lanes != 4 && p.step_lanes != 8) return fail(h, MN_ERR_INVALID, "step_lanes must be 0 (default), 1, 2, 4 or 8");
     MnDev &d = h->P;
     const int32_t keep_n = d.n_stages;
     d.width = p.width; d.height = p.height; d.core_r = p.core_r; d.v_rel_max = p.v_rel_max; d.p = p.p;
@@ -78,7 +80,10 @@ static int derive(mn_handle *h, const mn_params &p) {
     d.min_start_goal_dis = p.min_start_goal_dis; d.init_theta = p.init_theta; d.init_speed = p.init_speed;
     d.dt = p.dt; d.robot_r = p.robot_r; d.max_speed = p.max_speed;
     double amax = p.a[0];
-    for (int i = 0; i < 3; ++i) { d.a[i] = p.a[i]; d.w[i] = p.w[i]; if (p.a[i] > amax) amax = p.a[i]; }
+    for (int i = 0; i < 3; ++i) {
+        d.a[i] = p.a[i]; d.w[i] = p.w[i]; if (p.a[i] > amax) amax = p.a[i];
+        d.rot_c[i] = cos(p.w[i] * p.dt); d.rot_s[i] = sin(p.w[i] * p.dt);
+    }
     d.k_drag = amax / p.max_speed;  // robot.py:52
     d.sonar_range = p.sonar_range;
     const double phi = p.sonar_angle / (p.num_beams - 1);  // robot.py:14-21
@@ -100,6 +105,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     d.random_reset_state = p.random_reset_state; d.set_boundary = p.set_boundary;
     d.max_episode_steps = p.max_episode_steps; d.N = p.N;
     d.n_stages = keep_n;
+    { const char *dbg = getenv("MN_DEBUG_SKIP"); d.debug_skip = dbg ? atoi(dbg) : 0; }
     h->params = p;
     return MN_OK;
 }
@@ -136,7 +142,7 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     if (rc) { g_create_err = h->err; delete h; return rc; }
     MnArrays &A = h->A;
     A.n = n_envs;
-    A.npad = (n_envs + MN_WAVE - 1) / MN_WAVE * MN_WAVE;
+    A.npad = (n_envs + MN_PAD - 1) / MN_PAD * MN_PAD;
     const size_t np = (size_t)A.npad;
 #define ALLOC(field, count)                                    \
     if ((rc = dev_alloc(h, &A.field, (count))) != MN_OK) {      \
@@ -149,6 +155,8 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     ALLOC(ep_t, np) ALLOC(tot_t, np) ALLOC(counts, np)
     ALLOC(cx, np * MN_MAX_CORES) ALLOC(cy, np * MN_MAX_CORES) ALLOC(cg, np * MN_MAX_CORES)
     ALLOC(ox, np * MN_MAX_OBS) ALLOC(oy, np * MN_MAX_OBS) ALLOC(orad, np * MN_MAX_OBS)
+    ALLOC(qcx, np * MN_MAX_CORES) ALLOC(qcy, np * MN_MAX_CORES) ALLOC(qcg, np * MN_MAX_CORES)
+    ALLOC(qox, np * MN_MAX_OBS) ALLOC(qoy, np * MN_MAX_OBS) ALLOC(qor, np * MN_MAX_OBS)
     ALLOC(mt, np * 624) ALLOC(mt_pos, np)
     ALLOC(queue_count, 2) ALLOC(queue, np)
     if (p->precision == MN_PRECISION_F64) { ALLOC(obs64, np * MN_OBS_DIM) ALLOC(rew64, np) }
@@ -254,7 +262,7 @@ extern "C" int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev,
     const int parity = h->step_parity;
     const bool prof = h->prof_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev[2 * h->prof_n], s);
-    mn_launch_step(h->A, h->P, h->params.precision, actions_dev, obs_dev, reward_dev, done_dev, info_dev, parity, s);
+    mn_launch_step(h->A, h->P, h->params.precision, h->params.step_lanes, actions_dev, obs_dev, reward_dev, done_dev, info_dev, parity, s);
     if (prof) { (void)hipEventRecord(h->ev[2 * h->prof_n + 1], s); h->prof_n++; }
     MN_HIP(h, hipGetLastError());
     h->last_parity = parity;

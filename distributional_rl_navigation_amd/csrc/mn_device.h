@@ -34,21 +34,28 @@ __device__ __forceinline__ void mn_beam_geom(double mrx, double mry, double r2, 
     h2 = r2 - perp * perp;
 }
 
-//   h2 < 0                             -> no real solution          (robot.py:156,175 `continue`)
+// Per-beam scan state: `dist` = accepted range (valid when hit), `limit` = what the next candidate
+// must beat: +inf before the first hit, the accepted range afterwards, -inf once the reference's
+// `break` has fired (nothing can be accepted any more).
+//   h2 < 0                             -> no real solution          (robot.py:156,175 `continue`):
+//                                         sqrt gives NaN, every comparison below is false
 //   nearer root t = t_c -/+ h          (robot.py:184 picks the root with the smaller |t|)
 //   |t| > range or t < 0               -> `continue`               (robot.py:185,188)
 //   already hit and t >= best          -> `break`: later obstacles are never examined (:192-195)
 template <typename M>
-__device__ __forceinline__ void mn_beam_update(M tc, M h2, M range, bool &hit, M &dist, bool &stopped) {
-    M h = MnMath<M>::sqrt_(h2 > M(0) ? h2 : M(0));
-    M t = tc > M(0) ? tc - h : tc + h;
-    bool cand = (!stopped) && (h2 >= M(0)) && (t >= M(0)) && (t <= range);
-    bool brk = cand && hit && (t >= dist);
-    bool acc = cand && !brk;
-    stopped = stopped || brk;
-    dist = acc ? t : dist;
-    hit = hit || acc;
-}
+struct MnBeam {
+    M dist, limit;
+    __device__ __forceinline__ void init() { dist = M(0); limit = (M)INFINITY; }
+    __device__ __forceinline__ bool hit() const { return limit != (M)INFINITY; }
+    __device__ __forceinline__ void update(M tc, M h2, M range) {
+        const M h = MnMath<M>::sqrt_(h2);
+        const M t = tc > M(0) ? tc - h : tc + h;
+        const bool in_range = (t >= M(0)) && (t <= range);
+        const bool acc = in_range && (t < limit);
+        dist = acc ? t : dist;
+        limit = in_range ? (acc ? t : -(M)INFINITY) : limit;
+    }
+};
 
 // Rankine vortex contribution of one core at relative position (dx,dy) = core - point
 // (marinenav_env.py:433-453,461-465).  tangent*speed = (-dy,dx)/d * Gamma/(2 pi d) outside the

@@ -6,11 +6,14 @@
 #include "marinenav_hip.h"
 
 #define MN_WAVE 64
+#define MN_PAD 256
+#define MN_FIX_SCALE 16777216.0            // 2^24
+#define MN_FIX_INV (1.0 / 16777216.0)
 #define MN_TAB_ROWS (3 * MN_MAX_CORES + 3 * MN_MAX_OBS)
 
 // Device-resident state.  Everything is struct-of-arrays with the env index fastest, padded to a
 // multiple of 64 envs (one wavefront tile), so lane i of a wave touches element base+i of every
-// array: each load/store instruction of the step kernel moves one contiguous 256/512-byte run.
+// array.  npad is a multiple of 256 so that any lanes-per-env setting fills whole workgroups.
 struct MnArrays {
     int32_t n, npad;
     // robot pose (robot.py:40-44); kept in float64 in both precisions
@@ -23,6 +26,11 @@ struct MnArrays {
     // world tables, [k][npad], generation order (order matters for the sonar `break` quirk)
     double *cx, *cy, *cg;    // cg = +Gamma if clockwise else -Gamma
     double *ox, *oy, *orad;
+    // compact copy of the tables read by the mixed-precision step kernel (half the bytes):
+    // positions as int32 fixed point (2^-24 m: 6e-8 m resolution everywhere on the 50 m map, where a
+    // float32 would have 3.8e-6), signed Gamma and radius as float32.  Written by the reset kernel.
+    int32_t *qcx, *qcy, *qox, *qoy;
+    float *qcg, *qor;
     // numpy RandomState streams: [n][624] key words + position in the block
     uint32_t *mt;
     int32_t *mt_pos;
@@ -43,6 +51,7 @@ struct MnDev {
     double dt, robot_r, max_speed, k_drag, a[3], w[3];
     double sonar_range;
     double beam_rel[MN_NUM_BEAMS], beam_cos[MN_NUM_BEAMS], beam_sin[MN_NUM_BEAMS];
+    double rot_c[3], rot_s[3];  // cos / sin of w[i]*dt: per-sub-step heading rotation
     double two_pi;          // 2*pi as python computes it
     double two_pi_r;        // (2*pi)*r              -> Gamma = two_pi_r * v_edge
     double two_pi_vrel;     // (2*pi)*v_rel_max      -> check_core same-direction boundary
@@ -54,14 +63,15 @@ struct MnDev {
     double timestep_scale;
     int32_t num_cores, num_obs, reset_start_and_goal, random_reset_state, set_boundary, max_episode_steps, N;
     int32_t n_stages;
+    int32_t debug_skip;  // developer ablation hook (env MN_DEBUG_SKIP): 1 = sub-steps, 2 = sonar, 4 = obstacle rotation
     int64_t sched_t[MN_MAX_STAGES];
     int32_t sched_nc[MN_MAX_STAGES], sched_no[MN_MAX_STAGES];
     double sched_md[MN_MAX_STAGES];
 };
 
 // kernels (defined in mn_step.hip / mn_reset.hip)
-void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, const int32_t *actions, float *obs, float *reward,
-                    uint8_t *done, uint8_t *info, int parity, hipStream_t s);
+void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, int lanes, const int32_t *actions, float *obs,
+                    float *reward, uint8_t *done, uint8_t *info, int parity, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
                      const int32_t *list_dev, int mode, float *obs, hipStream_t s);

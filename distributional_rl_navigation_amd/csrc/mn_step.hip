@@ -5,54 +5,129 @@
 //   get_observation (:273-326) with Robot.sonar_reflection (robot.py:125-198),
 //   reward + termination ladder (:220-257), counters (:259-260).
 //
-// Mapping: one lane per environment, one 64-lane wavefront (= one workgroup) per tile of 64
-// consecutive envs.  All state is SoA with the env index fastest, so every global load/store
-// instruction moves one contiguous run per wave.  The vortex/obstacle tables of the tile are
-// staged in LDS as [row][lane] (lane-private columns, conflict-free ds_read_b64), which gives
-// dynamically indexable per-env tables without spending ~108 VGPRs on them; the same LDS is
-// reused at the end to transpose the 64x26 observation tile so it leaves as 16-byte coalesced
-// row-major stores.
+// Mapping (v2): L lanes per environment (L = 4 by default), 64/L environments per wavefront.
+//   * 65 536 envs are only 1024 wavefronts at one lane per env -- ONE wave per SIMD, nothing to hide
+//     the ~80 k-cycle dependent chain of a step behind (measured: SQ_WAIT_ANY 53 %, 11 cycles per
+//     instruction, profiles/r01_step_only_kernel_stats_v1.txt).  With L lanes per env the independent
+//     parts of a step are spread over the lane group -- the 8 vortex cores (8/L per lane, summed with
+//     DPP quad_perm / row_half_mirror adds, no LDS) and the 11 sonar beams (ceil(11/L) per lane) --
+//     while the short sequential part (float64 pose integration) is replicated in every lane of the
+//     group; all lanes of a group hold bit-identical poses because the DPP adds are commutative pairs.
+//     That gives L x more wavefronts per SIMD and ~3 x shorter per-wave instruction streams.
+//   * Everything a lane needs lives in registers (its cores, all 10 obstacles in the robot frame);
+//     no LDS, no barriers.  World tables are SoA [row][env], so a wave's load of row k touches 64/L
+//     consecutive envs (the L lanes of a group read the same address, which the coalescer merges).
+//   * Heading: ONE float64 sincos per step; the 10 sub-steps advance (cos, sin) by the constant
+//     rotation of w*dt (3 possible values, host constants) instead of 10 sincosf calls.
+//   * Observations leave as float2 stores into the row-major [env][26] tile the IQN consumes.
 #include "mn_device.h"
 
 namespace {
 
-template <typename M, bool PARITY>
-__global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
-                                                          float *__restrict__ obs_out, float *__restrict__ reward_out,
-                                                          uint8_t *__restrict__ done_out, uint8_t *__restrict__ info_out,
-                                                          int parity) {
-    __shared__ double tab[MN_TAB_ROWS][MN_WAVE];  // 54 x 64 x 8 B = 27 KiB per wave
-    const int lane = threadIdx.x;
-    const int e = blockIdx.x * MN_WAVE + lane;
+// sum over the L lanes of a group; every lane ends with the bit-identical total
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+    if (L >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    if (L >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if (L >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if (L >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    return v;
+}
+
+template <int L, int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+    if (L >= 2) v = dpp_add<L, 0xB1>(v);
+    if (L >= 4) v = dpp_add<L, 0x4E>(v);
+    if (L >= 8) v = dpp_add<L, 0x141>(v);
+    if (L >= 16) v = dpp_add<L, 0x140>(v);
+    return v;
+}
+
+template <typename M, bool PARITY, int L>
+__global__ __launch_bounds__(256, (L >= 4 && !PARITY) ? 4 : 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
+                                                      float *__restrict__ obs_out, float *__restrict__ reward_out,
+                                                      uint8_t *__restrict__ done_out, uint8_t *__restrict__ info_out,
+                                                      int parity) {
+    constexpr int CPL = MN_MAX_CORES / L;            // vortex cores per lane
+    constexpr int BPL = (MN_NUM_BEAMS + L - 1) / L;  // sonar beams per lane
+    static_assert(MN_MAX_CORES % L == 0, "L must divide 8");
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / L;        // environment (< npad: the grid covers exactly npad * L lanes)
+    const int q = tid % L;        // lane within the env's group
     const bool active = e < A.n;
     const int np = A.npad;
 
-    if (blockIdx.x == 0 && lane == 0) A.queue_count[parity ^ 1] = 0u;  // counter of the NEXT step
+    if (tid == 0) A.queue_count[parity ^ 1] = 0u;  // counter the NEXT step will fill
 
-    // ---- load state (coalesced, one element per lane) -----------------------------------------
+    // ---- state -----------------------------------------------------------------------------------
     double x = A.x[e], y = A.y[e], theta = A.theta[e], speed = A.speed[e];
     const double gx = A.goal_x[e], gy = A.goal_y[e];
     const int cnt = A.counts[e];
-    const int nc = cnt & 0xff, no = (cnt >> 8) & 0xff;
-    int ep_t = A.ep_t[e];
+    const int ep_t = A.ep_t[e];
     int action = active ? actions[e] : 0;
     action = action < 0 ? 0 : (action > 8 ? 8 : action);
 
-    // ---- stage world tables in LDS (lane-private columns: no barrier needed) ------------------
+    // World tables: every load below is UNCONDITIONAL (rows beyond the placed count hold zeros), so
+    // all ~70 loads of a lane are in flight together and the kernel pays one memory latency, not a
+    // counts -> tables dependent chain.  Padding is applied afterwards with selects.
+    // this lane's vortex cores (generation order is irrelevant for a sum)
+    double ccx[CPL], ccy[CPL], ccg[CPL];
+    // all obstacles (every lane needs them: a beam walks the list in generation order)
+    double obx[MN_MAX_OBS], oby[MN_MAX_OBS], obr2[MN_MAX_OBS];
+    if (PARITY) {   // float64 master tables
 #pragma unroll
-    for (int k = 0; k < MN_MAX_CORES; ++k) {
-        const bool v = k < nc;
-        tab[k][lane] = v ? A.cx[k * np + e] : 0.0;
-        tab[MN_MAX_CORES + k][lane] = v ? A.cy[k * np + e] : 0.0;
-        tab[2 * MN_MAX_CORES + k][lane] = v ? A.cg[k * np + e] : 0.0;
+        for (int j = 0; j < CPL; ++j) {
+            const int k = q * CPL + j;
+            ccx[j] = A.cx[k * np + e]; ccy[j] = A.cy[k * np + e]; ccg[j] = A.cg[k * np + e];
+        }
+#pragma unroll
+        for (int k = 0; k < MN_MAX_OBS; ++k) {
+            obx[k] = A.ox[k * np + e]; oby[k] = A.oy[k * np + e]; obr2[k] = A.orad[k * np + e];
+        }
+    } else {        // compact tables: int32 fixed-point positions (2^-24 m), float32 Gamma / radius
+        int qx[CPL], qy[CPL], px[MN_MAX_OBS], py[MN_MAX_OBS];
+        float qg[CPL], pr[MN_MAX_OBS];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int k = q * CPL + j;
+            qx[j] = A.qcx[k * np + e]; qy[j] = A.qcy[k * np + e]; qg[j] = A.qcg[k * np + e];
+        }
+#pragma unroll
+        for (int k = 0; k < MN_MAX_OBS; ++k) {
+            px[k] = A.qox[k * np + e]; py[k] = A.qoy[k * np + e]; pr[k] = A.qor[k * np + e];
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            ccx[j] = (double)qx[j] * MN_FIX_INV; ccy[j] = (double)qy[j] * MN_FIX_INV; ccg[j] = (double)qg[j];
+        }
+#pragma unroll
+        for (int k = 0; k < MN_MAX_OBS; ++k) {
+            obx[k] = (double)px[k] * MN_FIX_INV; oby[k] = (double)py[k] * MN_FIX_INV; obr2[k] = (double)pr[k];
+        }
     }
-    constexpr int OB = 3 * MN_MAX_CORES;
+    const int nc = cnt & 0xff, no = (cnt >> 8) & 0xff;
+    M cgs[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const bool v = q * CPL + j < nc;
+        ccx[j] = v ? ccx[j] : 1.0e6;   // padding: far away, zero circulation
+        ccy[j] = v ? ccy[j] : 1.0e6;
+        cgs[j] = v ? (M)ccg[j] : M(0);
+    }
 #pragma unroll
     for (int k = 0; k < MN_MAX_OBS; ++k) {
-        const bool v = k < no;
-        tab[OB + k][lane] = v ? A.ox[k * np + e] : 0.0;
-        tab[OB + MN_MAX_OBS + k][lane] = v ? A.oy[k * np + e] : 0.0;
-        tab[OB + 2 * MN_MAX_OBS + k][lane] = v ? A.orad[k * np + e] : 0.0;
+        const bool v = k < no;         // padding: far away, r = 0 -> can never be hit, so the beam
+        obx[k] = v ? obx[k] : 1.0e6;   // loop needs no count test
+        oby[k] = v ? oby[k] : 1.0e6;
+        obr2[k] = v ? obr2[k] * obr2[k] : 0.0;
     }
 
     // marinenav_env.py:205 dis_before
@@ -62,38 +137,47 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
     // robot.py:55-56: actions[i] = (a[i // 3], w[i % 3])
     const int ai = action / 3, wi = action - 3 * ai;
     const double acc = ai == 0 ? P.a[0] : (ai == 1 ? P.a[1] : P.a[2]);
-    const double wv = wi == 0 ? P.w[0] : (wi == 1 ? P.w[1] : P.w[2]);
-    const double dt = P.dt;
-    const double two_pi = P.two_pi;
+    const double wdt = (wi == 0 ? P.w[0] : (wi == 1 ? P.w[1] : P.w[2])) * P.dt;
+    const double rot_c = wi == 0 ? P.rot_c[0] : (wi == 1 ? P.rot_c[1] : P.rot_c[2]);   // cos(w*dt)
+    const double rot_s = wi == 0 ? P.rot_s[0] : (wi == 1 ? P.rot_s[1] : P.rot_s[2]);   // sin(w*dt)
+    const double dt = P.dt, two_pi = P.two_pi;
 
     const M r2 = (M)(P.core_r * P.core_r);
     const M inv_two_pi_r2 = (M)(1.0 / P.two_pi_r_r);
     const M inv_two_pi = (M)(1.0 / P.two_pi);
 
+    // heading: wrap once on entry (state may have been set from outside), one sincos per step
+    while (theta < 0.0) theta += two_pi;
+    while (theta >= two_pi) theta -= two_pi;
+    double sn = 0.0, cs = 1.0;
+    if (!(P.debug_skip & 4)) sincos(theta, &sn, &cs);
+
     // ---- N kinematic sub-steps (marinenav_env.py:208-212) -------------------------------------
     M velx = 0, vely = 0;
-    for (int s = 0; s < P.N; ++s) {
+    const int nsub = (P.debug_skip & 1) ? 0 : P.N;
+    for (int s = 0; s < nsub; ++s) {
         // current at the pre-move position: superposition over ALL cores
         M cvx = 0, cvy = 0;
-        for (int k = 0; k < nc; ++k) {
-            const M dx = (M)(tab[k][lane] - x);
-            const M dy = (M)(tab[MN_MAX_CORES + k][lane] - y);
-            mn_core_velocity<M>(dx, dy, (M)tab[2 * MN_MAX_CORES + k][lane], r2, inv_two_pi_r2, inv_two_pi, cvx, cvy);
-        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            mn_core_velocity<M>((M)(ccx[j] - x), (M)(ccy[j] - y), cgs[j], r2, inv_two_pi_r2, inv_two_pi, cvx, cvy);
+        cvx = group_sum<L>(cvx);
+        cvy = group_sum<L>(cvy);
         // robot.py:98-107: velocity = speed*(cos,sin) + current ; position += velocity*dt
-        M sn, cs;
-        MnMath<M>::sincos_((M)theta, &sn, &cs);
-        velx = (M)speed * cs + cvx;
-        vely = (M)speed * sn + cvy;
+        velx = (M)(speed * cs) + cvx;
+        vely = (M)(speed * sn) + cvy;
         x += (double)velx * dt;
         y += (double)vely * dt;
         // robot.py:113-114: drag + clip
         speed += (acc - P.k_drag * speed) * dt;
         speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
-        // robot.py:117-123: heading + wrap to [0, 2pi)
-        theta += wv * dt;
-        while (theta < 0.0) theta += two_pi;
-        while (theta >= two_pi) theta -= two_pi;
+        // robot.py:117-123: heading + wrap to [0, 2pi); (cos, sin) advance by the constant rotation
+        theta += wdt;
+        theta = theta < 0.0 ? theta + two_pi : theta;
+        theta = theta >= two_pi ? theta - two_pi : theta;
+        const double c2 = cs * rot_c - sn * rot_s;
+        sn = sn * rot_c + cs * rot_s;
+        cs = c2;
     }
 
     // marinenav_env.py:214 dis_after
@@ -101,70 +185,56 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
     const double dis_after = sqrt(dax * dax + day * day);
 
     // ---- observation (marinenav_env.py:273-326) ------------------------------------------------
-    // Final-heading rotation in float64 (one sincos per step): the goal vector (|g| up to 70 m) and
-    // the sonar geometry cancel too much for float32 sin/cos.
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    M ob[MN_OBS_DIM];
-    {
-        const M c = (M)cs, s_ = (M)sn;
-        ob[0] = c * velx + s_ * vely;  // R(theta)^T * velocity: lagged velocity, final heading (App. A K5)
-        ob[1] = -s_ * velx + c * vely;
-    }
-    ob[2] = (M)(cs * dax + sn * day);  // R(theta)^T (goal - p)
-    ob[3] = (M)(-sn * dax + cs * day);
-    const M range = (M)P.sonar_range;
-    // obstacle centres in the robot frame, once per obstacle
-    double mrx[MN_MAX_OBS], mry[MN_MAX_OBS], orr2[MN_MAX_OBS];
+    // obstacle centres in the robot frame: m_r = R(theta)^T (c - p); |m_r| = |c - p|
+    double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
+    if (!(P.debug_skip & 8))
 #pragma unroll
     for (int k = 0; k < MN_MAX_OBS; ++k) {
-        const double mx = tab[OB + k][lane] - x, my = tab[OB + MN_MAX_OBS + k][lane] - y;
-        const double r = tab[OB + 2 * MN_MAX_OBS + k][lane];
-        mrx[k] = cs * mx + sn * my;
-        mry[k] = -sn * mx + cs * my;
-        orr2[k] = r * r;
+        const double mx = obx[k] - x, my = oby[k] - y;
+        obx[k] = cs * mx + sn * my;
+        oby[k] = -sn * mx + cs * my;
+        const double d2 = mx * mx + my * my;
+        const bool nearer = (k < no) && (d2 < best);
+        best = nearer ? d2 : best;
+        best_r2 = nearer ? obr2[k] : best_r2;
     }
+    const M range = (M)P.sonar_range;
     const double half_pi = 0.5 * 3.141592653589793, three_half_pi = 3 * 3.141592653589793 / 2;
+    M bxo[BPL], byo[BPL];   // this lane's beams, hit point in the robot frame
 #pragma unroll
-    for (int b = 0; b < MN_NUM_BEAMS; ++b) {
-        const double angle = theta + P.beam_rel[b];  // robot.py:134, not wrapped
+    for (int j = 0; j < BPL; ++j) { bxo[j] = 0; byo[j] = 0; }
+    if (!(P.debug_skip & 2))
+#pragma unroll
+    for (int j = 0; j < BPL; ++j) {
+        const int b = q + L * j;
+        const int bb = b < MN_NUM_BEAMS ? b : MN_NUM_BEAMS - 1;
+        const double angle = theta + P.beam_rel[bb];  // robot.py:134, not wrapped
         const bool up = fabs(angle - half_pi) < 1e-03;
         const bool down = fabs(angle - three_half_pi) < 1e-03;
         // beam direction in the robot frame: the constant (cos rel, sin rel); a snapped beam points
         // along world (0,+-1), i.e. R^T (0,+-1) = +-(sin theta, cos theta)
-        double bx = P.beam_cos[b], by = P.beam_sin[b];
+        double bx = P.beam_cos[bb], by = P.beam_sin[bb];
         if (up || down) {
             const double sg = up ? 1.0 : -1.0;
             bx = sg * sn; by = sg * cs;
         }
-        bool hit = false, stopped = false;
-        M dist = M(0);
+        MnBeam<M> beam;
+        beam.init();
 #pragma unroll
         for (int k = 0; k < MN_MAX_OBS; ++k) {
-            if (k < no) {
-                double tc, h2;
-                mn_beam_geom(mrx[k], mry[k], orr2[k], bx, by, tc, h2);
-                mn_beam_update<M>((M)tc, (M)h2, range, hit, dist, stopped);
-            }
+            double tc, h2;
+            mn_beam_geom(obx[k], oby[k], obr2[k], bx, by, tc, h2);
+            beam.update((M)tc, (M)h2, range);
         }
-        ob[4 + 2 * b] = hit ? dist * (M)bx : M(0);  // misses are (0,0): marinenav_env.py:315-316
-        ob[5 + 2 * b] = hit ? dist * (M)by : M(0);
+        const bool hit = beam.hit();
+        bxo[j] = hit ? beam.dist * (M)bx : M(0);  // misses are (0,0): marinenav_env.py:315-316
+        byo[j] = hit ? beam.dist * (M)by : M(0);
     }
 
     // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
     double reward = P.timestep_penalty;
     reward += dis_before - dis_after;
-    // check_collision (:329-336): nearest-CENTRE obstacle only
-    bool collide = false;
-    {
-        double best = 1e300, best_r = 0.0;
-        for (int k = 0; k < no; ++k) {
-            const double mx = tab[OB + k][lane] - x, my = tab[OB + MN_MAX_OBS + k][lane] - y;
-            const double d2 = mx * mx + my * my;
-            if (d2 < best) { best = d2; best_r = tab[OB + 2 * MN_MAX_OBS + k][lane]; }
-        }
-        collide = no > 0 && sqrt(best) <= best_r + P.robot_r;
-    }
+    const bool collide = no > 0 && sqrt(best) <= sqrt(best_r2) + P.robot_r;
     const bool reach = dis_after <= P.goal_dis;  // check_reach_goal (:338-342)
     const bool out = (x < 0.0 || x > P.width) || (y < 0.0 || y > P.height);
     int done, info;
@@ -176,56 +246,74 @@ __global__ __launch_bounds__(MN_WAVE) void mn_step_kernel(MnArrays A, MnDev P, c
 
     // ---- write back ----------------------------------------------------------------------------
     if (active) {
-        A.x[e] = x; A.y[e] = y; A.theta[e] = theta; A.speed[e] = speed;
-        A.vx[e] = (double)velx; A.vy[e] = (double)vely;
-        A.ep_t[e] = ep_t + 1;
-        A.tot_t[e] += 1;
-        reward_out[e] = (float)reward;
-        done_out[e] = (uint8_t)done;
-        info_out[e] = (uint8_t)info;
-        if (PARITY) {
-            A.rew64[e] = reward;
+        float *orow = obs_out + (size_t)e * MN_OBS_DIM;
+        double *orow64 = PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr;
+        if (q == 0) {
+            A.x[e] = x; A.y[e] = y; A.theta[e] = theta; A.speed[e] = speed;
+            A.vx[e] = (double)velx; A.vy[e] = (double)vely;
+            A.ep_t[e] = ep_t + 1;
+            A.tot_t[e] += 1;
+            reward_out[e] = (float)reward;
+            done_out[e] = (uint8_t)done;
+            info_out[e] = (uint8_t)info;
+            // R(theta)^T * velocity: lagged velocity, final heading (App. A K5); R(theta)^T (goal - p)
+            const M c = (M)cs, s_ = (M)sn;
+            const M o0 = c * velx + s_ * vely, o1 = -s_ * velx + c * vely;
+            const M o2 = (M)(cs * dax + sn * day), o3 = (M)(-sn * dax + cs * day);
+            *reinterpret_cast<float2 *>(orow) = make_float2((float)o0, (float)o1);
+            *reinterpret_cast<float2 *>(orow + 2) = make_float2((float)o2, (float)o3);
+            if (PARITY) {
+                A.rew64[e] = reward;
+                orow64[0] = (double)o0; orow64[1] = (double)o1; orow64[2] = (double)o2; orow64[3] = (double)o3;
+            }
+        }
+        if (!(P.debug_skip & 16))
 #pragma unroll
-            for (int j = 0; j < MN_OBS_DIM; ++j) A.obs64[(size_t)e * MN_OBS_DIM + j] = (double)ob[j];
+        for (int j = 0; j < BPL; ++j) {
+            const int b = q + L * j;
+            if (b < MN_NUM_BEAMS) {
+                *reinterpret_cast<float2 *>(orow + 4 + 2 * b) = make_float2((float)bxo[j], (float)byo[j]);
+                if (PARITY) { orow64[4 + 2 * b] = (double)bxo[j]; orow64[5 + 2 * b] = (double)byo[j]; }
+            }
         }
     }
     // done-queue: one atomic per wave
     {
-        const unsigned long long m = __ballot(active && done);
+        const bool mine = active && done && q == 0;
+        const unsigned long long m = __ballot(mine);
         if (m) {
+            const int lane = threadIdx.x & (MN_WAVE - 1);
+            const int leader = __ffsll((long long)m) - 1;
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&A.queue_count[parity], (unsigned)__popcll(m));
-            base = __shfl(base, 0);
-            if (active && done) A.queue[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            if (lane == leader) base = atomicAdd(&A.queue_count[parity], (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            if (mine) A.queue[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
         }
     }
-    // observation tile: transpose through LDS -> row-major [env][26] float32, 16-byte stores
-    __syncthreads();  // every lane is done with its table column
-    float *ot = reinterpret_cast<float *>(&tab[0][0]);
-#pragma unroll
-    for (int j = 0; j < MN_OBS_DIM; ++j) ot[lane * MN_OBS_DIM + j] = (float)ob[j];
-    __syncthreads();
-    const int tile_first = blockIdx.x * MN_WAVE;
-    const int valid = A.n - tile_first;
-    float *gdst = obs_out + (size_t)tile_first * MN_OBS_DIM;
-    if (valid >= MN_WAVE) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(ot);
-        float4 *dst4 = reinterpret_cast<float4 *>(gdst);
-        constexpr int NV = MN_WAVE * MN_OBS_DIM / 4;  // 416
-        for (int q = lane; q < NV; q += MN_WAVE) dst4[q] = src4[q];
-    } else {
-        const int nf = valid * MN_OBS_DIM;
-        for (int q = lane; q < nf; q += MN_WAVE) gdst[q] = ot[q];
+}
+
+template <typename M, bool PARITY>
+void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actions, float *obs, float *reward,
+              uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
+    const dim3 block(256);
+#define MN_LAUNCH(LL)                                                                                              \
+    hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / 256)), block, 0, s, A, P, \
+                       actions, obs, reward, done, info, parity)
+    switch (lanes) {
+        case 1: MN_LAUNCH(1); break;
+        case 2: MN_LAUNCH(2); break;
+        case 8: MN_LAUNCH(8); break;
+        default: MN_LAUNCH(4); break;
     }
+#undef MN_LAUNCH
 }
 
 }  // namespace
 
-void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, const int32_t *actions, float *obs, float *reward,
-                    uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
-    const dim3 grid(A.npad / MN_WAVE), block(MN_WAVE);
+void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, int lanes, const int32_t *actions, float *obs,
+                    float *reward, uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
     if (precision == MN_PRECISION_F64)
-        hipLaunchKernelGGL((mn_step_kernel<double, true>), grid, block, 0, s, A, P, actions, obs, reward, done, info, parity);
+        launch_l<double, true>(lanes, A, P, actions, obs, reward, done, info, parity, s);
     else
-        hipLaunchKernelGGL((mn_step_kernel<float, false>), grid, block, 0, s, A, P, actions, obs, reward, done, info, parity);
+        launch_l<float, false>(lanes, A, P, actions, obs, reward, done, info, parity, s);
 }

@@ -40,7 +40,7 @@ class VecMarineNavEnv:
     """
 
     def __init__(self, n_envs, seed=0, seeds=None, schedule=None, device="cuda:0", precision="mixed",
-                 timestep_scale=1.0, first_index=0, params=None):
+                 timestep_scale=1.0, first_index=0, params=None, step_lanes=0):
         if not torch.cuda.is_available():
             raise _capi.MarineNavHipError("VecMarineNavEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.L = _capi.lib()
@@ -50,6 +50,7 @@ class VecMarineNavEnv:
         self.params = params if params is not None else _capi.default_params()
         self.params.precision = _capi.PRECISION_F64 if precision in ("f64", "float64", 0) else _capi.PRECISION_MIXED
         self.precision = "f64" if self.params.precision == _capi.PRECISION_F64 else "mixed"
+        self.params.step_lanes = int(step_lanes)
         h = C.c_void_p()
         rc = self.L.mn_create(self.n_envs, C.byref(self.params), C.byref(h))
         if rc:

@@ -180,14 +180,15 @@ def _load_g3(env, z, lo, hi):
     env.set_state(s, z["ep_t"][lo:hi])
 
 
+@pytest.mark.parametrize("lanes", [4, 1, 2, 8])
 @pytest.mark.parametrize("precision,atol,rtol", [("f64", 1e-9, 0.0), ("mixed", 1e-5, 1e-5)])
-def test_g3_single_step_golden(torch, precision, atol, rtol):
+def test_g3_single_step_golden(torch, precision, atol, rtol, lanes):
     """2048 independent (world, state, action) triples from the Python reference.
     f64: <= 1e-9.  mixed: |err| <= 1e-5 + 1e-5*|ref| on the float32 outputs (north-star tolerance;
     f32 ulp at 50 m is 3.8e-6), discrete outcomes identical except within 1e-5 of a threshold."""
     z = np.load(os.path.join(G, "g3_single_step.npz"))
     n = len(z["action"])
-    env = make_env(n, precision)
+    env = make_env(n, precision, step_lanes=lanes)   # lanes per env in the step kernel (default 4)
     _load_g3(env, z, 0, n)
     env.step(torch.from_numpy(z["action"].astype(np.int32)).to(env.device))
     obs = env.get_obs64() if precision == "f64" else env.obs.cpu().numpy().astype(np.float64)
