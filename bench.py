@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no-learner", action="store_true", help="random policy, step kernel only (configs[1])")
     ap.add_argument("--cpu-steps", type=int, default=4_000_000, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
+    ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
     ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env in the step kernel (0 = library default)")
     args = ap.parse_args()
@@ -85,6 +86,8 @@ def main():
         agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device=device,
                          seed=100 if args.shared_learner else 100 + rank, learning_starts=0,
                          distributed=args.shared_learner and world > 1, act_chunk=args.act_chunk)
+    if agent is not None and args.torch_act:
+        agent.use_fused_act = False
     total_timesteps = 3_000_000 * n * world      # eps stays on the reference's initial 10 % ramp
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)

@@ -1,0 +1,235 @@
+// iqn_act.hip -- fused IQN action-value kernel for gfx950 (MI355X).
+//
+// Replaces, for inference on a whole vector of environments, ObsEncoder.forward + the mean over the
+// K = 32 quantile samples of ObsEncoder.get_qvals (thirdparty/IQN/model.py:141-191):
+//     cos   = cos(tau * pi * [0..63])                                  (model.py:149-155)
+//     x     = relu(cos @ W1^T + b1) * features                         (:177-181, Hadamard)
+//     x     = relu(x @ W2^T + b2) ; x = relu(x @ W3^T + b3) ; q = x @ W4^T + b4   (:183-185)
+//     Q     = mean over the K taus                                      (:188-191)
+// `features` (the three linear observation encoders, :170-173) are computed by the caller (a 26->208
+// linear map, <1 % of the FLOPs) and streamed in.
+//
+// Why a kernel: in eager PyTorch this path is ~95 % of a training vector step at 65 536 envs and is
+// bound by elementwise traffic -- the [n*32, 208] activation is written and re-read five times
+// (profiles/r01_full_loop_kernel_stats_v1.txt).  Here a wavefront owns one environment (32 tau rows)
+// at a time and carries it through all four layers in registers; nothing but features, taus and the 9
+// Q-values touches HBM.
+//
+// MFMA mapping: exact-f32 v_mfma_f32_16x16x4_f32 (the reference is float32; no reduced precision).
+// Every layer is computed TRANSPOSED, H^T = W . X^T: the weights are the A operand (16 output
+// features x 4 k), the activations the B operand (4 k x 16 tau rows) and the C tile is
+// [16 features x 16 taus] with lane l holding column (l & 15) and rows 4*(l >> 4) + r.  Because the
+// k order of a dot product is free, MFMA step (t, r) of the NEXT layer is defined to consume input
+// features {16t + 4g + r : g = 0..3} -- which is exactly register r of C tile t in lane group g.  So a
+// layer's accumulator registers ARE the next layer's B operands: no LDS round trip, no shuffles.
+// The weights are permuted once per workgroup into that order while being copied to LDS
+// (125 KiB of the 160 KiB: one 512-thread workgroup per CU, 2 waves per SIMD so one wave's bias /
+// ReLU / cos VALU work runs under the other's MFMAs); each ds_read_b128 feeds 4 k-steps x 2 tau
+// tiles = 8 MFMAs.  Layers 1 and 2 are fused over the 13 feature tiles of the 208-wide activation,
+// so the live state is 32 accumulator + 32 cos registers per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "marinenav_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int K_TAUS = 32;      // model.py:118
+constexpr int N_COS = 64;       // model.py:130
+constexpr int F = 208;          // 16 + 16 + 176 feature width
+constexpr int H = 64;           // hidden width
+constexpr int A_OUT = 9;        // actions
+constexpr int T1 = F / 16;      // 13 feature tiles
+// LDS layout (floats)
+constexpr int OFF_W1 = 0;                         // [13 t][4 m4][64 lanes][4]
+constexpr int OFF_W2 = OFF_W1 + T1 * 4 * 64 * 4;  // [4 mt][13 t][64][4]
+constexpr int OFF_W3 = OFF_W2 + 4 * T1 * 64 * 4;  // [4 mt][4 t2][64][4]
+constexpr int OFF_W4 = OFF_W3 + 4 * 4 * 64 * 4;   // [4 t2][64][4]
+constexpr int OFF_B1 = OFF_W4 + 4 * 64 * 4;       // [208]
+constexpr int OFF_B2 = OFF_B1 + F;                // [64]
+constexpr int OFF_B3 = OFF_B2 + H;                // [64]
+constexpr int OFF_B4 = OFF_B3 + H;                // [16]
+constexpr int LDS_FLOATS = OFF_B4 + 16;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    f32x4 r;
+    r.x = v.x > 0.f ? v.x : 0.f; r.y = v.y > 0.f ? v.y : 0.f; r.z = v.z > 0.f ? v.z : 0.f; r.w = v.w > 0.f ? v.w : 0.f;
+    return r;
+}
+
+// sum over the 16 lanes of a row (lanes sharing l >> 4)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad xor 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad xor 2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ features, const float *__restrict__ taus,
+                                                           const float *__restrict__ W1, const float *__restrict__ b1,
+                                                           const float *__restrict__ W2, const float *__restrict__ b2,
+                                                           const float *__restrict__ W3, const float *__restrict__ b3,
+                                                           const float *__restrict__ W4, const float *__restrict__ b4,
+                                                           float *__restrict__ qvals, int n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+
+    // ---- weights -> LDS, permuted into MFMA A-fragment order (nn.Linear stores [out][in]) ----------
+    for (int i = tid; i < OFF_B1; i += blockDim.x) {
+        const int j = i & 3, l = (i >> 2) & 63, g = l >> 4, row = l & 15;
+        float v;
+        if (i < OFF_W2) {            // W1p[t][m4][l][j] = W1[16t + row][4*(4*m4 + j) + g]
+            const int q = i >> 8, m4 = q & 3, t = q >> 2;
+            v = W1[(16 * t + row) * N_COS + 4 * (4 * m4 + j) + g];
+        } else if (i < OFF_W3) {     // W2p[mt][t][l][r] = W2[16mt + row][16t + 4g + r]
+            const int q = (i - OFF_W2) >> 8, t = q % T1, mt = q / T1;
+            v = W2[(16 * mt + row) * F + 16 * t + 4 * g + j];
+        } else if (i < OFF_W4) {     // W3p[mt][t2][l][r] = W3[16mt + row][16t2 + 4g + r]
+            const int q = (i - OFF_W3) >> 8, t2 = q & 3, mt = q >> 2;
+            v = W3[(16 * mt + row) * H + 16 * t2 + 4 * g + j];
+        } else {                     // W4p[t2][l][r] = W4[row][16t2 + 4g + r] (rows >= 9 are zero)
+            const int t2 = (i - OFF_W4) >> 8;
+            v = row < A_OUT ? W4[row * H + 16 * t2 + 4 * g + j] : 0.f;
+        }
+        lds[i] = v;
+    }
+    for (int i = tid; i < F; i += blockDim.x) lds[OFF_B1 + i] = b1[i];
+    if (tid < H) { lds[OFF_B2 + tid] = b2[tid]; lds[OFF_B3 + tid] = b3[tid]; }
+    if (tid < 16) lds[OFF_B4 + tid] = tid < A_OUT ? b4[tid] : 0.f;
+    __syncthreads();
+
+    const int lane = tid & 63, g = lane >> 4, col = lane & 15;
+    const int wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
+
+    // pis[k] = float32(pi * k) exactly as the reference builds it (model.py:130), k = 4m + g
+    float pk[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) pk[m] = (float)(3.141592653589793 * (double)(4 * m + g));
+
+    // one environment (32 tau rows = NT = 2 column tiles) per wave iteration
+    constexpr int NT = 2;
+    for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
+        float tau[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e * K_TAUS + 16 * nt + col];
+        // layer-1 B operands: cos(tau * pis[k]) for k = 4m + g  (model.py:155)
+        float cb[16][NT];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) cb[m][nt] = cosf(tau[nt] * pk[m]);
+
+        const f32x4 *fe = reinterpret_cast<const f32x4 *>(features + (size_t)e * F) + g;   // + 4*t per tile
+
+        f32x4 acc2[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- layers 1 + 2 fused over the 13 feature tiles ------------------------------------------
+        for (int t = 0; t < T1; ++t) {
+            const f32x4 fv = fe[4 * t];          // features[e][16t + 4g + r]
+            f32x4 acc1[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4) {
+                const f32x4 a = ldsv[(OFF_W1 >> 2) + (t * 4 + m4) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc1[nt] = mfma(a[j], cb[4 * m4 + j][nt], acc1[nt]);
+            }
+            const f32x4 bias = ldsv[(OFF_B1 >> 2) + 4 * t + g];      // b1[16t + 4g + r]
+            f32x4 h1[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) h1[nt] = relu4(acc1[nt] + bias) * fv;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 a = ldsv[(OFF_W2 >> 2) + (mt * T1 + t) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma(a[r], h1[nt][r], acc2[mt][nt]);
+            }
+        }
+        // ---- layer 2 epilogue, layer 3 ---------------------------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 bias = ldsv[(OFF_B2 >> 2) + 4 * mt + g];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = relu4(acc2[mt][nt] + bias);
+        }
+        f32x4 acc3[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const f32x4 a = ldsv[(OFF_W3 >> 2) + (mt * 4 + t2) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mfma(a[r], acc2[t2][nt][r], acc3[mt][nt]);
+            }
+            const f32x4 bias = ldsv[(OFF_B3 >> 2) + 4 * mt + g];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = relu4(acc3[mt][nt] + bias);
+        }
+        // ---- layer 4 (9 outputs padded to one 16-row tile) -------------------------------------------
+        f32x4 acc4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            const f32x4 a = ldsv[(OFF_W4 >> 2) + t2 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc4[nt] = mfma(a[r], acc3[t2][nt][r], acc4[nt]);
+        }
+        // ---- mean over the 32 taus (model.py:190); action = 4g + r -----------------------------------
+        const f32x4 bias4 = ldsv[(OFF_B4 >> 2) + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s0 = row_sum16(acc4[0][r] + acc4[1][r]) * (1.0f / K_TAUS) + bias4[r];
+            const int action = 4 * g + r;
+            if (col == 0 && action < A_OUT) qvals[(size_t)e * A_OUT + action] = s0;
+        }
+    }
+}
+
+}  // namespace
+
+// C-ABI ----------------------------------------------------------------------------------------------
+extern "C" int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1,
+                            const float *W2, const float *b2, const float *W3, const float *b3, const float *W4,
+                            const float *b4, float *qvals_dev, int32_t n, int32_t num_taus, void *stream) {
+    if (!features_dev || !taus_dev || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !W4 || !b4 || !qvals_dev) return MN_ERR_INVALID;
+    if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
+        n_cu = prop.multiProcessorCount;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+            return MN_ERR_HIP;
+        attr_set = true;
+    }
+    int blocks = (n + 7) / 8;
+    if (blocks > n_cu) blocks = n_cu;
+    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, features_dev,
+                       taus_dev, W1, b1, W2, b2, W3, b3, W4, b4, qvals_dev, n);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}

@@ -40,6 +40,7 @@ class IQNAgent:
         self.initial_eps, self.final_eps = initial_eps, final_eps
         self.N = 8                                   # train-time quantile samples (agent.py:286,290)
         self.act_chunk = act_chunk
+        self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
 
         self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
         self.qnetwork_target = ObsEncoder(state_size, action_size, seed, device)   # identical init (App. A A1)
@@ -136,16 +137,21 @@ class IQNAgent:
         return self.act_eval(state, eps, cvar), cvar
 
     @torch.no_grad()
-    def qvals_batch(self, states, cvar=1.0):
+    def qvals_batch(self, states, cvar=1.0, taus=None):
         """Q(s, .) = mean over K = 32 quantile samples, for a whole vector of states (device tensor).
-        Chunked over envs so the [chunk*K, 208] activations stay cache-resident."""
+        On the GPU this is the fused HIP kernel (csrc/iqn_act.hip); on CPU tensors (tests) plain PyTorch,
+        chunked over envs."""
+        if states.is_cuda and self.use_fused_act:
+            from .fused_act import fused_qvals
+            return fused_qvals(self.qnetwork_local, states, cvar, taus=taus, generator=self.gen)
         n = states.shape[0]
         out = torch.empty(n, self.action_size, dtype=torch.float32, device=states.device)
         step = self.act_chunk
         for lo in range(0, n, step):
             hi = min(n, lo + step)
             c = cvar[lo:hi] if torch.is_tensor(cvar) else cvar
-            out[lo:hi] = self.qnetwork_local.get_qvals(states[lo:hi], c)
+            t = taus[lo:hi] if taus is not None else None
+            out[lo:hi] = self.qnetwork_local.get_qvals(states[lo:hi], c, taus=t)
         return out
 
     @torch.no_grad()

@@ -180,6 +180,22 @@ int mn_last_done_count(mn_handle *h, void *stream, int32_t *out);
 int mn_profile_begin(mn_handle *h, int32_t max_launches);
 int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
 
+/* ---- IQN inference ---------------------------------------------------------------------------
+ * Fused ObsEncoder.forward + mean over the K = 32 quantile samples of ObsEncoder.get_qvals
+ * (thirdparty/IQN/model.py:141-191) for n observations:
+ *   features_dev [n][208] f32 : cat(velocity_encoder, goal_encoder, sensor_encoder outputs), model.py:170-173
+ *   taus_dev     [n][32]  f32 : quantile fractions, already multiplied by cvar (model.py:149-153)
+ *   W1 [208][64], b1 [208]    : cos_embedding      (nn.Linear layout [out][in], device pointers)
+ *   W2 [64][208], b2 [64]     : hidden_layer
+ *   W3 [64][64],  b3 [64]     : hidden_layer_2
+ *   W4 [9][64],   b4 [9]      : output_layer
+ *   qvals_dev    [n][9]   f32 : mean over taus of the quantile values
+ * Exact float32 (v_mfma_f32_16x16x4_f32); weights are read on every call, so they may change
+ * between calls (training).  num_taus must be 32. */
+int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1, const float *W2,
+                 const float *b2, const float *W3, const float *b3, const float *W4, const float *b4, float *qvals_dev,
+                 int32_t n, int32_t num_taus, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
