@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = {(8, 10): 406, (8, 5): 346, (4, 6): 310}   # 190 + 12 * (n_cores + n_obs)
 HBM_PEAK_GBS = 8000.0
+# IQN act, K = 32 taus: 2 * 32 * (64*208 + 208*64 + 64*64 + 64*9) FLOP per env-step ("~2.0 MFLOP")
+ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 
 
 def cpu_baseline(n_steps, world):
@@ -111,12 +114,22 @@ def main():
     g0 = agent.grad_steps if agent else 0
     fence()
     env.profile_begin(args.steps)
+    import ctypes as C
+    from distributional_rl_navigation_amd import _capi
+    fused = agent is not None and agent.use_fused_act
+    if fused:
+        _capi.lib().mn_iqn_profile_begin(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         obs = one_step(obs)
     fence()
     elapsed = time.perf_counter() - t0
     step_kernel_ms, launches = env.profile_end()
+    act_ms, act_launches = 0.0, 0
+    if fused:
+        ms, nl = C.c_double(), C.c_int32()
+        _capi.lib().mn_iqn_profile_end(C.c_void_p(torch.cuda.current_stream(device).cuda_stream), C.byref(ms), C.byref(nl))
+        act_ms, act_launches = ms.value, nl.value
     grad_steps = (agent.grad_steps - g0) if agent else 0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -149,8 +162,8 @@ def main():
                 "cvar": args.cvar,
             },
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
-            "roofline": {
-                "kernel": "mn_step_kernel<float,false>",
+            "roofline_env_step": {
+                "kernel": "mn_step_kernel<float,false,L>",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -163,6 +176,15 @@ def main():
                 "kernel_only_env_steps_per_sec": n / (step_kernel_ms * 1e-3) if step_kernel_ms > 0 else None,
             },
         }
+        if fused and act_ms > 0:
+            tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
+            out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
+                "kernel": "iqn_qvals_kernel", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "launch_ms": act_ms, "launches_timed": act_launches,
+            }
+        else:
+            out["roofline"] = out["roofline_env_step"]
         if args.cpu_steps > 0:
             v, dt = cpu_baseline(args.cpu_steps, (args.cores, args.obstacles, min_dis))
             out["cpu_baseline"] = {

@@ -107,10 +107,13 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
     const int wave = tid >> 6, waves_per_block = blockDim.x >> 6;
     const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
 
-    // pis[k] = float32(pi * k) exactly as the reference builds it (model.py:130), k = 4m + g
-    float pk[16];
+    // cos(tau * pi * k) = cos(2 pi * (tau * k / 2)), k = 4m + g: the phase in REVOLUTIONS is tau * (k/2),
+    // one exact-ish multiply; v_fract + v_cos_f32 replace libm's ~35-instruction range reduction.  The
+    // reference rounds tau * float32(pi k) before its cos (model.py:130,155), so the two already
+    // differ by ~1e-5 rad of input rounding at k = 63; that noise dominates either cos error.
+    float hk[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) pk[m] = (float)(3.141592653589793 * (double)(4 * m + g));
+    for (int m = 0; m < 16; ++m) hk[m] = 0.5f * (float)(4 * m + g);
 
     // one environment (32 tau rows = NT = 2 column tiles) per wave iteration
     constexpr int NT = 2;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 #pragma unroll
         for (int m = 0; m < 16; ++m)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) cb[m][nt] = cosf(tau[nt] * pk[m]);
+            for (int nt = 0; nt < NT; ++nt) cb[m][nt] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[m]));
 
         const f32x4 *fe = reinterpret_cast<const f32x4 *>(features + (size_t)e * F) + g;   // + 4*t per tile
 
@@ -210,6 +213,37 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 }  // namespace
 
 // C-ABI ----------------------------------------------------------------------------------------------
+namespace {
+hipEvent_t g_ev[2 * 4096];
+int g_prof_max = 0, g_prof_n = 0, g_ev_made = 0;
+}  // namespace
+
+extern "C" int mn_iqn_profile_begin(int32_t max_launches) {
+    if (max_launches < 0 || max_launches > 4096) return MN_ERR_INVALID;
+    while (g_ev_made < 2 * max_launches) {
+        if (hipEventCreate(&g_ev[g_ev_made]) != hipSuccess) return MN_ERR_HIP;
+        ++g_ev_made;
+    }
+    g_prof_max = max_launches;
+    g_prof_n = 0;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches) {
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MN_ERR_HIP;
+    double sum = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) return MN_ERR_HIP;
+        sum += ms;
+    }
+    if (mean_ms) *mean_ms = g_prof_n ? sum / g_prof_n : 0.0;
+    if (launches) *launches = g_prof_n;
+    g_prof_max = 0;
+    g_prof_n = 0;
+    return MN_OK;
+}
+
 extern "C" int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1,
                             const float *W2, const float *b2, const float *W3, const float *b3, const float *W4,
                             const float *b4, float *qvals_dev, int32_t n, int32_t num_taus, void *stream) {
@@ -229,7 +263,10 @@ extern "C" int mn_iqn_qvals(const float *features_dev, const float *taus_dev, co
     }
     int blocks = (n + 7) / 8;
     if (blocks > n_cu) blocks = n_cu;
+    const bool prof = g_prof_n < g_prof_max;
+    if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], (hipStream_t)stream);
     hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, features_dev,
                        taus_dev, W1, b1, W2, b2, W3, b3, W4, b4, qvals_dev, n);
+    if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], (hipStream_t)stream); ++g_prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }

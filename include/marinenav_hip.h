@@ -196,6 +196,10 @@ int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *
                  const float *b2, const float *W3, const float *b3, const float *W4, const float *b4, float *qvals_dev,
                  int32_t n, int32_t num_taus, void *stream);
 
+/* Benchmark hook: HIP events on the launch stream around the next mn_iqn_qvals launches. */
+int mn_iqn_profile_begin(int32_t max_launches);
+int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches);
+
 #ifdef __cplusplus
 }
 #endif
