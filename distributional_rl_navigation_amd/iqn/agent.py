@@ -333,7 +333,10 @@ class IQNAgent:
         per_iter = train_env.n_envs if per_iter is None else per_iter
         actions = self.act_batch(obs, eps, cvar)
         next_obs, reward, done, info = train_env.step(actions)          # other half of the double buffer
-        self.memory.add_batch(obs, actions, reward, next_obs, done.float())   # terminal obs, before the reset
+        if obs.is_cuda:   # terminal obs, appended before the reset overwrites the finished rows
+            self.memory.add_vector_step(obs, actions, reward, next_obs, done)
+        else:
+            self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         obs = train_env.reset_done()                                    # first observations where done
         loss = None
         if self.current_timestep >= self.learning_starts:

@@ -34,6 +34,27 @@ class ReplayBuffer:
                        as_t([reward], torch.float32), as_t(next_state, torch.float32).view(1, -1),
                        as_t([float(done)], torch.float32))
 
+    def add_vector_step(self, obs, actions_i32, reward, next_obs, done_u8):
+        """One vector step of the HIP env (device tensors exactly as VecMarineNavEnv returns them:
+        obs / next_obs [n,26] f32, actions [n] i32, reward [n] f32, done [n] u8) appended by ONE kernel
+        (csrc/replay.hip); same FIFO semantics as add_batch."""
+        import ctypes as C
+        from .. import _capi
+        n = obs.shape[0]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        for t in (obs, actions_i32, reward, next_obs, done_u8):
+            assert t.is_cuda and t.is_contiguous()
+        assert actions_i32.dtype == torch.int32 and done_u8.dtype == torch.uint8 and obs.dtype == torch.float32
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_replay_append(p(obs), p(actions_i32), p(reward), p(next_obs), p(done_u8), p(self.states),
+                                          p(self.next_states), p(self.actions), p(self.rewards), p(self.dones),
+                                          n, self.ptr, self.capacity, stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_replay_append failed ({rc})")
+        m = min(n, self.capacity)
+        self.ptr = (self.ptr + m) % self.capacity
+        self.size = min(self.capacity, self.size + m)
+
     def add_batch(self, states, actions, rewards, next_states, dones):
         """n transitions at once; FIFO eviction like deque(maxlen)."""
         n = states.shape[0]

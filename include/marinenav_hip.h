@@ -85,7 +85,7 @@ typedef struct mn_params {
     int32_t N;                       /* robot.py:29 sub-steps per action */
     int32_t num_beams;               /* robot.py:9, must equal MN_NUM_BEAMS */
     int32_t precision;               /* MN_PRECISION_* */
-    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = default (4), or 1, 2, 4, 8 */
+    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = default (2), or 1, 2, 4, 8 */
 } mn_params;
 
 typedef struct mn_handle mn_handle;
@@ -195,6 +195,16 @@ int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launche
 int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1, const float *W2,
                  const float *b2, const float *W3, const float *b3, const float *W4, const float *b4, float *qvals_dev,
                  int32_t n, int32_t num_taus, void *stream);
+
+/* ---- replay ring ------------------------------------------------------------------------------
+ * ReplayBuffer.add (thirdparty/IQN/replay_buffer.py:26-34) for n transitions in one launch: batch row i
+ * goes to ring slot (ptr + i) mod capacity (FIFO eviction like deque(maxlen); if n > capacity only the
+ * newest `capacity` rows are written, starting at ptr).  Batch: obs / next_obs [n][26] f32, actions [n]
+ * i32, reward [n] f32, done [n] u8.  Ring (device, the layout ReplayBuffer.sample returns): states /
+ * next_states [cap][26] f32, actions [cap] i64, rewards / dones [cap] f32.  The caller advances ptr. */
+int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const float *reward_dev, const float *next_obs_dev,
+                     const uint8_t *done_dev, float *ring_states, float *ring_next_states, int64_t *ring_actions,
+                     float *ring_rewards, float *ring_dones, int64_t n, int64_t ptr, int64_t capacity, void *stream);
 
 /* Benchmark hook: HIP events on the launch stream around the next mn_iqn_qvals launches. */
 int mn_iqn_profile_begin(int32_t max_launches);

@@ -64,3 +64,24 @@ def test_fused_act_agrees_with_torch_argmax(torch):
     assert bool((q.argmax(1)[clear] == q_ref.argmax(1)[clear]).all())
     assert float(clear.float().mean()) > 0.9
     env.close()
+
+
+def test_replay_append_kernel_matches_torch_ring(torch):
+    """mn_replay_append (one launch) == ReplayBuffer.add_batch (indexed copies), incl. wrap-around and
+    n > capacity (deque(maxlen) semantics, replay_buffer.py:19,26-34)."""
+    from distributional_rl_navigation_amd.iqn.replay_buffer import ReplayBuffer
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    a = ReplayBuffer(1000, 32, "cuda:0", seed=0, gamma=0.99)
+    b = ReplayBuffer(1000, 32, "cuda:0", seed=0, gamma=0.99)
+    for n in (300, 300, 300, 300, 64, 1500, 7, 1000):
+        obs = torch.randn(n, 26, device="cuda:0", generator=g)
+        nxt = torch.randn(n, 26, device="cuda:0", generator=g)
+        act = torch.randint(0, 9, (n,), device="cuda:0", dtype=torch.int32, generator=g)
+        rew = torch.randn(n, device="cuda:0", generator=g)
+        done = (torch.rand(n, device="cuda:0", generator=g) < 0.1).to(torch.uint8)
+        a.add_vector_step(obs, act, rew, nxt, done)
+        b.add_batch(obs, act.long(), rew, nxt, done.float())
+        assert a.ptr == b.ptr and a.size == b.size
+        for x, y in ((a.states, b.states), (a.next_states, b.next_states), (a.actions, b.actions),
+                     (a.rewards, b.rewards), (a.dones, b.dones)):
+            assert torch.equal(x, y), n
