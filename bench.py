@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-learner", action="store_true", help="random policy, step kernel only (configs[1])")
     ap.add_argument("--cpu-steps", type=int, default=4_000_000, help="oracle sample for cpu_baseline (0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
+    ap.add_argument("--no-train-graph", action="store_true", help="eager grad step instead of the captured hipGraph")
     ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
     ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env in the step kernel (0 = library default)")
@@ -91,6 +92,8 @@ def main():
                          distributed=args.shared_learner and world > 1, act_chunk=args.act_chunk)
     if agent is not None and args.torch_act:
         agent.use_fused_act = False
+    if agent is not None and args.no_train_graph:
+        agent.use_train_graph = False
     total_timesteps = 3_000_000 * n * world      # eps stays on the reference's initial 10 % ramp
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)

@@ -41,6 +41,8 @@ class IQNAgent:
         self.N = 8                                   # train-time quantile samples (agent.py:286,290)
         self.act_chunk = act_chunk
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
+        self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
+        self._graph = None
 
         self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
         self.qnetwork_target = ObsEncoder(state_size, action_size, seed, device)   # identical init (App. A A1)
@@ -199,7 +201,12 @@ class IQNAgent:
         return loss.mean()
 
     def train(self, experiences, taus_target=None, taus_local=None):
-        """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor)."""
+        """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor).
+        On the GPU (single learner, taus not injected) the whole step -- forward, backward, clip, Adam,
+        ~100 tiny kernels -- is replayed from one captured hipGraph."""
+        if (self.use_train_graph and experiences[0].is_cuda and not self.distributed
+                and taus_target is None and taus_local is None and experiences[0].shape[0] == self.BATCH_SIZE):
+            return self._train_graphed(experiences)
         self.optimizer.zero_grad(set_to_none=False)
         loss = self.compute_loss(experiences, taus_target, taus_local)
         loss.backward()
@@ -209,6 +216,55 @@ class IQNAgent:
         self.optimizer.step()
         self.grad_steps += 1
         return loss.detach()
+
+    def _train_graphed(self, experiences):
+        if self._graph is None:
+            dev = experiences[0].device
+            self._g_in = tuple(torch.empty_like(t) for t in experiences)
+            for dst, src in zip(self._g_in, experiences):
+                dst.copy_(src)
+            # Adam must keep its step counter on the device to be capturable; same arithmetic
+            state = self.optimizer.state_dict()
+            self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR, capturable=True)
+            if state["state"]:
+                for st in state["state"].values():
+                    st["step"] = torch.as_tensor(st["step"], dtype=torch.float32, device=dev)
+                self.optimizer.load_state_dict(state)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            snap = [p.detach().clone() for p in self.qnetwork_local.parameters()]
+            opt_snap = None
+            with torch.cuda.stream(side):   # warm-up iterations on a side stream (allocations, lazy init)
+                for _ in range(3):
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self.compute_loss(self._g_in).backward()
+                    torch.nn.utils.clip_grad_norm_(self.qnetwork_local.parameters(), 0.5)
+                    if opt_snap is None:
+                        import copy
+                        opt_snap = copy.deepcopy(self.optimizer.state_dict())
+                    self.optimizer.step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            # the warm-up must not count as training: restore weights and optimizer state
+            with torch.no_grad():
+                for p_, s_ in zip(self.qnetwork_local.parameters(), snap):
+                    p_.copy_(s_)
+            self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR, capturable=True)
+            if state["state"]:
+                self.optimizer.load_state_dict(state)
+            self._graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self._graph):
+                loss = self.compute_loss(self._g_in)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(self.qnetwork_local.parameters(), 0.5)
+                self.optimizer.step()
+                self._g_loss = loss.detach()
+            # capture does not execute: weights / optimizer untouched so far
+        for dst, src in zip(self._g_in, experiences):
+            dst.copy_(src)
+        self._graph.replay()
+        self.grad_steps += 1
+        return self._g_loss
 
     def soft_update(self, local_model, target_model):
         """agent.py:307-317 (TAU = 1.0 -> hard copy)."""
