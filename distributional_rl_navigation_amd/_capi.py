@@ -72,7 +72,7 @@ SIGNATURES = [
     ("mn_last_done_count", C.c_int, [_vp, _vp, _pi32]),
     ("mn_profile_begin", C.c_int, [_vp, _i32]),
     ("mn_profile_end", C.c_int, [_vp, _vp, _pd, _pi32]),
-    ("mn_iqn_qvals", C.c_int, [_vp] * 11 + [_i32, _i32, _vp]),
+    ("mn_iqn_act", C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, C.c_float, _vp, _i32, _i32, _vp]),
     ("mn_replay_append", C.c_int, [_vp] * 10 + [_i64, _i64, _i64, _vp]),
     ("mn_iqn_profile_begin", C.c_int, [_i32]),
     ("mn_iqn_profile_end", C.c_int, [_vp, _pd, _pi32]),

@@ -6,14 +6,17 @@
 //     x     = relu(cos @ W1^T + b1) * features                         (:177-181, Hadamard)
 //     x     = relu(x @ W2^T + b2) ; x = relu(x @ W3^T + b3) ; q = x @ W4^T + b4   (:183-185)
 //     Q     = mean over the K taus                                      (:188-191)
-// `features` (the three linear observation encoders, :170-173) are computed by the caller (a 26->208
-// linear map, <1 % of the FLOPs) and streamed in.
+// The three linear observation encoders (:170-173, a block-diagonal 26 -> 208 map, <1 % of the FLOPs)
+// run on the VALU inside the kernel (each lane computes 3-4 of the 208 features from the wave-uniform
+// observation row and parks them in a per-wave LDS buffer), so the only inputs are the raw
+// observations and the taus.  An optional epilogue does the
+// argmax and the epsilon-greedy choice of IQNAgent.act (agent.py:199-203).
 //
 // Why a kernel: in eager PyTorch this path is ~95 % of a training vector step at 65 536 envs and is
 // bound by elementwise traffic -- the [n*32, 208] activation is written and re-read five times
 // (profiles/r01_full_loop_kernel_stats_v1.txt).  Here a wavefront owns one environment (32 tau rows)
-// at a time and carries it through all four layers in registers; nothing but features, taus and the 9
-// Q-values touches HBM.
+// at a time and carries it through all four layers in registers; nothing but observations, taus and
+// the 9 Q-values / the action touches HBM.
 //
 // MFMA mapping: exact-f32 v_mfma_f32_16x16x4_f32 (the reference is float32; no reduced precision).
 // Every layer is computed TRANSPOSED, H^T = W . X^T: the weights are the A operand (16 output
@@ -23,7 +26,7 @@
 // features {16t + 4g + r : g = 0..3} -- which is exactly register r of C tile t in lane group g.  So a
 // layer's accumulator registers ARE the next layer's B operands: no LDS round trip, no shuffles.
 // The weights are permuted once per workgroup into that order while being copied to LDS
-// (125 KiB of the 160 KiB: one 512-thread workgroup per CU, 2 waves per SIMD so one wave's bias /
+// (155 KiB of the 160 KiB incl. the encoders: one 512-thread workgroup per CU, 2 waves per SIMD so one wave's bias /
 // ReLU / cos VALU work runs under the other's MFMAs); each ds_read_b128 feeds 4 k-steps x 2 tau
 // tiles = 8 MFMAs.  Layers 1 and 2 are fused over the 13 feature tiles of the 208-wide activation,
 // so the live state is 32 accumulator + 32 cos registers per lane.
@@ -51,7 +54,12 @@ constexpr int OFF_B1 = OFF_W4 + 4 * 64 * 4;       // [208]
 constexpr int OFF_B2 = OFF_B1 + F;                // [64]
 constexpr int OFF_B3 = OFF_B2 + H;                // [64]
 constexpr int OFF_B4 = OFF_B3 + H;                // [16]
-constexpr int LDS_FLOATS = OFF_B4 + 16;
+constexpr int OBS = MN_OBS_DIM;                   // 26
+constexpr int OBS4 = 7;                           // 26 inputs padded to 7 float4
+constexpr int OFF_WE = OFF_B4 + 16;               // [7 i4][208 f][4]: block-diagonal encoder weights
+constexpr int OFF_BE = OFF_WE + OBS4 * F * 4;     // [208] encoder biases
+constexpr int OFF_FB = OFF_BE + F;                // [8 waves][208] per-wave feature buffer
+constexpr int LDS_FLOATS = OFF_FB + 8 * F;
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -70,12 +78,24 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ features, const float *__restrict__ taus,
-                                                           const float *__restrict__ W1, const float *__restrict__ b1,
-                                                           const float *__restrict__ W2, const float *__restrict__ b2,
-                                                           const float *__restrict__ W3, const float *__restrict__ b3,
-                                                           const float *__restrict__ W4, const float *__restrict__ b4,
-                                                           float *__restrict__ qvals, int n) {
+struct IqnWeights {   // device pointers, nn.Linear layout [out][in]
+    const float *ve_w, *ve_b, *ge_w, *ge_b, *se_w, *se_b;   // velocity / goal / sensor encoders
+    const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;     // cos_embedding, hidden_layer, hidden_layer_2, output_layer
+};
+
+// block-diagonal encoder weight: feature f (0..207) x observation input i (0..25)  (model.py:126-128,170-173)
+__device__ __forceinline__ float enc_weight(const IqnWeights &w, int f, int i) {
+    if (f < 16) return (i < 2) ? w.ve_w[f * 2 + i] : 0.f;
+    if (f < 32) return (i >= 2 && i < 4) ? w.ge_w[(f - 16) * 2 + (i - 2)] : 0.f;
+    return (i >= 4 && i < OBS) ? w.se_w[(f - 32) * 22 + (i - 4)] : 0.f;
+}
+
+__global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
+                                                           IqnWeights w, float *__restrict__ qvals,
+                                                           const float *__restrict__ explore_u, float eps,
+                                                           int32_t *__restrict__ actions, int n) {
+    const float *__restrict__ W1 = w.W1, *__restrict__ b1 = w.b1, *__restrict__ W2 = w.W2, *__restrict__ b2 = w.b2;
+    const float *__restrict__ W3 = w.W3, *__restrict__ b3 = w.b3, *__restrict__ W4 = w.W4, *__restrict__ b4 = w.b4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
 
@@ -101,6 +121,13 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
     for (int i = tid; i < F; i += blockDim.x) lds[OFF_B1 + i] = b1[i];
     if (tid < H) { lds[OFF_B2 + tid] = b2[tid]; lds[OFF_B3 + tid] = b3[tid]; }
     if (tid < 16) lds[OFF_B4 + tid] = tid < A_OUT ? b4[tid] : 0.f;
+    // encoder: WEp[i4][f][c] = Wenc[f][4*i4 + c] (block-diagonal 208 x 26, zero elsewhere / padding)
+    for (int i = tid; i < OBS4 * F * 4; i += blockDim.x) {
+        const int c = i & 3, f = (i >> 2) % F, i4 = (i >> 2) / F;
+        const int inp = 4 * i4 + c;
+        lds[OFF_WE + i] = inp < OBS ? enc_weight(w, f, inp) : 0.f;
+    }
+    for (int i = tid; i < F; i += blockDim.x) lds[OFF_BE + i] = i < 16 ? w.ve_b[i] : (i < 32 ? w.ge_b[i - 16] : w.se_b[i - 32]);
     __syncthreads();
 
     const int lane = tid & 63, g = lane >> 4, col = lane & 15;
@@ -128,7 +155,32 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) cb[m][nt] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[m]));
 
-        const f32x4 *fe = reinterpret_cast<const f32x4 *>(features + (size_t)e * F) + g;   // + 4*t per tile
+        // ---- observation encoders (model.py:170-173): lane l computes features l, l+64, l+128, l+192 from
+        // the 26 inputs (wave-uniform -> scalar loads) and parks them in this wave's LDS buffer, from
+        // where every lane later reads the float4 {16t + 4g + r} it needs for the Hadamard product
+        {
+            const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
+            float ov[OBS4 * 4];
+#pragma unroll
+            for (int i = 0; i < OBS4 * 4; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
+            float *fb = lds + OFF_FB + wave * F;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = lane + 64 * j;
+                if (f < F) {
+                    float a = lds[OFF_BE + f];
+#pragma unroll
+                    for (int i4 = 0; i4 < OBS4; ++i4) {
+                        const f32x4 wv = ldsv[(OFF_WE >> 2) + i4 * F + f];
+                        a += wv[0] * ov[4 * i4] + wv[1] * ov[4 * i4 + 1] + wv[2] * ov[4 * i4 + 2] + wv[3] * ov[4 * i4 + 3];
+                    }
+                    fb[f] = a;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const f32x4 *fbv = reinterpret_cast<const f32x4 *>(lds + OFF_FB + wave * F) + g;   // + 4*t per tile
 
         f32x4 acc2[4][NT];
 #pragma unroll
@@ -138,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 
         // ---- layers 1 + 2 fused over the 13 feature tiles ------------------------------------------
         for (int t = 0; t < T1; ++t) {
-            const f32x4 fv = fe[4 * t];          // features[e][16t + 4g + r]
+            const f32x4 fv = fbv[4 * t];          // features[e][16t + 4g + r]
             f32x4 acc1[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -201,11 +253,31 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
         }
         // ---- mean over the 32 taus (model.py:190); action = 4g + r -----------------------------------
         const f32x4 bias4 = ldsv[(OFF_B4 >> 2) + g];
+        float qa[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float s0 = row_sum16(acc4[0][r] + acc4[1][r]) * (1.0f / K_TAUS) + bias4[r];
+            qa[r] = row_sum16(acc4[0][r] + acc4[1][r]) * (1.0f / K_TAUS) + bias4[r];
             const int action = 4 * g + r;
-            if (col == 0 && action < A_OUT) qvals[(size_t)e * A_OUT + action] = s0;
+            if (qvals && col == 0 && action < A_OUT) qvals[(size_t)e * A_OUT + action] = qa[r];
+        }
+        // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
+        if (actions) {
+            // lane 16g holds actions 4g..4g+3; gather the 9 values (first maximum wins, like np.argmax)
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int a = 0; a < A_OUT; ++a) {
+                const float v = __shfl(qa[a & 3], 16 * (a >> 2));
+                if (v > best) { best = v; arg = a; }
+            }
+            if (lane == 0) {
+                int act = arg;
+                if (explore_u && eps > 0.f) {
+                    const float u = explore_u[e];            // greedy iff u > eps (agent.py:200)
+                    if (!(u > eps)) { act = (int)(u / eps * (float)A_OUT); act = act > A_OUT - 1 ? A_OUT - 1 : act; }
+                }
+                actions[e] = act;
+            }
         }
     }
 }
@@ -244,10 +316,11 @@ extern "C" int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launch
     return MN_OK;
 }
 
-extern "C" int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1,
-                            const float *W2, const float *b2, const float *W3, const float *b3, const float *W4,
-                            const float *b4, float *qvals_dev, int32_t n, int32_t num_taus, void *stream) {
-    if (!features_dev || !taus_dev || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !W4 || !b4 || !qvals_dev) return MN_ERR_INVALID;
+extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+                          const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
+                          void *stream) {
+    if (!obs_dev || !taus_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
+    for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
     static int n_cu = 0;
     static bool attr_set = false;
@@ -261,12 +334,14 @@ extern "C" int mn_iqn_qvals(const float *features_dev, const float *taus_dev, co
             return MN_ERR_HIP;
         attr_set = true;
     }
+    IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
+                    weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
     if (blocks > n_cu) blocks = n_cu;
     const bool prof = g_prof_n < g_prof_max;
     if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], (hipStream_t)stream);
-    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, features_dev,
-                       taus_dev, W1, b1, W2, b2, W3, b3, W4, b4, qvals_dev, n);
+    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, obs_dev,
+                       taus_dev, w, qvals_dev, explore_u_dev, eps, actions_dev, n);
     if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], (hipStream_t)stream); ++g_prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }

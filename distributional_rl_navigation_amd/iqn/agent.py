@@ -159,7 +159,11 @@ class IQNAgent:
     @torch.no_grad()
     def act_batch(self, states, eps, cvar=1.0):
         """Batched eps-greedy act (agent.py:186-205 per row): states [n,26] f32 on device ->
-        actions [n] int32 on device.  Exploration draws come from a device generator."""
+        actions [n] int32 on device.  On the GPU this is ONE fused HIP kernel (network, mean over taus,
+        argmax, exploration); exploration draws come from a device generator."""
+        if states.is_cuda and self.use_fused_act:
+            from .fused_act import fused_act
+            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen)
         q = self.qvals_batch(states, cvar)
         greedy = q.argmax(dim=1).to(torch.int32)
         if eps <= 0.0:

@@ -1,43 +1,70 @@
-"""Python side of the fused IQN action-value kernel (csrc/iqn_act.hip, `mn_iqn_qvals`)."""
+"""Python side of the fused IQN act kernel (csrc/iqn_act.hip, `mn_iqn_act`)."""
 import ctypes as C
 
 import torch
 
 from .. import _capi
 
+_ORDER = ("velocity_encoder", "goal_encoder", "sensor_encoder", "cos_embedding", "hidden_layer", "hidden_layer_2", "output_layer")
+
 
 def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-@torch.no_grad()
-def fused_qvals(net, states, cvar=1.0, taus=None, generator=None):
-    """Q(s, .) = mean over K = 32 quantile samples (model.py:188-191) for states [n, 26] on the GPU.
+def _weight_ptrs(net):
+    ptrs = (C.c_void_p * 14)()
+    i = 0
+    for name in _ORDER:
+        m = getattr(net, name)
+        for t in (m.weight, m.bias):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+            ptrs[i] = t.data_ptr()
+            i += 1
+    return ptrs
 
-    The three observation encoders (26 -> 208, model.py:170-173) run in PyTorch; the cosine
-    embedding, Hadamard product, the three hidden layers and the mean over taus run in one HIP kernel.
-    `taus` [n, 32] may be injected (tests); otherwise they are drawn on the device generator.
-    """
-    assert states.is_cuda and states.dtype == torch.float32
-    n = states.shape[0]
-    K = net.K
-    feats = torch.cat((net.velocity_encoder(states[:, :2]), net.goal_encoder(states[:, 2:4]),
-                       net.sensor_encoder(states[:, 4:])), 1).contiguous()
+
+def _taus(net, n, device, cvar, taus, generator):
     if taus is None:
-        taus = torch.rand(n, K, device=states.device, generator=generator)
-    taus = taus.to(device=states.device, dtype=torch.float32)
+        taus = torch.rand(n, net.K, device=device, generator=generator)
+    taus = taus.to(device=device, dtype=torch.float32)
     if torch.is_tensor(cvar):
-        taus = taus * cvar.to(states.device).view(-1, 1)
+        taus = taus * cvar.to(device).view(-1, 1)
     elif cvar != 1.0:
         taus = taus * cvar
-    taus = taus.contiguous()
-    q = torch.empty(n, net.action_size, dtype=torch.float32, device=states.device)
-    w = [net.cos_embedding.weight, net.cos_embedding.bias, net.hidden_layer.weight, net.hidden_layer.bias,
-         net.hidden_layer_2.weight, net.hidden_layer_2.bias, net.output_layer.weight, net.output_layer.bias]
-    for t in w:
-        assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
-    stream = C.c_void_p(torch.cuda.current_stream(states.device).cuda_stream)
-    rc = _capi.lib().mn_iqn_qvals(_p(feats), _p(taus), *[_p(t) for t in w], _p(q), n, K, stream)
+    return taus.contiguous()
+
+
+@torch.no_grad()
+def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False):
+    """IQNAgent.act for states [n, 26] on the GPU in ONE kernel: encoders, cosine embedding, Hadamard
+    product, hidden layers, mean over K = 32 taus, argmax and epsilon-greedy.
+    Returns actions [n] int32 (and Q-values [n, 9] if want_qvals).  `taus` [n, 32] may be injected."""
+    assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous()
+    n = states.shape[0]
+    dev = states.device
+    t = _taus(net, n, dev, cvar, taus, generator)
+    u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
+    actions = torch.empty(n, dtype=torch.int32, device=dev)
+    q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = _capi.lib().mn_iqn_act(_p(states), _p(t), _weight_ptrs(net), _p(q) if q is not None else None,
+                                _p(u) if u is not None else None, C.c_float(float(eps)), _p(actions), n, net.K, stream)
     if rc:
-        raise _capi.MarineNavHipError(f"mn_iqn_qvals failed ({rc})")
+        raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
+    return (actions, q) if want_qvals else actions
+
+
+@torch.no_grad()
+def fused_qvals(net, states, cvar=1.0, taus=None, generator=None):
+    """Q(s, .) = mean over K = 32 quantile samples (model.py:188-191) for states [n, 26] on the GPU."""
+    assert states.is_cuda and states.dtype == torch.float32
+    states = states.contiguous()
+    n = states.shape[0]
+    t = _taus(net, n, states.device, cvar, taus, generator)
+    q = torch.empty(n, net.action_size, dtype=torch.float32, device=states.device)
+    stream = C.c_void_p(torch.cuda.current_stream(states.device).cuda_stream)
+    rc = _capi.lib().mn_iqn_act(_p(states), _p(t), _weight_ptrs(net), _p(q), None, C.c_float(0.0), None, n, net.K, stream)
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
     return q

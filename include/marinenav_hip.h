@@ -181,20 +181,22 @@ int mn_profile_begin(mn_handle *h, int32_t max_launches);
 int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
 
 /* ---- IQN inference ---------------------------------------------------------------------------
- * Fused ObsEncoder.forward + mean over the K = 32 quantile samples of ObsEncoder.get_qvals
- * (thirdparty/IQN/model.py:141-191) for n observations:
- *   features_dev [n][208] f32 : cat(velocity_encoder, goal_encoder, sensor_encoder outputs), model.py:170-173
- *   taus_dev     [n][32]  f32 : quantile fractions, already multiplied by cvar (model.py:149-153)
- *   W1 [208][64], b1 [208]    : cos_embedding      (nn.Linear layout [out][in], device pointers)
- *   W2 [64][208], b2 [64]     : hidden_layer
- *   W3 [64][64],  b3 [64]     : hidden_layer_2
- *   W4 [9][64],   b4 [9]      : output_layer
- *   qvals_dev    [n][9]   f32 : mean over taus of the quantile values
- * Exact float32 (v_mfma_f32_16x16x4_f32); weights are read on every call, so they may change
- * between calls (training).  num_taus must be 32. */
-int mn_iqn_qvals(const float *features_dev, const float *taus_dev, const float *W1, const float *b1, const float *W2,
-                 const float *b2, const float *W3, const float *b3, const float *W4, const float *b4, float *qvals_dev,
-                 int32_t n, int32_t num_taus, void *stream);
+ * Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
+ * K = 32 quantile samples + mean over them (model.py:141-191), then argmax and the epsilon-greedy choice.
+ *   obs_dev   [n][26] f32 : observations (row-major, as mn_step writes them)
+ *   taus_dev  [n][32] f32 : quantile fractions, already multiplied by cvar (model.py:149-153)
+ *   weights   [14]        : HOST array of DEVICE pointers, nn.Linear layout [out][in], in state-dict order:
+ *                           velocity_encoder.weight [16][2], .bias [16], goal_encoder.weight [16][2], .bias [16],
+ *                           sensor_encoder.weight [176][22], .bias [176], cos_embedding.weight [208][64], .bias [208],
+ *                           hidden_layer.weight [64][208], .bias [64], hidden_layer_2.weight [64][64], .bias [64],
+ *                           output_layer.weight [9][64], .bias [9].  Read on every call (they change while training).
+ *   qvals_dev [n][9] f32  : mean over taus of the quantile values (may be NULL)
+ *   explore_u_dev [n] f32 : uniform [0,1) draws for exploration (may be NULL = greedy); env i takes the
+ *                           greedy action iff u_i > eps (agent.py:200), else action floor(u_i / eps * 9)
+ *   actions_dev [n] i32   : chosen actions (may be NULL if only Q-values are wanted)
+ * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32. */
+int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+               const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus, void *stream);
 
 /* ---- replay ring ------------------------------------------------------------------------------
  * ReplayBuffer.add (thirdparty/IQN/replay_buffer.py:26-34) for n transitions in one launch: batch row i
@@ -206,7 +208,7 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
                      const uint8_t *done_dev, float *ring_states, float *ring_next_states, int64_t *ring_actions,
                      float *ring_rewards, float *ring_dones, int64_t n, int64_t ptr, int64_t capacity, void *stream);
 
-/* Benchmark hook: HIP events on the launch stream around the next mn_iqn_qvals launches. */
+/* Benchmark hook: HIP events on the launch stream around the next mn_iqn_act launches. */
 int mn_iqn_profile_begin(int32_t max_launches);
 int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches);
 

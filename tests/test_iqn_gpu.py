@@ -119,3 +119,25 @@ def test_graphed_train_step_equals_eager(torch):
     np.testing.assert_allclose(l0, l1, rtol=2e-3)
     for a, b in zip(p0, p1):
         assert float((a - b).abs().max()) < 6e-4
+
+
+def test_fused_act_epilogue_argmax_and_exploration(torch):
+    """Epilogue of the act kernel (agent.py:199-203): greedy = first argmax of its own Q-values;
+    eps-greedy takes the greedy action iff u > eps, else a uniform random action."""
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    net = ObsEncoder.load(os.path.join(G, "pretrained_IQN_seed3"), "cuda:0")
+    n = 20000
+    g = torch.Generator(device="cuda:0"); g.manual_seed(1)
+    obs = torch.randn(n, 26, device="cuda:0", generator=g) * 5.0
+    taus = torch.rand(n, 32, device="cuda:0", generator=g)
+    a, q = fused_act(net, obs, 0.0, 1.0, taus=taus, want_qvals=True)
+    assert a.dtype == torch.int32 and bool((a.long() == q.argmax(1)).all())
+    g2 = torch.Generator(device="cuda:0"); g2.manual_seed(7)
+    a1 = fused_act(net, obs, 1.0, 1.0, taus=taus, generator=g2)            # always explore
+    cnt = torch.bincount(a1.long(), minlength=9).float() / n
+    assert bool(((a1 >= 0) & (a1 < 9)).all()) and float((cnt - 1 / 9).abs().max()) < 0.01
+    g3 = torch.Generator(device="cuda:0"); g3.manual_seed(8)
+    a2 = fused_act(net, obs, 0.3, 1.0, taus=taus, generator=g3)
+    frac_greedy = float((a2 == a).float().mean())                          # 0.7 + 0.3 * P(random == greedy)
+    assert 0.70 < frac_greedy < 0.76
