@@ -188,20 +188,37 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // ---- layers 1 + 2 fused over the 13 feature tiles ------------------------------------------
+        // ---- layers 1 + 2 fused over the 13 feature tiles, software-pipelined: the layer-1 MFMAs of
+        // tile t+1 are issued BEFORE the bias / ReLU / Hadamard epilogue of tile t, so the wave's own VALU
+        // work sits in the shadow of its own MFMAs (in-order issue would otherwise drain the matrix pipe
+        // at every tile boundary) -------------------------------------------------------------------
+        f32x4 acc1[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const f32x4 a = ldsv[(OFF_W1 >> 2) + m4 * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc1[nt] = mfma(a[j], cb[4 * m4 + j][nt], acc1[nt]);
+        }
+#pragma unroll
         for (int t = 0; t < T1; ++t) {
-            const f32x4 fv = fbv[4 * t];          // features[e][16t + 4g + r]
-            f32x4 acc1[NT];
+            f32x4 nxt[NT];
+            if (t + 1 < T1) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NT; ++nt) nxt[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int m4 = 0; m4 < 4; ++m4) {
-                const f32x4 a = ldsv[(OFF_W1 >> 2) + (t * 4 + m4) * 64 + lane];
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const f32x4 a = ldsv[(OFF_W1 >> 2) + ((t + 1) * 4 + m4) * 64 + lane];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc1[nt] = mfma(a[j], cb[4 * m4 + j][nt], acc1[nt]);
+                        for (int nt = 0; nt < NT; ++nt) nxt[nt] = mfma(a[j], cb[4 * m4 + j][nt], nxt[nt]);
+                }
             }
+            const f32x4 fv = fbv[4 * t];                             // features[e][16t + 4g + r]
             const f32x4 bias = ldsv[(OFF_B1 >> 2) + 4 * t + g];      // b1[16t + 4g + r]
             f32x4 h1[NT];
 #pragma unroll
@@ -213,6 +230,10 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma(a[r], h1[nt][r], acc2[mt][nt]);
+            }
+            if (t + 1 < T1) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc1[nt] = nxt[nt];
             }
         }
         // ---- layer 2 epilogue, layer 3 ---------------------------------------------------------------
@@ -322,18 +343,18 @@ extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const flo
     if (!obs_dev || !taus_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
-    static int n_cu = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int dev = 0;
+    static int n_cu_of[64] = {0};   // per device: CU count, and "dynamic LDS attribute set" marker
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
+    if (n_cu_of[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
-        n_cu = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
             return MN_ERR_HIP;
-        attr_set = true;
+        n_cu_of[dev] = prop.multiProcessorCount;
     }
+    const int n_cu = n_cu_of[dev];
     IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
                     weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
