@@ -93,6 +93,8 @@ static int derive(mn_handle *h, const mn_params &p) {
         d.beam_cos[i] = cos(d.beam_rel[i]);
         d.beam_sin[i] = sin(d.beam_rel[i]);
     }
+    d.fan_sin = sin(p.sonar_angle / 2); d.fan_cos = cos(p.sonar_angle / 2);
+    d.fan_filter = (p.sonar_angle / 2 < 0.49 * M_PI) ? 1 : 0;
     d.two_pi = 2 * M_PI;
     d.two_pi_r = 2 * M_PI * p.core_r;
     d.two_pi_vrel = 2 * M_PI * p.v_rel_max;

@@ -52,6 +52,8 @@ struct MnDev {
     double sonar_range;
     double beam_rel[MN_NUM_BEAMS], beam_cos[MN_NUM_BEAMS], beam_sin[MN_NUM_BEAMS];
     double rot_c[3], rot_s[3];  // cos / sin of w[i]*dt: per-sub-step heading rotation
+    double fan_sin, fan_cos;    // sin / cos of half the sonar opening angle (work-list wedge test)
+    int32_t fan_filter;         // 1 if the fan is a convex wedge (half angle < 90 deg)
     double two_pi;          // 2*pi as python computes it
     double two_pi_r;        // (2*pi)*r              -> Gamma = two_pi_r * v_edge
     double two_pi_vrel;     // (2*pi)*v_rel_max      -> check_core same-direction boundary

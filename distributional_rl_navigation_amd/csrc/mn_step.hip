@@ -52,7 +52,7 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 
 template <typename M, bool PARITY, int L>
-__global__ __launch_bounds__(256, (L >= 4 && !PARITY) ? 4 : 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
                                                       float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                       uint8_t *__restrict__ done_out, uint8_t *__restrict__ info_out,
                                                       int parity) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, (L >= 4 && !PARITY) ? 4 : 2) void mn_step_kern
         const bool v = k < no;         // padding: far away, r = 0 -> can never be hit, so the beam
         obx[k] = v ? obx[k] : 1.0e6;   // loop needs no count test
         oby[k] = v ? oby[k] : 1.0e6;
-        obr2[k] = v ? obr2[k] * obr2[k] : 0.0;
+        obr2[k] = v ? obr2[k] : 0.0;   // radius (squared where needed)
     }
 
     // marinenav_env.py:205 dis_before
@@ -185,25 +185,41 @@ __global__ __launch_bounds__(256, (L >= 4 && !PARITY) ? 4 : 2) void mn_step_kern
     const double dis_after = sqrt(dax * dax + day * day);
 
     // ---- observation (marinenav_env.py:273-326) ------------------------------------------------
-    // obstacle centres in the robot frame: m_r = R(theta)^T (c - p); |m_r| = |c - p|
+    // Obstacle centres in the robot frame, m_r = R(theta)^T (c - p) (|m_r| = |c - p|), and at the same
+    // time the sonar work-list: only obstacles that can intersect the fan at all -- within range + r of
+    // the robot and inside the +-60 degree wedge widened by r -- are appended, IN GENERATION ORDER, to a
+    // lane-private LDS column.  A dropped obstacle can never produce a candidate, so it can neither be
+    // hit nor trigger the reference's `break`; the scan over the list is therefore equivalent to the
+    // scan over all obstacles (robot.py:147-198).  Typically 0-3 of the 10 obstacles survive, and the
+    // beam loop runs to the longest list in the wavefront instead of 10.
+    __shared__ double lst_x[MN_MAX_OBS][256], lst_y[MN_MAX_OBS][256];
+    __shared__ M lst_r[MN_MAX_OBS][256];     // radius: float32 is exact for the compact tables, float64 in parity mode
+    const int tl = threadIdx.x;
+    int nrel = 0;
     double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
+    const double reach0 = P.sonar_range + 0.05;
     if (!(P.debug_skip & 8))
 #pragma unroll
     for (int k = 0; k < MN_MAX_OBS; ++k) {
         const double mx = obx[k] - x, my = oby[k] - y;
-        obx[k] = cs * mx + sn * my;
-        oby[k] = -sn * mx + cs * my;
+        const double rx_ = cs * mx + sn * my, ry_ = -sn * mx + cs * my;
         const double d2 = mx * mx + my * my;
-        const bool nearer = (k < no) && (d2 < best);
+        const bool in = k < no;
+        const bool nearer = in && (d2 < best);
         best = nearer ? d2 : best;
-        best_r2 = nearer ? obr2[k] : best_r2;
+        best_r2 = nearer ? obr2[k] * obr2[k] : best_r2;
+        const double r = obr2[k];          // (radius; squared below)
+        const double reach = reach0 + r;
+        const bool rel = in && (d2 <= reach * reach) &&
+                         (!P.fan_filter || (P.fan_sin * rx_ - P.fan_cos * fabs(ry_) >= -(r + 0.05)));
+        if (rel) { lst_x[nrel][tl] = rx_; lst_y[nrel][tl] = ry_; lst_r[nrel][tl] = (M)r; }
+        nrel += rel ? 1 : 0;
     }
     const M range = (M)P.sonar_range;
     const double half_pi = 0.5 * 3.141592653589793, three_half_pi = 3 * 3.141592653589793 / 2;
     M bxo[BPL], byo[BPL];   // this lane's beams, hit point in the robot frame
-#pragma unroll
-    for (int j = 0; j < BPL; ++j) { bxo[j] = 0; byo[j] = 0; }
-    if (!(P.debug_skip & 2))
+    double bdx[BPL], bdy[BPL];
+    MnBeam<M> beam[BPL];
 #pragma unroll
     for (int j = 0; j < BPL; ++j) {
         const int b = q + L * j;
@@ -213,28 +229,37 @@ __global__ __launch_bounds__(256, (L >= 4 && !PARITY) ? 4 : 2) void mn_step_kern
         const bool down = fabs(angle - three_half_pi) < 1e-03;
         // beam direction in the robot frame: the constant (cos rel, sin rel); a snapped beam points
         // along world (0,+-1), i.e. R^T (0,+-1) = +-(sin theta, cos theta)
-        double bx = P.beam_cos[bb], by = P.beam_sin[bb];
+        bdx[j] = P.beam_cos[bb]; bdy[j] = P.beam_sin[bb];
         if (up || down) {
             const double sg = up ? 1.0 : -1.0;
-            bx = sg * sn; by = sg * cs;
+            bdx[j] = sg * sn; bdy[j] = sg * cs;
         }
-        MnBeam<M> beam;
-        beam.init();
+        beam[j].init();
+    }
+    if (!(P.debug_skip & 2))
+    for (int s_ = 0; __any(s_ < nrel); ++s_) {
+        const bool v = s_ < nrel;
+        const double ox_ = lst_x[s_][tl], oy_ = lst_y[s_][tl];
+        const double rr = (double)lst_r[s_][tl];
+        const double r2o = v ? rr * rr : -1.0;    // exhausted list: h^2 < 0 -> NaN -> never a candidate
 #pragma unroll
-        for (int k = 0; k < MN_MAX_OBS; ++k) {
+        for (int j = 0; j < BPL; ++j) {
             double tc, h2;
-            mn_beam_geom(obx[k], oby[k], obr2[k], bx, by, tc, h2);
-            beam.update((M)tc, (M)h2, range);
+            mn_beam_geom(ox_, oy_, r2o, bdx[j], bdy[j], tc, h2);
+            beam[j].update((M)tc, (M)h2, range);
         }
-        const bool hit = beam.hit();
-        bxo[j] = hit ? beam.dist * (M)bx : M(0);  // misses are (0,0): marinenav_env.py:315-316
-        byo[j] = hit ? beam.dist * (M)by : M(0);
+    }
+#pragma unroll
+    for (int j = 0; j < BPL; ++j) {
+        const bool hit = beam[j].hit();
+        bxo[j] = hit ? beam[j].dist * (M)bdx[j] : M(0);  // misses are (0,0): marinenav_env.py:315-316
+        byo[j] = hit ? beam[j].dist * (M)bdy[j] : M(0);
     }
 
     // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
     double reward = P.timestep_penalty;
     reward += dis_before - dis_after;
-    const bool collide = no > 0 && sqrt(best) <= sqrt(best_r2) + P.robot_r;
+    const bool collide = no > 0 && sqrt(best) <= sqrt(best_r2) + P.robot_r;   // sqrt(r*r) == r exactly
     const bool reach = dis_after <= P.goal_dis;  // check_reach_goal (:338-342)
     const bool out = (x < 0.0 || x > P.width) || (y < 0.0 || y > P.height);
     int done, info;
