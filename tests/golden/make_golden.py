@@ -17,6 +17,7 @@ Outputs (all small, committed):
                         files + the reference's stored returns/success/time/energy
   eval_config_seed3.json     data file shipped by the reference (30 evaluation worlds)
   g7_iqn.npz            IQN forward / loss / grads with injected taus, adjust_cvar, linear_eps
+  g8_boundary_trace.npz set_boundary = True, robot.N = 5 trace (run_experiments.py settings)
   pretrained_IQN_seed3/ checkpoint data files shipped by the reference (weights only)
 """
 import contextlib
@@ -191,6 +192,31 @@ def g2_traces():
     sched = dict(timesteps=[0, 900, 2100], num_cores=[4, 6, 8], num_obstacles=[6, 8, 10],
                  min_start_goal_dis=[30.0, 35.0, 40.0])
     trace(5, sched, "g2_trace_seed5_schedule.npz", n_steps=3100)
+
+
+def g8_boundary_trace():
+    """run_experiments.py:192-211 style settings: set_boundary = True, robot.N = 5, fixed start/goal near
+    the map edge so that 'out of boundary' terminations occur; caller-side reset on done."""
+    env = MarineNavEnv(seed=21)
+    env.set_boundary = True
+    env.robot.N = 5
+    env.reset_start_and_goal = False
+    env.start = np.array([3.0, 4.0])
+    env.goal = np.array([46.0, 45.0])
+    env.num_cores, env.num_obs = 8, 8
+    ar = np.random.RandomState(77)
+    n_steps = 1500
+    actions = ar.randint(9, size=n_steps)
+    obs0 = env.reset()
+    rec = {k: [] for k in ("obs", "reward", "done", "info", "state", "ep_t", "reset_obs")}
+    for t in range(n_steps):
+        ob, r, d, info = env.step(int(actions[t]))
+        rec["obs"].append(ob); rec["reward"].append(r); rec["done"].append(d)
+        rec["info"].append(INFO_CODE[info["state"]]); rec["state"].append(robot_state(env)); rec["ep_t"].append(env.episode_timesteps)
+        rec["reset_obs"].append(env.reset() if d else np.zeros(26))
+    out = {k: np.array(v) for k, v in rec.items()}
+    out.update(actions=actions, obs0=obs0, seed=21, start=env.start, goal=env.goal)
+    np.savez_compressed(os.path.join(OUT, "g8_boundary_trace.npz"), **out)
 
 
 def g3_single_step(n_worlds=64, per_world=32):
@@ -455,7 +481,7 @@ def g7_iqn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_reset(); g1b_eval_worlds()
     if "g2" in which:
@@ -470,6 +496,8 @@ if __name__ == "__main__":
         g6_pretrained_replay()
     if "g7" in which:
         g7_iqn()
+    if "g8" in which:
+        g8_boundary_trace()
     for f in sorted(os.listdir(OUT)):
         p = os.path.join(OUT, f)
         if os.path.isfile(p):

@@ -97,3 +97,24 @@ def test_learn_vec_runs_and_trains(torch):
     # replay holds consistent transitions: reward/done of the stored rows are finite / binary
     assert torch.isfinite(agent.memory.states).all() and set(agent.memory.dones.unique().tolist()) <= {0.0, 1.0}
     env.close()
+
+
+def test_train_driver_end_to_end(torch, tmp_path):
+    """train_iqn.run_trial (counterpart of train_IQN_model.py:74-121) on a tiny budget: writes the
+    reference's per-trial files with the reference's schemas."""
+    from distributional_rl_navigation_amd import train_iqn
+    params = dict(agent="IQN", seed=2, total_timesteps=40_000, eval_freq=20_000, save_dir=str(tmp_path),
+                  training_time="test")
+    d = train_iqn.run_trial("cuda:0", params, n_envs=1024, batch=64, replay=20_000)
+    files = sorted(os.listdir(d))
+    for f in ("trial_config.json", "training_schedule.json", "eval_config.json", "greedy_evaluations.npz",
+              "adaptive_evaluations.npz", "network_params.pth", "constructor_params.json"):
+        assert f in files, (f, files)
+    with open(os.path.join(d, "eval_config.json")) as f, open(os.path.join(G, "eval_config_seed3.json")) as g:
+        mine, ref = json.load(f), json.load(g)
+    assert mine["env_7"]["env"]["cores"] == ref["env_7"]["env"]["cores"]      # same 30 eval worlds as the reference
+    z = np.load(os.path.join(d, "greedy_evaluations.npz"), allow_pickle=True)
+    assert z["rewards"].shape[1] == 30 and len(z["timesteps"]) >= 1
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    net = ObsEncoder.load(d)
+    assert sum(p.numel() for p in net.parameters()) == 35785

@@ -376,3 +376,27 @@ def test_schedule_and_ragged_batch(torch):
     assert ep[66] == z["ep_t"][-1] and tot[66] == z["tot_t"][-1]
     assert worst < 1e-7, worst
     env.close()
+
+
+def test_g8_boundary_and_robot_n5_on_device(torch):
+    """Out-of-boundary branch (marinenav_env.py:240-243) and robot.N = 5 (run_experiments.py:204) through
+    the gym-shaped facade, against the reference trace."""
+    from distributional_rl_navigation_amd.marinenav_env.env import MarineNavEnv
+    z = np.load(os.path.join(G, "g8_boundary_trace.npz"))
+    env = MarineNavEnv(seed=int(z["seed"]))
+    env.set_boundary = True
+    env.robot.N = 5
+    env.reset_start_and_goal = False
+    env.start = np.array(z["start"]); env.goal = np.array(z["goal"])
+    env.num_cores, env.num_obs = 8, 8
+    np.testing.assert_allclose(env.reset(), z["obs0"], atol=1e-10)
+    names = ("normal", "out of boundary", "too long episode", "collision", "reach goal")
+    for t, a in enumerate(z["actions"]):
+        obs, r, d, info = env.step(int(a))
+        assert d == bool(z["done"][t]) and info["state"] == names[int(z["info"][t])], t
+        np.testing.assert_allclose(obs, z["obs"][t], atol=1e-7)
+        assert abs(r - z["reward"][t]) < 1e-7
+        if d:
+            np.testing.assert_allclose(env.reset(), z["reset_obs"][t], atol=1e-10)
+    assert (z["info"] == 1).sum() >= 5
+    env.close()

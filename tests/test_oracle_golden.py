@@ -155,3 +155,24 @@ def test_g6_pretrained_replay(policy, tol):
         assert (info == 4) == bool(z[f"{policy}_success"][i])
         assert abs(0.1 * 10 * L - z[f"{policy}_time"][i]) < 1e-9
         assert abs(ret - z[f"{policy}_reward"][i]) < max(tol, 1e-6 if L > 600 else tol), (i, ret, z[f"{policy}_reward"][i])
+
+
+def test_g8_boundary_and_robot_n5_trace():
+    """set_boundary = True + robot.N = 5 (run_experiments.py:192-211 settings): out-of-boundary branch of
+    the termination ladder (marinenav_env.py:240-243) against the reference."""
+    z = np.load(os.path.join(G, "g8_boundary_trace.npz"))
+    env = OracleEnv(int(z["seed"]))
+    env.set_flags(reset_start_and_goal=False, random_reset_state=True, set_boundary=True)
+    env.set_robot_N(5)
+    env.set_start_goal(z["start"], z["goal"])
+    env.set_world_size(8, 8, 25.0)
+    np.testing.assert_allclose(env.reset(), z["obs0"], atol=1e-10)
+    worst = 0.0
+    for t, a in enumerate(z["actions"]):
+        obs, r, d, info = env.step(int(a))
+        assert d == bool(z["done"][t]) and info == z["info"][t], t
+        assert env.get_state()[1] == z["ep_t"][t]
+        worst = max(worst, np.abs(obs - z["obs"][t]).max(), abs(r - z["reward"][t]))
+        if d:
+            np.testing.assert_allclose(env.reset(), z["reset_obs"][t], atol=1e-10)
+    assert (z["info"] == 1).sum() >= 5 and worst < 1e-8
