@@ -27,6 +27,9 @@ HBM_PEAK_GBS = 8000.0
 # IQN act, K = 32 taus: 2 * 32 * (64*208 + 208*64 + 64*64 + 64*9) FLOP per env-step ("~2.0 MFLOP")
 ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at
+# 65 536 envs, 8 cores / 10 obstacles: profiles/r01_full_loop_kernel_stats.txt.  Not measured live.
+PMC_TRAFFIC_BYTES = {"step": 30.1e6, "act": 66.5e6}
 
 
 def cpu_baseline(n_steps, world):
@@ -172,7 +175,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_BYTES["step"] if (n, args.cores, args.obstacles) == (65536, 8, 10) else None,
+                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (bytes per launch, not live)",
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "launch_ms": step_kernel_ms,
                 "launches_timed": launches,
@@ -183,7 +187,9 @@ def main():
             tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
                 "kernel": "iqn_qvals_kernel", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                "traffic": PMC_TRAFFIC_BYTES["act"] if n == 65536 else None,
+                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch, not live)",
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "launch_ms": act_ms, "launches_timed": act_launches,
             }
         else:

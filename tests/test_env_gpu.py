@@ -400,3 +400,35 @@ def test_g8_boundary_and_robot_n5_on_device(torch):
             np.testing.assert_allclose(env.reset(), z["reset_obs"][t], atol=1e-10)
     assert (z["info"] == 1).sum() >= 5
     env.close()
+
+
+def test_c_abi_error_behaviour(torch):
+    """Status codes instead of exceptions across the C-ABI: over-capacity worlds, bad parameters,
+    out-of-range env windows; mn_last_error carries the text."""
+    import ctypes as C
+    from distributional_rl_navigation_amd import _capi
+    L = _capi.lib()
+    p = _capi.default_params()
+    p.num_beams = 12
+    h = C.c_void_p()
+    assert L.mn_create(4, C.byref(p), C.byref(h)) == -1 and b"num_beams" in L.mn_last_error(None)
+    assert L.mn_create(0, C.byref(_capi.default_params()), C.byref(h)) == -1
+    env = make_env(4, "mixed")
+    with pytest.raises(ValueError):
+        env.load_worlds([dict(cores=np.zeros((9, 4)), obstacles=np.zeros((0, 3)), start=[1, 1], goal=[2, 2],
+                              init_theta=0.0, init_speed=0.0)])
+    with pytest.raises(_capi.MarineNavHipError):
+        env.set_attrs(num_cores=9)                       # beyond the device capacity of 8
+    env.params.num_cores = 8
+    with pytest.raises(_capi.MarineNavHipError):
+        env.get_state(2, 5)                              # window past n_envs
+    with pytest.raises(_capi.MarineNavHipError):
+        env.get_obs64()                                  # float64 copies exist only in f64 precision
+    with pytest.raises(_capi.MarineNavHipError):
+        env.set_schedule(dict(timesteps=[0], num_cores=[9], num_obstacles=[1], min_start_goal_dis=[30.0]))
+    # actions outside [0, 9) are clamped, never read out of bounds
+    env.set_attrs(num_cores=4, num_obs=6)
+    env.reset()
+    env.step(torch.tensor([-5, 100, 3, 8], dtype=torch.int32, device=env.device))
+    assert bool(torch.isfinite(env.obs).all())
+    env.close()
