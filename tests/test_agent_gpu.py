@@ -144,3 +144,29 @@ def test_cvar_experiment_sweep(torch):
         assert all(abs(t - 0.5 * len(a)) < 1e-9 for t, a in zip(r["time"], r["actions"]))   # dt * N = 0.5 s
         assert not any(s and o_ for s, o_ in zip(r["success"], r["out_of_area"]))
     assert np.mean(res["IQN_1.0"]["success"]) > 0.6 and np.mean(res["adaptive_IQN"]["success"]) > 0.6
+
+
+def test_reference_shaped_single_env_learn_loop(torch, tmp_path):
+    """Drop-in check: the reference-shaped IQNAgent.learn (agent.py:94-173) drives the gym-shaped facade
+    (reset / step / reset_with_eval_config / discount / robot.*) exactly as train_IQN_model.py would."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.env import make
+    sched = dict(timesteps=[0, 1000000, 2000000], num_cores=[4, 6, 8], num_obstacles=[6, 8, 10],
+                 min_start_goal_dis=[30.0, 35.0, 40.0])
+    train_env = make("marinenav_env:marinenav_env-v0", seed=0, schedule=sched)
+    eval_env = make("marinenav_env:marinenav_env-v0", seed=348)
+    with open(os.path.join(G, "eval_config_seed3.json")) as f:
+        cfg = json.load(f)
+    cfg = {k: cfg[k] for k in ("env_0", "env_11")}                      # two eval worlds keep the test short
+    agent = IQNAgent(train_env.get_state_space_dimension(), train_env.get_action_space_dimension(), device="cuda:0",
+                     seed=100, BATCH_SIZE=32, BUFFER_SIZE=5000, learning_starts=150, target_update_interval=50)
+    agent.learn(total_timesteps=260, train_env=train_env, eval_env=eval_env, eval_config=cfg, eval_freq=100,
+                eval_log_path=str(tmp_path), verbose=False)
+    assert agent.current_timestep == 261 and agent.learning_timestep == 111       # `<=` loop, agent.py:113
+    assert agent.grad_steps == 28                                                  # every 4th learning step
+    z = np.load(os.path.join(tmp_path, "greedy_evaluations.npz"), allow_pickle=True)
+    assert list(z["timesteps"]) == [150, 250] and z["rewards"].shape == (2, 2)    # first eval at learning_starts (A9)
+    assert os.path.exists(os.path.join(tmp_path, "network_params.pth"))
+    w = train_env._venv.get_worlds(0, 1)[0]
+    assert w["n_cores"] <= 4 and w["n_obs"] <= 6                                   # curriculum stage 0
+    train_env.close(); eval_env.close()
