@@ -79,7 +79,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run: RCCL, even for 1 rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
@@ -92,7 +93,7 @@ def main():
     if not args.no_learner:
         agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device=device,
                          seed=100 if args.shared_learner else 100 + rank, learning_starts=0,
-                         distributed=args.shared_learner and world > 1, act_chunk=args.act_chunk)
+                         distributed=args.shared_learner and use_dist, act_chunk=args.act_chunk)
     if agent is not None and args.torch_act:
         agent.use_fused_act = False
     if agent is not None and args.no_train_graph:
@@ -111,7 +112,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -137,7 +138,7 @@ def main():
         _capi.lib().mn_iqn_profile_end(C.c_void_p(torch.cuda.current_stream(device).cuda_stream), C.byref(ms), C.byref(nl))
         act_ms, act_launches = ms.value, nl.value
     grad_steps = (agent.grad_steps - g0) if agent else 0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,7 +204,7 @@ def main():
                 "host_cpus": os.cpu_count(),
             }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     env.close()
