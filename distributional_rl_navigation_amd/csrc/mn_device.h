@@ -60,10 +60,15 @@ struct MnBeam {
 // Rankine vortex contribution of one core at relative position (dx,dy) = core - point
 // (marinenav_env.py:433-453,461-465).  tangent*speed = (-dy,dx)/d * Gamma/(2 pi d) outside the
 // core and (-dy,dx)/d * Gamma d/(2 pi r^2) inside; signed Gamma carries the spin direction.
+// The two branches of compute_speed (:461-465) meet at d = r, and Gamma/(2 pi d^2) <= Gamma/(2 pi r^2)
+// exactly when d >= r, so the profile is min(1/(2 pi r^2), 1/(2 pi d^2)) -- one v_min instead of a
+// compare + select, and d = 0 stays finite.
 template <typename M>
 __device__ __forceinline__ void mn_core_velocity(M dx, M dy, M gs, M r2, M inv_two_pi_r2, M inv_two_pi, M &vx, M &vy) {
-    M d2 = dx * dx + dy * dy;
-    M f = d2 <= r2 ? inv_two_pi_r2 : inv_two_pi * MnMath<M>::rcp(d2);
+    (void)r2;
+    const M d2 = dx * dx + dy * dy;
+    M f = inv_two_pi * MnMath<M>::rcp(d2);
+    f = f < inv_two_pi_r2 ? f : inv_two_pi_r2;
     f *= gs;
     vx -= dy * f;
     vy += dx * f;

@@ -19,7 +19,8 @@
 //     consecutive envs (the L lanes of a group read the same address, which the coalescer merges).
 //   * Heading: ONE float64 sincos per step; the 10 sub-steps advance (cos, sin) by the constant
 //     rotation of w*dt (3 possible values, host constants) instead of 10 sincosf calls.
-//   * Observations leave as float2 stores into the row-major [env][26] tile the IQN consumes.
+//   * Observations leave as float2 stores into the row-major [env][26] tile the IQN consumes (an LDS
+//     transpose to 16-byte coalesced rows was measured: its two barriers cost more than it saves).
 #include "mn_device.h"
 
 namespace {
@@ -155,29 +156,77 @@ __global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, co
     // ---- N kinematic sub-steps (marinenav_env.py:208-212) -------------------------------------
     M velx = 0, vely = 0;
     const int nsub = (P.debug_skip & 1) ? 0 : P.N;
-    for (int s = 0; s < nsub; ++s) {
-        // current at the pre-move position: superposition over ALL cores
-        M cvx = 0, cvy = 0;
+    if constexpr (!PARITY && CPL >= 2) {
+        // Mixed precision: the core positions RELATIVE to the robot are formed once in float64, then
+        // tracked in float32 (d -= v*dt): the rounding of a relative position is relative to the
+        // DISTANCE to that core, which is what the 1/d field is sensitive to (a far core's 4e-6 m costs
+        // 1e-8 m/s; a core 0.5 m away is tracked to 3e-8 m).  The absolute pose still integrates in
+        // float64 below.  Cores are processed two at a time on float2 so the compiler can use the
+        // packed v_pk_mul / v_pk_fma forms.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int NP = CPL / 2;
+        f2 rdx[NP], rdy[NP], gsv[NP];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
-            mn_core_velocity<M>((M)(ccx[j] - x), (M)(ccy[j] - y), cgs[j], r2, inv_two_pi_r2, inv_two_pi, cvx, cvy);
-        cvx = group_sum<L>(cvx);
-        cvy = group_sum<L>(cvy);
-        // robot.py:98-107: velocity = speed*(cos,sin) + current ; position += velocity*dt
-        velx = (M)(speed * cs) + cvx;
-        vely = (M)(speed * sn) + cvy;
-        x += (double)velx * dt;
-        y += (double)vely * dt;
-        // robot.py:113-114: drag + clip
-        speed += (acc - P.k_drag * speed) * dt;
-        speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
-        // robot.py:117-123: heading + wrap to [0, 2pi); (cos, sin) advance by the constant rotation
-        theta += wdt;
-        theta = theta < 0.0 ? theta + two_pi : theta;
-        theta = theta >= two_pi ? theta - two_pi : theta;
-        const double c2 = cs * rot_c - sn * rot_s;
-        sn = sn * rot_c + cs * rot_s;
-        cs = c2;
+        for (int p_ = 0; p_ < NP; ++p_) {
+            rdx[p_] = (f2){(float)(ccx[2 * p_] - x), (float)(ccx[2 * p_ + 1] - x)};
+            rdy[p_] = (f2){(float)(ccy[2 * p_] - y), (float)(ccy[2 * p_ + 1] - y)};
+            gsv[p_] = (f2){(float)cgs[2 * p_], (float)cgs[2 * p_ + 1]};
+        }
+        const float dtf = (float)dt, i2p = (float)inv_two_pi, i2pr = (float)inv_two_pi_r2;
+        for (int s = 0; s < nsub; ++s) {
+            f2 ax = (f2){0.f, 0.f}, ay = (f2){0.f, 0.f};
+#pragma unroll
+            for (int p_ = 0; p_ < NP; ++p_) {
+                const f2 d2 = rdx[p_] * rdx[p_] + rdy[p_] * rdy[p_];
+                f2 f = (f2){__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)} * i2p;
+                f.x = f.x < i2pr ? f.x : i2pr;
+                f.y = f.y < i2pr ? f.y : i2pr;
+                f *= gsv[p_];
+                ax -= rdy[p_] * f;
+                ay += rdx[p_] * f;
+            }
+            const float cvx = group_sum<L>(ax.x + ax.y), cvy = group_sum<L>(ay.x + ay.y);
+            velx = (float)(speed * cs) + cvx;
+            vely = (float)(speed * sn) + cvy;
+            x += (double)velx * dt;
+            y += (double)vely * dt;
+            const f2 mvx = (f2){velx * dtf, velx * dtf}, mvy = (f2){vely * dtf, vely * dtf};
+#pragma unroll
+            for (int p_ = 0; p_ < NP; ++p_) { rdx[p_] -= mvx; rdy[p_] -= mvy; }
+            speed += (acc - P.k_drag * speed) * dt;
+            speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
+            theta += wdt;
+            theta = theta < 0.0 ? theta + two_pi : theta;
+            theta = theta >= two_pi ? theta - two_pi : theta;
+            const double c2 = cs * rot_c - sn * rot_s;
+            sn = sn * rot_c + cs * rot_s;
+            cs = c2;
+        }
+    } else {
+        for (int s = 0; s < nsub; ++s) {
+            // current at the pre-move position: superposition over ALL cores
+            M cvx = 0, cvy = 0;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                mn_core_velocity<M>((M)(ccx[j] - x), (M)(ccy[j] - y), cgs[j], r2, inv_two_pi_r2, inv_two_pi, cvx, cvy);
+            cvx = group_sum<L>(cvx);
+            cvy = group_sum<L>(cvy);
+            // robot.py:98-107: velocity = speed*(cos,sin) + current ; position += velocity*dt
+            velx = (M)(speed * cs) + cvx;
+            vely = (M)(speed * sn) + cvy;
+            x += (double)velx * dt;
+            y += (double)vely * dt;
+            // robot.py:113-114: drag + clip
+            speed += (acc - P.k_drag * speed) * dt;
+            speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
+            // robot.py:117-123: heading + wrap to [0, 2pi); (cos, sin) advance by the constant rotation
+            theta += wdt;
+            theta = theta < 0.0 ? theta + two_pi : theta;
+            theta = theta >= two_pi ? theta - two_pi : theta;
+            const double c2 = cs * rot_c - sn * rot_s;
+            sn = sn * rot_c + cs * rot_s;
+            cs = c2;
+        }
     }
 
     // marinenav_env.py:214 dis_after
