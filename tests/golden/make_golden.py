@@ -18,6 +18,7 @@ Outputs (all small, committed):
   eval_config_seed3.json     data file shipped by the reference (30 evaluation worlds)
   g7_iqn.npz            IQN forward / loss / grads with injected taus, adjust_cvar, linear_eps
   g8_boundary_trace.npz set_boundary = True, robot.N = 5 trace (run_experiments.py settings)
+  g9_planners.npz       APF / BA baseline actions for 2304 observations
   pretrained_IQN_seed3/ checkpoint data files shipped by the reference (weights only)
 """
 import contextlib
@@ -217,6 +218,31 @@ def g8_boundary_trace():
     out = {k: np.array(v) for k, v in rec.items()}
     out.update(actions=actions, obs0=obs0, seed=21, start=env.start, goal=env.goal)
     np.savez_compressed(os.path.join(OUT, "g8_boundary_trace.npz"), **out)
+
+
+def g9_planners():
+    """Classical baselines (APF.py:17-78, BA.py:14-155) on the 2048 observations of g3 plus synthetic
+    corner cases: expected action indices."""
+    import APF, BA
+    z = np.load(os.path.join(OUT, "g3_single_step.npz"))
+    obs = z["obs"].copy()
+    rng = np.random.RandomState(99)
+    extra = obs[rng.randint(len(obs), size=256)].copy()
+    extra[:64, :2] *= 1e-4                      # near-zero velocity branches
+    extra[64:128, 4:] = 0.0                     # no sonar returns
+    for i in range(128, 192):                   # exactly one / two returns
+        pts = extra[i, 4:].reshape(11, 2); keep = rng.choice(11, size=1 + (i % 2), replace=False)
+        m = np.zeros(11, bool); m[keep] = True
+        pts[~m] = 0.0
+        pts[m] = rng.uniform(-8, 8, size=(m.sum(), 2))
+    for i in range(192, 256):                   # vertical wall: same x for all returns
+        pts = extra[i, 4:].reshape(11, 2); pts[:, 0] = rng.uniform(1, 8); pts[:, 1] = rng.uniform(-6, 6, size=11)
+    obs = np.concatenate([obs, extra])
+    env = MarineNavEnv(seed=0)
+    apf = APF.APF_agent(env.robot.a, env.robot.w)
+    ba = BA.BA_agent(env.robot.a, env.robot.w)
+    a_apf = np.array([apf.act(o) for o in obs]); a_ba = np.array([ba.act(o) for o in obs])
+    np.savez_compressed(os.path.join(OUT, "g9_planners.npz"), obs=obs, apf=a_apf, ba=a_ba, a=env.robot.a, w=env.robot.w)
 
 
 def g3_single_step(n_worlds=64, per_world=32):
@@ -481,7 +507,7 @@ def g7_iqn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which:
         g1_reset(); g1b_eval_worlds()
     if "g2" in which:
@@ -498,6 +524,8 @@ if __name__ == "__main__":
         g7_iqn()
     if "g8" in which:
         g8_boundary_trace()
+    if "g9" in which:
+        g9_planners()
     for f in sorted(os.listdir(OUT)):
         p = os.path.join(OUT, f)
         if os.path.isfile(p):
