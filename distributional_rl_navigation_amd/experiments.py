@@ -10,8 +10,9 @@ import numpy as np
 import torch
 
 from .marinenav_env.vec_env import VecMarineNavEnv
+from .planners import apf_act_batch, ba_act_batch
 
-POLICIES = ("adaptive_IQN", "IQN_0.25", "IQN_0.5", "IQN_0.75", "IQN_1.0")   # run_experiments.py:216
+POLICIES = ("adaptive_IQN", "IQN_0.25", "IQN_0.5", "IQN_0.75", "IQN_1.0", "APF", "BA")   # run_experiments.py:216 (minus DQN)
 _CVAR = {"IQN_0.25": 0.25, "IQN_0.5": 0.5, "IQN_0.75": 0.75, "IQN_1.0": 1.0}
 
 
@@ -37,7 +38,7 @@ def generate_worlds(num, n_obs, n_cores, seed=15, device="cuda:0"):
 
 @torch.no_grad()
 def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000):
-    """run_experiments.py:213-282 for the IQN policies.  Returns {policy: dict(success, time, energy,
+    """run_experiments.py:213-282 for the IQN policies and the classical APF / BA baselines.  Returns {policy: dict(success, time, energy,
     out_of_area, reward, actions)} with one entry per world (the reference's exp_data schema minus the
     per-step quantile dumps and wall-clock timings)."""
     worlds = generate_worlds(num, n_obs, n_cores, seed, device)
@@ -48,11 +49,19 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     dev = env.device
     fixed = torch.ones(n, device=dev)
     adaptive = torch.zeros(n, dtype=torch.bool, device=dev)
+    classical = {}                                                 # policy name -> env rows driven by a planner
+    iqn_rows = torch.zeros(n, dtype=torch.bool, device=dev)
     for p, name in enumerate(policies):
+        rows = slice(p * num, (p + 1) * num)
+        if name in ("APF", "BA"):
+            classical[name] = rows
+            continue
+        iqn_rows[rows] = True
         if name == "adaptive_IQN":
-            adaptive[p * num:(p + 1) * num] = True
+            adaptive[rows] = True
         else:
-            fixed[p * num:(p + 1) * num] = _CVAR[name]
+            fixed[rows] = _CVAR[name]
+    iqn_idx = torch.nonzero(iqn_rows).view(-1)
     a_tab = torch.tensor(env.params.a[:], device=dev); w_tab = torch.tensor(env.params.w[:], device=dev)
     energy_tab = ((a_tab / a_tab.max()).abs().view(3, 1) + (w_tab / w_tab.max()).abs().view(1, 3)).reshape(-1)
     alive = torch.ones(n, dtype=torch.bool, device=dev)
@@ -62,8 +71,14 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     acts = torch.full((max_steps, n), -1, dtype=torch.int32, device=dev)
     agent.qnetwork_local.eval()
     for t in range(max_steps):
-        cv = torch.where(adaptive, agent.adjust_cvar_batch(obs), fixed)      # agent.py:249-267 per row
-        a = agent.act_batch(obs, 0.0, cv)
+        a = torch.zeros(n, dtype=torch.int32, device=dev)
+        if iqn_idx.numel():
+            o = obs[iqn_idx]
+            cv = torch.where(adaptive[iqn_idx], agent.adjust_cvar_batch(o), fixed[iqn_idx])   # agent.py:249-267 per row
+            a[iqn_idx] = agent.act_batch(o, 0.0, cv)
+        for name, rows in classical.items():                                 # APF.py:17-78 / BA.py:14-72
+            fn = apf_act_batch if name == "APF" else ba_act_batch
+            a[rows] = fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32)
         obs, reward, done, info = env.step(a)
         ret += torch.where(alive, (env.discount ** t) * reward.double(), torch.zeros_like(ret))
         length += alive.long()

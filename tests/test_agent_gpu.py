@@ -144,6 +144,7 @@ def test_cvar_experiment_sweep(torch):
         assert all(abs(t - 0.5 * len(a)) < 1e-9 for t, a in zip(r["time"], r["actions"]))   # dt * N = 0.5 s
         assert not any(s and o_ for s, o_ in zip(r["success"], r["out_of_area"]))
     assert np.mean(res["IQN_1.0"]["success"]) > 0.6 and np.mean(res["adaptive_IQN"]["success"]) > 0.6
+    assert np.mean(res["APF"]["success"]) + np.mean(res["BA"]["success"]) > 0.2      # classical baselines do reach goals
 
 
 def test_reference_shaped_single_env_learn_loop(torch, tmp_path):
