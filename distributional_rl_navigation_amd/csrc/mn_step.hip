@@ -194,14 +194,16 @@ __global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, co
 #pragma unroll
             for (int p_ = 0; p_ < NP; ++p_) { rdx[p_] -= mvx; rdy[p_] -= mvy; }
             speed += (acc - P.k_drag * speed) * dt;
-            speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
-            theta += wdt;
-            theta = theta < 0.0 ? theta + two_pi : theta;
-            theta = theta >= two_pi ? theta - two_pi : theta;
+            speed = fmin(fmax(speed, 0.0), P.max_speed);           // robot.py:114 clip
             const double c2 = cs * rot_c - sn * rot_s;
             sn = sn * rot_c + cs * rot_s;
             cs = c2;
         }
+        // heading (robot.py:117-123): N increments of w*dt, each wrapped into [0, 2pi).  The wrapped sum is
+        // formed once here (it differs from the reference's step-by-step sum by rounding only, ~1e-15 rad)
+        theta += (double)nsub * wdt;
+        while (theta < 0.0) theta += two_pi;
+        while (theta >= two_pi) theta -= two_pi;
     } else {
         for (int s = 0; s < nsub; ++s) {
             // current at the pre-move position: superposition over ALL cores
@@ -373,7 +375,11 @@ void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actio
 #define MN_LAUNCH(LL)                                                                                              \
     hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / 256)), block, 0, s, A, P, \
                        actions, obs, reward, done, info, parity)
-    switch (lanes) {   // measured on MI355X at 65 536 envs: L = 2 is fastest (21.5 us vs 23 / 27 / 33 for 1 / 4 / 8)
+    // Default (lanes == 0), measured on MI355X: up to ~128 K envs the launch is latency-bound and two lanes per env
+    // win (19.6 vs 20.5 us at 65 536); beyond that several rounds of waves hide latency by themselves and the
+    // mapping with the least total work wins (1 M envs: 121 us at L = 1 -> 44 % of the HBM roofline, 165 us at L = 2).
+    if (lanes == 0) lanes = A.n <= 131072 ? 2 : 1;
+    switch (lanes) {
         case 1: MN_LAUNCH(1); break;
         case 4: MN_LAUNCH(4); break;
         case 8: MN_LAUNCH(8); break;
