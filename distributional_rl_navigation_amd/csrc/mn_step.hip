@@ -5,7 +5,7 @@
 //   get_observation (:273-326) with Robot.sonar_reflection (robot.py:125-198),
 //   reward + termination ladder (:220-257), counters (:259-260).
 //
-// Mapping (v2): L lanes per environment (L = 2 by default), 64/L environments per wavefront.
+// Mapping (v2): L lanes per environment (default: 2 up to 128 K envs, 1 beyond), 64/L environments per wavefront.
 //   * 65 536 envs are only 1024 wavefronts at one lane per env -- ONE wave per SIMD, nothing to hide
 //     the ~80 k-cycle dependent chain of a step behind (measured: SQ_WAIT_ANY 53 %, 11 cycles per
 //     instruction, profiles/r01_step_only_kernel_stats_v1.txt).  With L lanes per env the independent

@@ -85,7 +85,7 @@ typedef struct mn_params {
     int32_t N;                       /* robot.py:29 sub-steps per action */
     int32_t num_beams;               /* robot.py:9, must equal MN_NUM_BEAMS */
     int32_t precision;               /* MN_PRECISION_* */
-    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = default (2), or 1, 2, 4, 8 */
+    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = auto (2 up to 128 K envs, else 1), or 1, 2, 4, 8 */
 } mn_params;
 
 typedef struct mn_handle mn_handle;
