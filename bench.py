@@ -120,12 +120,13 @@ def main():
         obs = one_step(obs)
     g0 = agent.grad_steps if agent else 0
     fence()
-    env.profile_begin(args.steps)
+    n_prof = min(args.steps, 2000)     # HIP-event pairs recorded around the first n_prof launches of the timed region
+    env.profile_begin(n_prof)
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
     fused = agent is not None and agent.use_fused_act
     if fused:
-        _capi.lib().mn_iqn_profile_begin(args.steps)
+        _capi.lib().mn_iqn_profile_begin(n_prof)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         obs = one_step(obs)
