@@ -144,6 +144,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # learner alone (outside the timed region): back-to-back IQN grad steps (sample + train), batch 256, 8 quantiles.
+    # Eager = what the loop uses (there the ~130 launches hide behind the act kernel); back to back the eager step is
+    # CPU-launch-bound, which is where the captured hipGraph (IQNAgent.use_train_graph) pays.
+    learner_only = {}
+    if agent is not None and len(agent.memory) > agent.BATCH_SIZE:
+        for mode in ("eager", "hipgraph"):
+            if mode == "hipgraph" and agent.distributed:
+                continue
+            agent.use_train_graph = (mode == "hipgraph")
+            for _ in range(5):
+                agent.train(agent.memory.sample())
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(50):
+                agent.train(agent.memory.sample())
+            torch.cuda.synchronize(device)
+            learner_only[mode] = 50 / (time.perf_counter() - t1)
+
     if rank == 0:
         env_steps = n * world * args.steps
         bytes_per = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
@@ -171,6 +189,7 @@ def main():
                 "cvar": args.cvar,
             },
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
+            "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             "roofline_env_step": {
                 "kernel": "mn_step_kernel<float,false,L>",
                 "bound": "hbm",

@@ -234,6 +234,8 @@ class IQNAgent:
                 for st in state["state"].values():
                     st["step"] = torch.as_tensor(st["step"], dtype=torch.float32, device=dev)
                 self.optimizer.load_state_dict(state)
+                for g_ in self.optimizer.param_groups:
+                    g_["capturable"] = True
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             snap = [p.detach().clone() for p in self.qnetwork_local.parameters()]
@@ -255,6 +257,8 @@ class IQNAgent:
             self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR, capturable=True)
             if state["state"]:
                 self.optimizer.load_state_dict(state)
+                for g_ in self.optimizer.param_groups:
+                    g_["capturable"] = True
             self._graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(self._graph):
