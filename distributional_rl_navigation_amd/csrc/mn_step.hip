@@ -23,6 +23,10 @@
 //     transpose to 16-byte coalesced rows was measured: its two barriers cost more than it saves).
 #include "mn_device.h"
 
+#ifndef MN_STEP_BLOCK
+#define MN_STEP_BLOCK 64    // threads per workgroup (npad is a multiple of 256, so 64 / 128 / 256 all tile it); measured: same at 65 536 envs, 64 is 4 % faster at 1 M
+#endif
+
 namespace {
 
 // sum over the L lanes of a group; every lane ends with the bit-identical total
@@ -53,7 +57,7 @@ __device__ __forceinline__ double group_sum(double v) {
 }
 
 template <typename M, bool PARITY, int L>
-__global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
                                                       float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                       uint8_t *__restrict__ done_out, uint8_t *__restrict__ info_out,
                                                       int parity) {
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, co
     // hit nor trigger the reference's `break`; the scan over the list is therefore equivalent to the
     // scan over all obstacles (robot.py:147-198).  Typically 0-3 of the 10 obstacles survive, and the
     // beam loop runs to the longest list in the wavefront instead of 10.
-    __shared__ double lst_x[MN_MAX_OBS][256], lst_y[MN_MAX_OBS][256];
-    __shared__ M lst_r[MN_MAX_OBS][256];     // radius: float32 is exact for the compact tables, float64 in parity mode
+    __shared__ double lst_x[MN_MAX_OBS][MN_STEP_BLOCK], lst_y[MN_MAX_OBS][MN_STEP_BLOCK];
+    __shared__ M lst_r[MN_MAX_OBS][MN_STEP_BLOCK];     // radius: float32 is exact for the compact tables, float64 in parity mode
     const int tl = threadIdx.x;
     int nrel = 0;
     double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
@@ -371,9 +375,9 @@ __global__ __launch_bounds__(256, 2) void mn_step_kernel(MnArrays A, MnDev P, co
 template <typename M, bool PARITY>
 void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actions, float *obs, float *reward,
               uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
-    const dim3 block(256);
+    const dim3 block(MN_STEP_BLOCK);
 #define MN_LAUNCH(LL)                                                                                              \
-    hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / 256)), block, 0, s, A, P, \
+    hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / MN_STEP_BLOCK)), block, 0, s, A, P, \
                        actions, obs, reward, done, info, parity)
     // Default (lanes == 0), measured on MI355X: up to ~128 K envs the launch is latency-bound and two lanes per env
     // win (19.6 vs 20.5 us at 65 536); beyond that several rounds of waves hide latency by themselves and the
