@@ -432,3 +432,27 @@ def test_c_abi_error_behaviour(torch):
     env.step(torch.tensor([-5, 100, 3, 8], dtype=torch.int32, device=env.device))
     assert bool(torch.isfinite(env.obs).all())
     env.close()
+
+
+def test_vector_curriculum_timestep_scale(torch):
+    """Curriculum in vector mode: the stage is looked up with total_timesteps[i] * timestep_scale
+    (marinenav_env.py:89-98 with aggregate experience), so with scale = n_envs the stages of
+    train_IQN_model.py:86-90 switch after the same number of ENV steps as in the reference."""
+    n = 8
+    sched = dict(timesteps=[0, 80, 160], num_cores=[4, 6, 8], num_obstacles=[6, 8, 10], min_start_goal_dis=[30.0, 35.0, 40.0])
+    env = make_env(n, "mixed", seed=3, schedule=sched, timestep_scale=n)
+    env.reset()
+    assert all(w["n_cores"] <= 4 and w["n_obs"] <= 6 for w in env.get_worlds())
+    a = torch.zeros(n, dtype=torch.int32, device=env.device)
+    for t in range(1, 25):
+        env.step(a)
+        env.reset(mask=torch.ones(n, dtype=torch.uint8, device=env.device))      # force a reset every step
+        w = env.get_worlds()
+        agg = t * n                                                              # aggregate env steps so far
+        stage = 0 if agg < 80 else (1 if agg < 160 else 2)
+        want_c, want_o = sched["num_cores"][stage], sched["num_obstacles"][stage]
+        assert all(x["n_cores"] <= want_c and x["n_obs"] <= want_o for x in w), (t, stage)
+        assert any(x["n_cores"] == want_c for x in w) and any(x["n_obs"] >= want_o - 2 for x in w), (t, stage)
+        prev = sched["num_cores"][stage - 1] if stage else 0
+        assert max(x["n_cores"] for x in w) > prev
+    env.close()
