@@ -25,7 +25,7 @@
 // k order of a dot product is free, MFMA step (t, r) of the NEXT layer is defined to consume input
 // features {16t + 4g + r : g = 0..3} -- which is exactly register r of C tile t in lane group g.  So a
 // layer's accumulator registers ARE the next layer's B operands: no LDS round trip, no shuffles.
-// The weights are permuted once per workgroup into that order while being copied to LDS
+// The weights are permuted into that order once per call (iqn_pack_kernel) and copied to LDS per workgroup
 // (155 KiB of the 160 KiB incl. the encoders: one 512-thread workgroup per CU, 2 waves per SIMD so one wave's bias /
 // ReLU / cos VALU work runs under the other's MFMAs); each ds_read_b128 feeds 4 k-steps x 2 tau
 // tiles = 8 MFMAs.  Layers 1 and 2 are fused over the 13 feature tiles of the 208-wide activation,
@@ -90,44 +90,55 @@ __device__ __forceinline__ float enc_weight(const IqnWeights &w, int f, int i) {
     return (i >= 4 && i < OBS) ? w.se_w[(f - 32) * 22 + (i - 4)] : 0.f;
 }
 
-__global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
-                                                           IqnWeights w, float *__restrict__ qvals,
-                                                           const float *__restrict__ explore_u, float eps,
-                                                           int32_t *__restrict__ actions, int n) {
-    const float *__restrict__ W1 = w.W1, *__restrict__ b1 = w.b1, *__restrict__ W2 = w.W2, *__restrict__ b2 = w.b2;
-    const float *__restrict__ W3 = w.W3, *__restrict__ b3 = w.b3, *__restrict__ W4 = w.W4, *__restrict__ b4 = w.b4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-
-    // ---- weights -> LDS, permuted into MFMA A-fragment order (nn.Linear stores [out][in]) ----------
-    for (int i = tid; i < OFF_B1; i += blockDim.x) {
+// Value of element i of the LDS weight image (floats [0, OFF_FB)): weights permuted into MFMA A-fragment
+// order (nn.Linear stores [out][in]), biases, block-diagonal encoder.
+__device__ __forceinline__ float pack_element(const IqnWeights &w, int i) {
+    if (i < OFF_B1) {
         const int j = i & 3, l = (i >> 2) & 63, g = l >> 4, row = l & 15;
-        float v;
         if (i < OFF_W2) {            // W1p[t][m4][l][j] = W1[16t + row][4*(4*m4 + j) + g]
             const int q = i >> 8, m4 = q & 3, t = q >> 2;
-            v = W1[(16 * t + row) * N_COS + 4 * (4 * m4 + j) + g];
+            return w.W1[(16 * t + row) * N_COS + 4 * (4 * m4 + j) + g];
         } else if (i < OFF_W3) {     // W2p[mt][t][l][r] = W2[16mt + row][16t + 4g + r]
             const int q = (i - OFF_W2) >> 8, t = q % T1, mt = q / T1;
-            v = W2[(16 * mt + row) * F + 16 * t + 4 * g + j];
+            return w.W2[(16 * mt + row) * F + 16 * t + 4 * g + j];
         } else if (i < OFF_W4) {     // W3p[mt][t2][l][r] = W3[16mt + row][16t2 + 4g + r]
             const int q = (i - OFF_W3) >> 8, t2 = q & 3, mt = q >> 2;
-            v = W3[(16 * mt + row) * H + 16 * t2 + 4 * g + j];
-        } else {                     // W4p[t2][l][r] = W4[row][16t2 + 4g + r] (rows >= 9 are zero)
-            const int t2 = (i - OFF_W4) >> 8;
-            v = row < A_OUT ? W4[row * H + 16 * t2 + 4 * g + j] : 0.f;
-        }
-        lds[i] = v;
+            return w.W3[(16 * mt + row) * H + 16 * t2 + 4 * g + j];
+        }                            // W4p[t2][l][r] = W4[row][16t2 + 4g + r] (rows >= 9 are zero)
+        const int t2 = (i - OFF_W4) >> 8;
+        return row < A_OUT ? w.W4[row * H + 16 * t2 + 4 * g + j] : 0.f;
     }
-    for (int i = tid; i < F; i += blockDim.x) lds[OFF_B1 + i] = b1[i];
-    if (tid < H) { lds[OFF_B2 + tid] = b2[tid]; lds[OFF_B3 + tid] = b3[tid]; }
-    if (tid < 16) lds[OFF_B4 + tid] = tid < A_OUT ? b4[tid] : 0.f;
-    // encoder: WEp[i4][f][c] = Wenc[f][4*i4 + c] (block-diagonal 208 x 26, zero elsewhere / padding)
-    for (int i = tid; i < OBS4 * F * 4; i += blockDim.x) {
-        const int c = i & 3, f = (i >> 2) % F, i4 = (i >> 2) / F;
+    if (i < OFF_B2) return w.b1[i - OFF_B1];
+    if (i < OFF_B3) return w.b2[i - OFF_B2];
+    if (i < OFF_B4) return w.b3[i - OFF_B3];
+    if (i < OFF_WE) return (i - OFF_B4) < A_OUT ? w.b4[i - OFF_B4] : 0.f;
+    if (i < OFF_BE) {                // WEp[i4][f][c] = Wenc[f][4*i4 + c] (block-diagonal 208 x 26, zero elsewhere / padding)
+        const int k = i - OFF_WE, c = k & 3, f = (k >> 2) % F, i4 = (k >> 2) / F;
         const int inp = 4 * i4 + c;
-        lds[OFF_WE + i] = inp < OBS ? enc_weight(w, f, inp) : 0.f;
+        return inp < OBS ? enc_weight(w, f, inp) : 0.f;
     }
-    for (int i = tid; i < F; i += blockDim.x) lds[OFF_BE + i] = i < 16 ? w.ve_b[i] : (i < 32 ? w.ge_b[i - 16] : w.se_b[i - 32]);
+    const int f = i - OFF_BE;
+    return f < 16 ? w.ve_b[f] : (f < 32 ? w.ge_b[f - 16] : w.se_b[f - 32]);
+}
+
+// Builds the 149 KiB LDS image once per call in global memory, so that each of the 256 workgroups of the
+// act kernel fills its LDS with a straight 16-byte coalesced copy instead of a 38 K-element gather.
+__global__ __launch_bounds__(256) void iqn_pack_kernel(IqnWeights w, float *__restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < OFF_FB) packed[i] = pack_element(w, i);
+}
+
+__global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
+                                                           const float *__restrict__ packed, float *__restrict__ qvals,
+                                                           const float *__restrict__ explore_u, float eps,
+                                                           int32_t *__restrict__ actions, int n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(packed);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+        for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
 
     const int lane = tid & 63, g = lane >> 4, col = lane & 15;
@@ -343,7 +354,8 @@ extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const flo
     if (!obs_dev || !taus_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
-    static int n_cu_of[64] = {0};   // per device: CU count, and "dynamic LDS attribute set" marker
+    static int n_cu_of[64] = {0};       // per device: CU count (0 = not initialised)
+    static float *packed_of[64] = {nullptr};   // per device: LDS weight image built by iqn_pack_kernel
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
     if (n_cu_of[dev] == 0) {
@@ -352,17 +364,20 @@ extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const flo
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
             return MN_ERR_HIP;
+        if (hipMalloc(reinterpret_cast<void **>(&packed_of[dev]), OFF_FB * sizeof(float)) != hipSuccess) return MN_ERR_ALLOC;
         n_cu_of[dev] = prop.multiProcessorCount;
     }
     const int n_cu = n_cu_of[dev];
+    float *packed = packed_of[dev];
     IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
                     weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
     if (blocks > n_cu) blocks = n_cu;
     const bool prof = g_prof_n < g_prof_max;
     if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], (hipStream_t)stream);
+    hipLaunchKernelGGL(iqn_pack_kernel, dim3((OFF_FB + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, packed);
     hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, obs_dev,
-                       taus_dev, w, qvals_dev, explore_u_dev, eps, actions_dev, n);
+                       taus_dev, packed, qvals_dev, explore_u_dev, eps, actions_dev, n);
     if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], (hipStream_t)stream); ++g_prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
