@@ -46,7 +46,7 @@ class IQNAgent:
 
         self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
         self.qnetwork_target = ObsEncoder(state_size, action_size, seed, device)   # identical init (App. A A1)
-        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR)
+        self.optimizer = self._make_adam()
         self.memory = ReplayBuffer(BUFFER_SIZE, BATCH_SIZE, device, seed, GAMMA, n_step, state_size)
         random.seed(seed)                            # replay_buffer.py:21 seeds python `random` (eps-greedy)
         self.gen = torch.Generator(device=self.device)
@@ -65,13 +65,19 @@ class IQNAgent:
         self.eval_times = dict(greedy=[], adaptive=[])
         self.eval_energies = dict(greedy=[], adaptive=[])
 
+    def _make_adam(self):
+        """Adam(lr=1e-4) as agent.py:66; on the GPU the fused single-kernel implementation (same update rule)."""
+        fused = torch.device(self.device).type == "cuda" and os.environ.get("MN_FUSED_ADAM", "1") == "1"
+        return optim.Adam(self.qnetwork_local.parameters(), lr=self.LR, fused=fused) if fused else \
+            optim.Adam(self.qnetwork_local.parameters(), lr=self.LR)
+
     # ---- checkpoints ---------------------------------------------------------------------------
     def load_model(self, path, device="cpu"):
         """agent.py:86-92."""
         self.qnetwork_local = ObsEncoder.load(path, device)
         self.qnetwork_target = ObsEncoder.load(path, device)
-        self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR)
         self.device = torch.device(device)
+        self.optimizer = self._make_adam()
 
     # ---- schedules -----------------------------------------------------------------------------
     def linear_eps(self, total_timesteps):
