@@ -305,6 +305,7 @@ extern "C" int mn_load_worlds(mn_handle *h, int32_t first, int32_t count, const 
                               const double *init_speed, float *obs_dev, void *stream) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     if (!n_cores || !cores_xy || !clockwise || !gamma || !n_obs || !obs_xy || !obs_r || !start || !goal || !init_theta || !init_speed)
         return MN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -356,6 +357,7 @@ extern "C" int mn_get_worlds(mn_handle *h, int32_t first, int32_t count, int32_t
                              double *init_theta, double *init_speed) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     MN_HIP(h, hipDeviceSynchronize());
     const int C = MN_MAX_CORES, O = MN_MAX_OBS;
     std::vector<double> cx, cy, cg, ox, oy, orr, sx(count), sy(count), gx(count), gy(count);
@@ -395,6 +397,7 @@ extern "C" int mn_get_worlds(mn_handle *h, int32_t first, int32_t count, int32_t
 extern "C" int mn_get_state(mn_handle *h, int32_t first, int32_t count, double *state, int32_t *ep_t, int64_t *tot_t) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     MN_HIP(h, hipDeviceSynchronize());
     if (state) {
         std::vector<double> v(count);
@@ -413,6 +416,7 @@ extern "C" int mn_set_state(mn_handle *h, int32_t first, int32_t count, const do
                             const int64_t *tot_t) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     MN_HIP(h, hipDeviceSynchronize());
     if (state) {
         std::vector<double> v(count);
@@ -430,6 +434,7 @@ extern "C" int mn_set_state(mn_handle *h, int32_t first, int32_t count, const do
 extern "C" int mn_get_obs64(mn_handle *h, int32_t first, int32_t count, double *out) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     if (!out) return MN_ERR_INVALID;
     if (!h->A.obs64) return fail(h, MN_ERR_INVALID, "float64 observations are kept only with MN_PRECISION_F64");
     MN_HIP(h, hipDeviceSynchronize());
@@ -440,6 +445,7 @@ extern "C" int mn_get_obs64(mn_handle *h, int32_t first, int32_t count, double *
 extern "C" int mn_get_reward64(mn_handle *h, int32_t first, int32_t count, double *out) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     if (!out) return MN_ERR_INVALID;
     if (!h->A.rew64) return fail(h, MN_ERR_INVALID, "float64 rewards are kept only with MN_PRECISION_F64");
     MN_HIP(h, hipDeviceSynchronize());
@@ -450,6 +456,7 @@ extern "C" int mn_get_reward64(mn_handle *h, int32_t first, int32_t count, doubl
 extern "C" int mn_peek_next_double(mn_handle *h, int32_t first, int32_t count, double *out) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;
+    if (count == 0) return MN_OK;
     if (!out) return MN_ERR_INVALID;
     MN_HIP(h, hipDeviceSynchronize());
     mn_launch_peek(h->A, first, count, h->peek_scratch, nullptr);
