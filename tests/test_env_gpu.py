@@ -456,3 +456,17 @@ def test_vector_curriculum_timestep_scale(torch):
         prev = sched["num_cores"][stage - 1] if stage else 0
         assert max(x["n_cores"] for x in w) > prev
     env.close()
+
+
+def test_c_abi_from_plain_c(torch, tmp_path):
+    """The boundary is a C ABI: examples/c_abi_demo.c (gcc, no Python, no torch) creates, resets and steps
+    4096 envs through libmarinenav_hip.so and checks the counters."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "distributional_rl_navigation_amd")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call(["gcc", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_abi_demo.c"),
+                           "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-L" + pkg, "-lmarinenav_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.check_output([exe, "4096", "120"], text=True)
+    assert "total_timesteps 120" in out and "M env steps/s" in out, out
