@@ -204,11 +204,14 @@ class IQNAgent:
             Q_targets = rewards.unsqueeze(-1) + (self.GAMMA ** self.n_step * Q_targets_next * (1. - dones.unsqueeze(-1)))
         Q_expected, taus = self.qnetwork_local(states, self.N, taus=taus_local)
         Q_expected = Q_expected.gather(2, actions.unsqueeze(-1).expand(B, self.N, 1))
-        td_error = Q_targets - Q_expected                                                   # (B, N, N)
-        huber_l = calculate_huber_loss(td_error, 1.0)
-        quantil_l = abs(taus - (td_error.detach() < 0).float()) * huber_l / 1.0
-        loss = quantil_l.sum(dim=1).mean(dim=1)
-        return loss.mean()
+        # td_error[b, i, j] = Q_targets[b, 0, j] - Q_expected[b, i, 0]   (B, N, N); Huber with kappa = 1
+        # (agent.py:401-407) as ONE fused op with its own backward instead of abs / le / pow / where chains
+        qt, qe = Q_targets.expand(B, self.N, self.N), Q_expected.expand(B, self.N, self.N)
+        huber_l = torch.nn.functional.huber_loss(qe, qt, reduction="none", delta=1.0)
+        with torch.no_grad():
+            weight = (taus - (qt < qe).to(taus.dtype)).abs()      # |tau - 1[td < 0]|, agent.py:293
+        # sum over the local-quantile axis, mean over the target-sample axis, mean over the batch (agent.py:294-295)
+        return (weight * huber_l).sum() / (B * self.N)
 
     def train(self, experiences, taus_target=None, taus_local=None):
         """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor).

@@ -49,7 +49,7 @@ class ObsEncoder(nn.Module):
         taus = taus.to(dev).unsqueeze(-1)
         if torch.is_tensor(cvar):
             taus = taus * cvar.to(dev).view(-1, 1, 1)
-        else:
+        elif cvar != 1.0:                      # x * 1.0 == x: skip the kernel
             taus = taus * cvar
         cos = torch.cos(taus * self.pis)
         return cos, taus
