@@ -29,7 +29,7 @@ ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at
 # 65 536 envs, 8 cores / 10 obstacles: profiles/r01_full_loop_kernel_stats.txt.  Not measured live.
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "act": 12.5e6}   # act: raw FETCH_SIZE (narrow loads, correction uncalibrated)
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "act": 24.8e6}   # 2 * FETCH_SIZE + WRITE_SIZE, calibrated: profiles/r01_pmc_calibration.txt
 
 
 def cpu_baseline(n_steps, world):
