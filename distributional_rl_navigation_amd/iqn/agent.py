@@ -40,6 +40,7 @@ class IQNAgent:
         self.initial_eps, self.final_eps = initial_eps, final_eps
         self.N = 8                                   # train-time quantile samples (agent.py:286,290)
         self.act_chunk = act_chunk
+        self.grad_steps_per_update = 1               # vectorised loop only: grad steps per training event
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
@@ -414,7 +415,8 @@ class IQNAgent:
         loss = None
         if self.current_timestep >= self.learning_starts:
             if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
-                loss = self.train(self.memory.sample())
+                for _ in range(self.grad_steps_per_update):      # 1 = the reference's cadence (agent.py:129-133)
+                    loss = self.train(self.memory.sample())
             if self.learning_timestep % self.target_update_interval == 0:
                 self.soft_update(self.qnetwork_local, self.qnetwork_target)
             self.learning_timestep += 1

@@ -54,7 +54,8 @@ def create_eval_configs(device, seed=348):
     return cfg
 
 
-def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True):
+def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
+              update_every=4, grad_steps=1):
     """train_IQN_model.py:74-121 on the vector env."""
     import torch
     from .iqn.agent import IQNAgent
@@ -81,7 +82,9 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     eval_env = VecMarineNavEnv(len(eval_config), device=device) if writer else None
 
     agent = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
-                     seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1)
+                     seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
+                     UPDATE_EVERY=update_every)
+    agent.grad_steps_per_update = grad_steps
     vec_steps = int(np.ceil((params["total_timesteps"] + 1) / total))
     eval_every = max(1, int(round(params["eval_freq"] / total)))
     agent.learn_vec(total_vector_steps=vec_steps, train_env=train_env, eval_env=eval_env, eval_config=eval_config,
@@ -104,6 +107,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--replay", type=int, default=100_000)
     ap.add_argument("--shared-learner", action="store_true")
+    ap.add_argument("--update-every", type=int, default=4, help="vector steps between training events (UPDATE_EVERY)")
+    ap.add_argument("--grad-steps", type=int, default=1, help="grad steps per training event")
     args = ap.parse_args(argv)
     params = json.load(args.config_file)
     import torch
@@ -117,7 +122,8 @@ def main(argv=None):
     stamp = datetime.now().strftime("%Y-%m-%d-%H-%M-%S")
     for p in trial_params(params):
         p["training_time"] = stamp
-        run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay)
+        run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay,
+                  update_every=args.update_every, grad_steps=args.grad_steps)
     if world > 1:
         dist.destroy_process_group()
 
