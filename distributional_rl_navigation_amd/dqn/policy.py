@@ -1,0 +1,94 @@
+"""Inference-side counterpart of the reference's DQN baseline (run_experiments.py:74-98, 367-376).
+
+The reference's DQN agent is its modified stable-baselines3 `ObsEncoderPolicy`: the features extractor is the
+whole 26 -> (16 | 16 | 176) -> 64 -> 64 -> 9 observation network WITHOUT activations on the three encoders
+(thirdparty/stable_baselines3/common/torch_layers.py:96-135), followed by sb3's default 9 -> 64 -> 64 -> 9 Q head
+(dqn/policies.py:48-58, torch_layers.py:137-174).  Only the greedy policy is needed on the batched path (the
+experiment sweep and evaluation); DQN training stays with sb3.
+
+Module / parameter names mirror sb3's (`q_net.features_extractor.*`, `q_net.q_net.{0,2,4}.*`) so that the
+`policy.pth` inside an sb3 checkpoint zip loads unchanged.
+"""
+import io
+import zipfile
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class _Extractor(nn.Module):
+    def __init__(self, state_size=26, action_size=9):
+        super().__init__()
+        assert state_size == 26, "observation dimension needs to be 26 (velocity, goal, measurements)"
+        self.velocity_encoder = nn.Linear(2, 16)
+        self.goal_encoder = nn.Linear(2, 16)
+        self.sensor_encoder = nn.Linear(22, 176)
+        self.hidden_layer = nn.Linear(208, 64)
+        self.hidden_layer_2 = nn.Linear(64, 64)
+        self.output_layer = nn.Linear(64, action_size)
+
+    def forward(self, x):
+        f = torch.cat((self.velocity_encoder(x[:, :2]), self.goal_encoder(x[:, 2:4]), self.sensor_encoder(x[:, 4:])), 1)
+        return self.output_layer(torch.relu(self.hidden_layer_2(torch.relu(self.hidden_layer(f)))))
+
+
+class _QNet(nn.Module):
+    def __init__(self, state_size, action_size, net_arch):
+        super().__init__()
+        self.features_extractor = _Extractor(state_size, action_size)
+        layers, d = [], action_size
+        for h in net_arch:
+            layers += [nn.Linear(d, h), nn.ReLU()]
+            d = h
+        layers.append(nn.Linear(d, action_size))
+        self.q_net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.q_net(self.features_extractor(x))
+
+
+class DQNPolicy(nn.Module):
+    """Greedy DQN policy over device-resident observation batches."""
+
+    def __init__(self, state_size=26, action_size=9, net_arch=(64, 64), device="cuda:0"):
+        super().__init__()
+        self.state_size, self.action_size = state_size, action_size
+        self.q_net = _QNet(state_size, action_size, list(net_arch))
+        self.device = torch.device(device)
+        self.to(self.device)
+        self.eval()
+
+    @classmethod
+    def load(cls, path, device="cuda:0"):
+        """`path`: an sb3 checkpoint .zip (its policy.pth is read), a bare policy.pth, or an .npz of the q_net.*
+        tensors (tests/golden/pretrained_DQN_seed3/q_net.npz)."""
+        if path.endswith(".npz"):
+            sd = {k: torch.from_numpy(v) for k, v in np.load(path).items()}
+        elif zipfile.is_zipfile(path) and "policy.pth" in zipfile.ZipFile(path).namelist():
+            with zipfile.ZipFile(path) as z:
+                sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu")
+        else:
+            sd = torch.load(path, map_location="cpu")
+        sd = {k: v for k, v in sd.items() if k.startswith("q_net.")}      # q_net_target.* is training state
+        pol = cls(device=device)
+        pol.load_state_dict(sd, strict=True)
+        return pol
+
+    @torch.no_grad()
+    def q_values(self, obs):
+        return self.q_net(obs.to(self.device, torch.float32).view(-1, self.state_size))
+
+    @torch.no_grad()
+    def act_batch(self, obs):
+        """QNetwork._predict (dqn/policies.py:69-73): argmax_a Q(obs, a), one int32 per row."""
+        return self.q_values(obs).argmax(dim=1).to(torch.int32)
+
+    def predict(self, observation, deterministic=True):
+        """sb3 surface used by run_experiments.py:86: `action, _ = agent.predict(obs, deterministic=True)`."""
+        if not deterministic:
+            raise NotImplementedError("only the greedy policy is provided on the batched path")
+        obs = torch.as_tensor(np.asarray(observation), dtype=torch.float32)
+        single = obs.dim() == 1
+        a = self.act_batch(obs.view(-1, self.state_size)).cpu().numpy().astype(np.int64)
+        return (a[0] if single else a), None

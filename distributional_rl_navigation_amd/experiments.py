@@ -13,6 +13,7 @@ from .marinenav_env.vec_env import VecMarineNavEnv
 from .planners import apf_act_batch, ba_act_batch
 
 POLICIES = ("adaptive_IQN", "IQN_0.25", "IQN_0.5", "IQN_0.75", "IQN_1.0", "APF", "BA")   # run_experiments.py:216 (minus DQN)
+ALL_POLICIES = POLICIES[:5] + ("DQN",) + POLICIES[5:]                                        # run_experiments.py:216, needs `dqn=`
 _CVAR = {"IQN_0.25": 0.25, "IQN_0.5": 0.5, "IQN_0.75": 0.75, "IQN_1.0": 1.0}
 
 
@@ -37,8 +38,9 @@ def generate_worlds(num, n_obs, n_cores, seed=15, device="cuda:0"):
 
 
 @torch.no_grad()
-def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000):
-    """run_experiments.py:213-282 for the IQN policies and the classical APF / BA baselines.  Returns {policy: dict(success, time, energy,
+def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000, dqn=None):
+    """run_experiments.py:213-282 for the IQN policies, the classical APF / BA baselines and (when `dqn`, a
+    `dqn.DQNPolicy`, is given and "DQN" is in `policies`) the greedy DQN baseline.  Returns {policy: dict(success, time, energy,
     out_of_area, reward, actions)} with one entry per world (the reference's exp_data schema minus the
     per-step quantile dumps and wall-clock timings)."""
     worlds = generate_worlds(num, n_obs, n_cores, seed, device)
@@ -53,7 +55,9 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     iqn_rows = torch.zeros(n, dtype=torch.bool, device=dev)
     for p, name in enumerate(policies):
         rows = slice(p * num, (p + 1) * num)
-        if name in ("APF", "BA"):
+        if name in ("APF", "BA", "DQN"):
+            if name == "DQN" and dqn is None:
+                raise ValueError("policy 'DQN' needs run_experiment(..., dqn=DQNPolicy.load(...))")
             classical[name] = rows
             continue
         iqn_rows[rows] = True
@@ -69,7 +73,8 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     length = torch.zeros(n, dtype=torch.int64, device=dev)
     last_info = torch.zeros(n, dtype=torch.uint8, device=dev)
     acts = torch.full((max_steps, n), -1, dtype=torch.int32, device=dev)
-    agent.qnetwork_local.eval()
+    if agent is not None:
+        agent.qnetwork_local.eval()
     for t in range(max_steps):
         a = torch.zeros(n, dtype=torch.int32, device=dev)
         if iqn_idx.numel():
@@ -77,6 +82,9 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
             cv = torch.where(adaptive[iqn_idx], agent.adjust_cvar_batch(o), fixed[iqn_idx])   # agent.py:249-267 per row
             a[iqn_idx] = agent.act_batch(o, 0.0, cv)
         for name, rows in classical.items():                                 # APF.py:17-78 / BA.py:14-72
+            if name == "DQN":                                                # run_experiments.py:86 (greedy predict)
+                a[rows] = dqn.act_batch(obs[rows])
+                continue
             fn = apf_act_batch if name == "APF" else ba_act_batch
             a[rows] = fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32)
         obs, reward, done, info = env.step(a)
@@ -88,7 +96,8 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
         alive = alive & ~done.bool()
         if not bool(alive.any()):
             break
-    agent.qnetwork_local.train()
+    if agent is not None:
+        agent.qnetwork_local.train()
     length_h = length.cpu().numpy(); info_h = last_info.cpu().numpy(); acts_h = acts.cpu().numpy()
     ret_h = ret.cpu().numpy(); energy_h = energy.cpu().numpy()
     dtN = env.params.dt * env.params.N

@@ -1,0 +1,87 @@
+"""DQN baseline on the GPU: greedy policy over the HIP simulator against the checkpoint's recorded evaluation,
+and the full 8-policy experiment sweep (run_experiments.py:213-218)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TF32_GAP = 0.05     # see tests/test_dqn_cpu.py / make_golden_dqn.py
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+def test_dqn_q_values_on_device(torch):
+    from distributional_rl_navigation_amd.dqn import DQNPolicy
+    g = np.load(os.path.join(G, "g10_dqn.npz"))
+    pol = DQNPolicy.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"), device="cuda:0")
+    q = pol.q_values(torch.from_numpy(g["obs"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(q, g["q"], rtol=0, atol=1e-3)       # = 1e-5 |Q|max: rocBLAS f32 reduction order vs the CPU's through 6 layers
+    a = pol.act_batch(torch.from_numpy(g["obs"]).cuda()).cpu().numpy()
+    top2 = np.sort(g["q"], axis=1)
+    clear = (top2[:, -1] - top2[:, -2]) > 1e-3
+    assert np.array_equal(a[clear], g["action"][clear]) and a.dtype == np.int32
+
+
+def test_dqn_closed_loop_on_hip_env(torch):
+    """30 evaluation worlds side by side in the f64 HIP env, greedy DQN actions: per episode, the action sequence
+    equals the recorded one up to the first step whose recorded action is within TF32_GAP of the max Q; fully
+    reproduced episodes also reproduce the recorded discounted return and outcome."""
+    from distributional_rl_navigation_amd.dqn import DQNPolicy
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    g = np.load(os.path.join(G, "g10_dqn.npz"))
+    with open(os.path.join(G, "eval_config_seed3.json")) as f:
+        cfg = json.load(f)
+    pol = DQNPolicy.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"), device="cuda:0")
+    env = VecMarineNavEnv(30, device="cuda:0", precision="f64")
+    obs = env.load_worlds([VecMarineNavEnv.world_from_eval_config(c) for c in cfg.values()]).clone()
+    rec, lens = g["eval_actions"].astype(np.int64), g["eval_len"]
+    following = np.ones(30, dtype=bool)            # still on the recorded trajectory
+    finished = np.zeros(30, dtype=bool)
+    ret = np.zeros(30); outcome = np.zeros(30, dtype=np.int64)
+    for t in range(int(lens.max())):
+        q = pol.q_values(obs).cpu().numpy()
+        a = q.argmax(1)
+        for i in np.nonzero(following & ~finished)[0]:
+            if a[i] != rec[i, t]:
+                assert q[i].max() - q[i, rec[i, t]] < TF32_GAP, (i, t, q[i])
+                following[i] = False
+        act = np.where(following & ~finished, rec[:, min(t, rec.shape[1] - 1)], 0).clip(0, 8)
+        obs, reward, done, info = env.step(torch.from_numpy(act.astype(np.int32)).cuda())
+        r64 = env.get_reward64(); d = done.cpu().numpy().astype(bool); inf = info.cpu().numpy()
+        live = following & ~finished
+        ret[live] += 0.99 ** t * r64[live]
+        for i in np.nonzero(live & d)[0]:
+            assert t + 1 == lens[i], (i, t, lens[i])
+            finished[i] = True; outcome[i] = inf[i]
+        assert not np.any(live & ~d & (t + 1 >= lens)), "episode outlived its recording"
+    full = following & finished
+    assert full.sum() >= 15, full.sum()
+    assert np.abs(ret[full] - g["eval_rewards"][full]).max() < 1e-4      # sb3 keeps rewards in float32
+    assert np.array_equal(outcome[full] == 4, g["eval_successes"][full].astype(bool))
+    env.close()
+
+
+def test_full_policy_sweep_with_dqn(torch):
+    from distributional_rl_navigation_amd.dqn import DQNPolicy
+    from distributional_rl_navigation_amd.experiments import ALL_POLICIES, run_experiment
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    agent = IQNAgent(26, 9, device="cuda:0", seed=2, BUFFER_SIZE=1024)
+    agent.load_model(os.path.join(G, "pretrained_IQN_seed3"), "cuda:0")
+    pol = DQNPolicy.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"), device="cuda:0")
+    assert ALL_POLICIES == ("adaptive_IQN", "IQN_0.25", "IQN_0.5", "IQN_0.75", "IQN_1.0", "DQN", "APF", "BA")
+    res, _ = run_experiment(agent, n_obs=6, n_cores=4, num=24, seed=15, policies=ALL_POLICIES, dqn=pol)
+    assert list(res.keys()) == list(ALL_POLICIES)
+    assert sum(res["DQN"]["success"]) >= 12, res["DQN"]["success"]
+    with pytest.raises(ValueError):
+        run_experiment(agent, n_obs=6, n_cores=4, num=2, policies=("DQN",))
+    only, _ = run_experiment(None, n_obs=6, n_cores=4, num=24, seed=15, policies=("DQN",), dqn=pol)
+    assert only["DQN"]["actions"] == res["DQN"]["actions"]          # rows are independent of the other policies
