@@ -21,12 +21,13 @@ struct mn_handle {
     uint32_t *mask_count = nullptr;
     int32_t *list_scratch = nullptr;
     double *peek_scratch = nullptr;
+    int device = -1;      // HIP device the handle's memory lives on (the caller's current device at mn_create)
     // profiling
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;
 
 #define MN_HIP(h, call)                                                                                     \
     do {                                                                                                    \
@@ -43,6 +44,21 @@ static int fail(mn_handle *h, int code, const char *msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
 }
+
+// Every entry point that touches device memory runs on the device the handle was created on: a caller that has
+// switched devices since (one process driving several GPUs) gets an error instead of a fault on a foreign pointer.
+static int on_device(mn_handle *h) {
+    if (!h) return MN_ERR_INVALID;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(h, MN_ERR_HIP, "hipGetDevice failed");
+    if (cur != h->device) {
+        char b[160];
+        snprintf(b, sizeof(b), "handle lives on HIP device %d but the calling thread's current device is %d", h->device, cur);
+        return fail(h, MN_ERR_INVALID, b);
+    }
+    return MN_OK;
+}
+#define MN_ON_DEVICE(h) do { int _rc = on_device(h); if (_rc) return _rc; } while (0)
 
 extern "C" int mn_default_params(mn_params *p) {
     if (!p) return MN_ERR_INVALID;
@@ -125,8 +141,12 @@ static int dev_alloc(mn_handle *h, T **out, size_t count, bool zero = true) {
 
 extern "C" int mn_destroy(mn_handle *h) {
     if (!h) return MN_ERR_INVALID;
+    int cur = -1;
+    const bool moved = hipGetDevice(&cur) == hipSuccess && h->device >= 0 && cur != h->device;
+    if (moved) (void)hipSetDevice(h->device);   // free on the owning device, then restore the caller's
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void *p : h->allocs) (void)hipFree(p);
+    if (moved) (void)hipSetDevice(cur);
     delete h;
     return MN_OK;
 }
@@ -136,6 +156,7 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, MN_ERR_NO_DEVICE, "no HIP device visible");
     mn_handle *h = new mn_handle();
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(nullptr, MN_ERR_HIP, "hipGetDevice failed"); }
     memset(&h->A, 0, sizeof(h->A));
     memset(&h->P, 0, sizeof(h->P));
     h->P.timestep_scale = 1.0;
@@ -204,6 +225,7 @@ extern "C" int mn_get_params(const mn_handle *h, mn_params *p) {
 
 extern "C" int mn_seed(mn_handle *h, const uint32_t *seeds_host, void *stream) {
     if (!h || !seeds_host) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     MN_HIP(h, hipMemcpyAsync(h->seeds_dev, seeds_host, (size_t)h->A.n * 4, hipMemcpyHostToDevice, s));
     mn_launch_seed(h->A, h->seeds_dev, s);
@@ -227,11 +249,12 @@ extern "C" int mn_set_schedule(mn_handle *h, int32_t n, const int64_t *ts, const
 
 static int range_ok(mn_handle *h, int first, int count) {
     if (!h || first < 0 || count < 0 || first + count > h->A.n) return fail(h, MN_ERR_INVALID, "env range out of bounds");
-    return MN_OK;
+    return on_device(h);
 }
 
 extern "C" int mn_set_start_goal(mn_handle *h, int32_t env_idx, const double start[2], const double goal[2]) {
     if (!h || !start || !goal || env_idx >= h->A.n) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     const int first = env_idx < 0 ? 0 : env_idx, count = env_idx < 0 ? h->A.n : 1;
     std::vector<double> v(count);
     double *dst[4] = {h->A.start_x, h->A.start_y, h->A.goal_x, h->A.goal_y};
@@ -245,6 +268,7 @@ extern "C" int mn_set_start_goal(mn_handle *h, int32_t env_idx, const double sta
 
 extern "C" int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     if (!mask_dev) {
         mn_launch_reset(h->A, h->P, h->params.precision, nullptr, (uint32_t)h->A.n, nullptr, 0, obs_dev, s);
@@ -260,6 +284,7 @@ extern "C" int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, v
 extern "C" int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                        uint8_t *info_dev, void *stream) {
     if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int parity = h->step_parity;
     const bool prof = h->prof_n < h->prof_max;
@@ -274,6 +299,7 @@ extern "C" int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev,
 
 extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream);
     MN_HIP(h, hipGetLastError());
     return MN_OK;
@@ -281,6 +307,7 @@ extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
 
 extern "C" int mn_last_done_count(mn_handle *h, void *stream, int32_t *out) {
     if (!h || !out) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
     MN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
     uint32_t v = 0;
     MN_HIP(h, hipMemcpy(&v, h->A.queue_count + h->last_parity, 4, hipMemcpyDeviceToHost));

@@ -21,6 +21,8 @@
  *    synchronous with respect to that handle's previous work on the NULL stream only, so call
  *    them after synchronising your stream.
  *  - One handle per GPU per process; a handle is not re-entrant across threads.
+ *    A handle is bound to the HIP device that was current at mn_create(); entry points called while another
+ *    device is current return MN_ERR_INVALID (mn_destroy switches to the owning device itself).
  */
 #ifndef MARINENAV_HIP_H
 #define MARINENAV_HIP_H
