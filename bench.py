@@ -8,10 +8,14 @@ the configuration its metric is quoted on.  With --gpus N every rank runs the sa
 on its own env shard (weak scaling; no data-path collective; --shared-learner adds the RCCL gradient
 all-reduce of configs[4]).
 
-Prints ONE JSON line on rank 0.  `roofline` is for the HIP step kernel (HBM-bound by north-star):
-achieved = 406 B/env-step (SURVEY 8d, 8 cores + 10 obstacles) x envs per launch / mean launch
-duration, measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` is
-the scalar C oracle (oracle/, a port) timed on this box's host cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the DOMINANT kernel of the timed loop, the fused IQN act
+kernel (MFMA-bound: 2.003 MFLOP/env-step x envs per launch / mean launch duration vs the dense f32 MFMA peak);
+`roofline_env_step` is the HIP step kernel (HBM-bound by north-star: 406 B/env-step (SURVEY 8d, 8 cores + 10
+obstacles) x envs per launch / mean launch duration).  With --no-learner the step kernel is the dominant kernel
+and `roofline` is its entry.  Both durations are measured with HIP events on the launch stream inside the timed
+region.  `cpu_baseline` is the scalar C oracle (oracle/, a port) timed on one host core of this box on a bounded
+sample; `cpu_baseline_all_cores` is the same oracle with one env per host thread (up to 64 threads; on the
+GPU box 256 threads gave 5.2 M env steps/s, i.e. the container's CPU share is ~9 cores' worth).
 """
 import argparse
 import json
@@ -46,6 +50,28 @@ def cpu_baseline(n_steps, world):
     return n_steps / dt, dt
 
 
+def cpu_baseline_all_cores(n_steps_each, world, threads):
+    """The same oracle, one env per host thread (ctypes releases the GIL for the whole C rollout)."""
+    import threading
+    import numpy as np
+    from oracle.oracle import OracleEnv
+    envs = []
+    for i in range(threads):
+        e = OracleEnv(i)
+        e.set_world_size(*world)
+        e.reset()
+        envs.append(e)
+    acts = [np.random.RandomState(1000 + i).randint(9, size=n_steps_each).astype(np.int32) for i in range(threads)]
+    ths = [threading.Thread(target=envs[i].rollout, args=(acts[i],)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return threads * n_steps_each / dt, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,7 +85,9 @@ def main():
     ap.add_argument("--shared-learner", action="store_true", help="one IQN, RCCL grad all-reduce (configs[4])")
     ap.add_argument("--cvar", type=float, default=1.0)
     ap.add_argument("--no-learner", action="store_true", help="random policy, step kernel only (configs[1])")
-    ap.add_argument("--cpu-steps", type=int, default=4_000_000, help="oracle sample for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=8_000_000, help="oracle sample for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="threads for the multi-thread oracle baseline (-1 = host CPUs this process may use, capped at 64; 0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
     ap.add_argument("--no-train-graph", action="store_true", help="eager grad step instead of the captured hipGraph")
     ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
@@ -224,6 +252,14 @@ def main():
                           f"{args.cores} cores / {args.obstacles} obstacles, random actions, resets included, {dt:.1f} s",
                 "host_cpus": os.cpu_count(),
             }
+            nth = min(64, len(os.sched_getaffinity(0))) if args.cpu_threads < 0 else args.cpu_threads
+            if nth > 1:
+                each = max(100_000, args.cpu_steps // 32)
+                v, dt = cpu_baseline_all_cores(each, (args.cores, args.obstacles, min_dis), nth)
+                out["cpu_baseline_all_cores"] = {
+                    "value": v, "unit": "env steps/s", "cores": nth, "kind": "port",
+                    "sample": f"{nth} host threads x {each} steps, one oracle env each, {dt:.1f} s",
+                }
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
