@@ -143,3 +143,33 @@ def test_fused_act_epilogue_argmax_and_exploration(torch):
     a2 = fused_act(net, obs, 0.3, 1.0, taus=taus, generator=g3)
     frac_greedy = float((a2 == a).float().mean())                          # 0.7 + 0.3 * P(random == greedy)
     assert 0.70 < frac_greedy < 0.76
+
+
+def test_g7_reference_vectors_on_device(torch):
+    """Golden vectors produced by the reference's own thirdparty/IQN code (tests/golden/make_golden.py, G7), on
+    the GPU: (1) the fused MFMA act kernel reproduces the reference's Q-values for injected taus (seeded init and
+    the shipped checkpoint), (2) one `IQNAgent.train` step on the device reproduces the reference's loss, clipped
+    gradients and post-Adam parameters.  Tolerances = the CPU test's (tests/test_iqn_cpu.py), f32 throughout."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_qvals
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    Z = np.load(os.path.join(G, "g7_iqn.npz"))
+    dev = "cuda:0"
+    obs = torch.from_numpy(Z["obs"]).to(dev); taus = torch.from_numpy(Z["taus32"]).to(dev)
+    net = ObsEncoder(26, 9, seed=7, device=dev)
+    for cvar in (1.0, 0.5):
+        q = fused_qvals(net, obs, cvar, taus=taus).cpu().numpy()
+        np.testing.assert_allclose(q, Z[f"qvals_cvar{cvar}"], rtol=1e-5, atol=1e-5)
+    pre = ObsEncoder.load(os.path.join(G, "pretrained_IQN_seed3"), dev)
+    q = fused_qvals(pre, obs, 1.0, taus=taus).cpu().numpy()
+    np.testing.assert_allclose(q, Z["pretrained_quantiles"].mean(axis=1), rtol=1e-5, atol=1e-4)
+
+    agent = IQNAgent(26, 9, BATCH_SIZE=16, seed=7, BUFFER_SIZE=64, device=dev)
+    agent.qnetwork_target.load_state_dict({k[4:]: torch.from_numpy(Z[k]).to(dev) for k in Z.files if k.startswith("tgt_")})
+    exp = tuple(torch.from_numpy(Z[k]).to(dev) for k in ("obs", "actions", "rewards", "next_obs", "dones"))
+    loss = agent.train(exp, taus_target=torch.from_numpy(Z["taus8_target"]).to(dev),
+                       taus_local=torch.from_numpy(Z["taus8_local"]).to(dev))
+    np.testing.assert_allclose(float(loss), float(Z["train_loss"]), rtol=1e-5)
+    for k, p in agent.qnetwork_local.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), Z["grad_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), Z["after_" + k], rtol=0, atol=2e-6, err_msg=k)
