@@ -90,6 +90,7 @@ def main():
                     help="threads for the multi-thread oracle baseline (-1 = host CPUs this process may use, capped at 64; 0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
     ap.add_argument("--no-train-graph", action="store_true", help="eager grad step instead of the captured hipGraph")
+    ap.add_argument("--torch-train", action="store_true", help="grad step through PyTorch autograd + Adam instead of the fused HIP step")
     ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
     ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env in the step kernel (0 = library default)")
@@ -126,6 +127,8 @@ def main():
         agent.use_fused_act = False
     if agent is not None and args.no_train_graph:
         agent.use_train_graph = False
+    if agent is not None:
+        agent.use_fused_train = not args.torch_train
     total_timesteps = 3_000_000 * n * world      # eps stays on the reference's initial 10 % ramp
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)
@@ -177,18 +180,22 @@ def main():
     # CPU-launch-bound, which is where the captured hipGraph (IQNAgent.use_train_graph) pays.
     learner_only = {}
     if agent is not None and len(agent.memory) > agent.BATCH_SIZE:
-        for mode in ("eager", "hipgraph"):
+        was_fused = agent.use_fused_train
+        for mode in ("fused_hip", "eager", "hipgraph"):       # the torch modes last: they advance torch's own Adam state
             if mode == "hipgraph" and agent.distributed:
                 continue
+            agent.use_fused_train = (mode == "fused_hip")
             agent.use_train_graph = (mode == "hipgraph")
+            reps = 200 if mode == "fused_hip" else 50
             for _ in range(5):
-                agent.train(agent.memory.sample())
+                agent.train_from_memory()
             torch.cuda.synchronize(device)
             t1 = time.perf_counter()
-            for _ in range(50):
-                agent.train(agent.memory.sample())
+            for _ in range(reps):
+                agent.train_from_memory()
             torch.cuda.synchronize(device)
-            learner_only[mode] = 50 / (time.perf_counter() - t1)
+            learner_only[mode] = reps / (time.perf_counter() - t1)
+        agent.use_fused_train = was_fused
 
     if rank == 0:
         env_steps = n * world * args.steps

@@ -44,6 +44,10 @@ class IQNAgent:
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
+        # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
+        # Adam) instead of ~150 PyTorch autograd / Adam kernels; False = the PyTorch path (always used on the CPU)
+        self.use_fused_train = torch.device(device).type == "cuda"
+        self._fused = None
 
         self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
         self.qnetwork_target = ObsEncoder(state_size, action_size, seed, device)   # identical init (App. A A1)
@@ -214,10 +218,33 @@ class IQNAgent:
         # sum over the local-quantile axis, mean over the target-sample axis, mean over the batch (agent.py:294-295)
         return (weight * huber_l).sum() / (B * self.N)
 
+    def _fused_trainer(self):
+        from .fused_train import FusedTrainer
+        if self._fused is None or not self._fused.owns(self):      # load_model() replaces the networks
+            self._fused = FusedTrainer(self)
+        return self._fused
+
+    def train_from_memory(self):
+        """`self.train(self.memory.sample())` (agent.py:131-133).  With `use_fused_train` the HIP step gathers its batch
+        straight from the device ring (no sampled copies)."""
+        if self.use_fused_train and self.device.type == "cuda":
+            m = self.memory
+            ft = self._fused_trainer()
+            idx, taus = ft.sample(m.size, self.BATCH_SIZE)                   # replay_buffer.py:47 + model.py:149
+            loss = ft.step((m.states, m.actions, m.rewards, m.next_states, m.dones), idx, taus[0], taus[1])
+            self.grad_steps += 1
+            return loss
+        return self.train(self.memory.sample())
+
     def train(self, experiences, taus_target=None, taus_local=None):
         """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor).
         On the GPU (single learner, taus not injected) the whole step -- forward, backward, clip, Adam,
         ~100 tiny kernels -- is replayed from one captured hipGraph."""
+        if self.use_fused_train and experiences[0].is_cuda:
+            exp = tuple(t.contiguous() for t in experiences)
+            loss = self._fused_trainer().step(exp, None, taus_target, taus_local)
+            self.grad_steps += 1
+            return loss
         if (self.use_train_graph and experiences[0].is_cuda and not self.distributed
                 and taus_target is None and taus_local is None and experiences[0].shape[0] == self.BATCH_SIZE):
             return self._train_graphed(experiences)
@@ -305,7 +332,7 @@ class IQNAgent:
             state = next_state
             if self.current_timestep >= self.learning_starts:
                 if self.learning_timestep % self.UPDATE_EVERY == 0 and len(self.memory) > self.BATCH_SIZE:
-                    self.train(self.memory.sample())
+                    self.train_from_memory()
                 if self.learning_timestep % self.target_update_interval == 0:
                     self.soft_update(self.qnetwork_local, self.qnetwork_target)
                 if self.learning_timestep % eval_freq == 0 and eval_env is not None:
@@ -416,7 +443,7 @@ class IQNAgent:
         if self.current_timestep >= self.learning_starts:
             if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
                 for _ in range(self.grad_steps_per_update):      # 1 = the reference's cadence (agent.py:129-133)
-                    loss = self.train(self.memory.sample())
+                    loss = self.train_from_memory()
             if self.learning_timestep % self.target_update_interval == 0:
                 self.soft_update(self.qnetwork_local, self.qnetwork_target)
             self.learning_timestep += 1

@@ -1,0 +1,129 @@
+"""Host side of the fused HIP gradient step (csrc/iqn_train.hip): IQNAgent.train (thirdparty/IQN/agent.py:269-304)
+as three kernels behind `mn_iqn_train_grad` / `mn_iqn_train_adam`.
+
+The kernels work on FLAT parameter vectors (35 785 floats, `named_parameters()` order).  `FusedTrainer` allocates one
+flat buffer per network and re-points every `nn.Parameter` at a view of it, so the PyTorch modules (checkpoints,
+`soft_update`, the fused act kernel, eager evaluation) and the HIP step always see the same memory.  The Adam
+moments / step counter live in flat device buffers owned by the trainer (the reference never checkpoints the
+optimizer, agent.py:86-92).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _capi
+
+P_TOTAL = 35785
+_ORDER = ("velocity_encoder", "goal_encoder", "sensor_encoder", "cos_embedding", "hidden_layer", "hidden_layer_2",
+          "output_layer")
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def flatten_network(net):
+    """One contiguous float32 buffer holding all parameters of `net`; the parameters become views of it."""
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [f"{m}.{s}" for m in _ORDER for s in ("weight", "bias")], names
+    params = list(net.parameters())
+    dev = params[0].device
+    assert dev.type == "cuda", "the fused gradient step is a HIP kernel: parameters must live on the GPU"
+    flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+    assert flat.numel() == P_TOTAL
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+    return flat
+
+
+class FusedTrainer:
+    def __init__(self, agent):
+        self.agent = agent
+        self.device = agent.device
+        self.local = flatten_network(agent.qnetwork_local)
+        self.target = flatten_network(agent.qnetwork_target)
+        z = lambda: torch.zeros(P_TOTAL, dtype=torch.float32, device=self.device)
+        self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._ws, self._ws_batch = None, 0
+        # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
+        self.rng_state = torch.tensor([int(agent.memory.gen.initial_seed()) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
+                                      device=self.device)
+        self._idx, self._taus = {}, {}
+        self._arange = {}
+        off = 0
+        for p in agent.qnetwork_local.parameters():      # p.grad = the (clipped) gradient of the last step, as torch
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self._nets = (agent.qnetwork_local, agent.qnetwork_target)
+
+    def owns(self, agent):
+        return self._nets == (agent.qnetwork_local, agent.qnetwork_target)
+
+    def _workspace(self, batch):
+        if self._ws_batch != batch:
+            n = _capi.lib().mn_iqn_train_workspace_floats(batch)
+            if n < 0:
+                raise ValueError("fused IQN gradient step: the batch size must be even")
+            self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def sample(self, ring_size, batch):
+        """ReplayBuffer.sample's index draw + the step's tau draws in ONE kernel -> (idx [B] i64, taus [2, B, 8])."""
+        if batch not in self._idx:
+            self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
+            self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)
+        idx, taus = self._idx[batch], self._taus[batch]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_iqn_sample(int(ring_size), batch, _p(self.rng_state), _p(idx), _p(taus), taus.numel(), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_sample failed ({rc}): need batch <= 1024 and ring_size >= batch")
+        return idx, taus
+
+    def step(self, ring, idx=None, taus_target=None, taus_local=None):
+        """One optimizer step.  `ring` = (states [c,26] f32, actions [c,1] i64, rewards [c,1] f32, next_states [c,26] f32,
+        dones [c,1] f32), all contiguous on the device; `idx` [B] i64 selects the batch rows (None: all rows in
+        order).  Returns the loss (device scalar tensor; a view of a buffer that the next step overwrites)."""
+        ag = self.agent
+        states, actions, rewards, next_states, dones = ring
+        for t in ring:
+            assert t.is_cuda and t.is_contiguous()
+        assert states.dtype == torch.float32 and actions.dtype == torch.int64 and dones.dtype == torch.float32
+        if idx is None:
+            B = states.shape[0]
+            idx = self._arange.get(B)
+            if idx is None:
+                idx = self._arange[B] = torch.arange(B, dtype=torch.int64, device=self.device)
+        B = idx.shape[0]
+        if taus_target is None or taus_local is None:
+            taus = torch.rand(2, B, ag.N, device=self.device)          # model.py:149, target forward first
+            tt = taus[0] if taus_target is None else taus_target
+            tl = taus[1] if taus_local is None else taus_local
+        else:
+            tt, tl = taus_target, taus_local
+        tt = tt.to(self.device, torch.float32).contiguous().view(B, ag.N)
+        tl = tl.to(self.device, torch.float32).contiguous().view(B, ag.N)
+        L = _capi.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = L.mn_iqn_train_grad(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), _p(idx), _p(tt), _p(tl),
+                                 _p(self.local), _p(self.target), _p(self._workspace(B)), _p(self.grad), _p(self.loss),
+                                 B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_train_grad failed ({rc})")
+        if ag.distributed:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)            # one 143 KB bucket over RCCL/xGMI
+            self.grad.div_(dist.get_world_size())
+        rc = L.mn_iqn_train_adam(_p(self.local), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev),
+                                 _p(self._workspace(B)), B, C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5),
+                                 stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_train_adam failed ({rc})")
+        return self.loss[0]

@@ -210,6 +210,39 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
                      const uint8_t *done_dev, float *ring_states, float *ring_next_states, int64_t *ring_actions,
                      float *ring_rewards, float *ring_dones, int64_t n, int64_t ptr, int64_t capacity, void *stream);
 
+/* ---- IQN gradient step ------------------------------------------------------------------------
+ * One optimizer step of IQNAgent.train (thirdparty/IQN/agent.py:269-304) on `batch` transitions gathered from the
+ * replay ring (layout above) at rows idx_dev[batch] (i64): target-network forward on next_states, local-network
+ * forward on states, quantile-Huber TD loss (kappa = 1, 8 x 8 tau pairs; agent.py:279-295, 401-407), backward.
+ * All pointers are device pointers, float32 unless noted, 16-byte aligned.
+ *   taus_*_dev [batch][8]     : the uniform(0,1) tau draws of model.py:149 for the target / local forward
+ *   params_local/_target      : FLAT parameter vectors, 35 785 floats in ObsEncoder.named_parameters() order
+ *                               (model.py:120-136): velocity_encoder.{weight[16][2],bias[16]}, goal_encoder.{[16][2],[16]},
+ *                               sensor_encoder.{[176][22],[176]}, cos_embedding.{[208][64],[208]},
+ *                               hidden_layer.{[64][208],[64]}, hidden_layer_2.{[64][64],[64]}, output_layer.{[9][64],[9]}
+ *   workspace                 : mn_iqn_train_workspace_floats(batch) floats of scratch (per-workgroup partial gradients,
+ *                               norm partials); pass the same buffer and batch to both calls
+ *   grad_out [35 785]         : d loss / d params_local (un-clipped); loss_out [1]: the loss
+ * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics); the caller may average
+ * grad_out over ranks (RCCL all-reduce) before mn_iqn_train_adam, which applies clip_grad_norm_(max_norm)
+ * (agent.py:299) and one torch.optim.Adam update (agent.py:300; exp_avg / exp_avg_sq [35 785], step_dev: i32 step
+ * counter on the device, incremented by the call; grad is overwritten with the clipped gradient).
+ * batch must be even, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
+int64_t mn_iqn_train_workspace_floats(int32_t batch);
+/* ReplayBuffer.sample (replay_buffer.py:42-47): `batch` DISTINCT uniform row indices in [0, ring_size) -> idx_out
+ * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).
+ * rng_state_dev: u64[2] = {seed, call counter} on the device; the counter is advanced by the call.
+ * batch <= 1024, ring_size >= batch. */
+int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out,
+                  int32_t n_taus_total, void *stream);
+int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                      const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev,
+                      const float *taus_target_dev, const float *taus_local_dev, const float *params_local,
+                      const float *params_target, float *workspace, float *grad_out, float *loss_out, int32_t batch,
+                      int32_t num_taus, float gamma, void *stream);
+int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
+                      int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
+
 /* Benchmark hook: HIP events on the launch stream around the next mn_iqn_act launches. */
 int mn_iqn_profile_begin(int32_t max_launches);
 int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches);

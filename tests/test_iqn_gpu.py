@@ -102,6 +102,7 @@ def test_graphed_train_step_equals_eager(torch):
     res = []
     for graphed in (False, True):
         ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device="cuda:0", seed=9)
+        ag.use_fused_train = False       # this test is about the two PyTorch paths
         ag.use_train_graph = graphed
         torch.manual_seed(1234)
         if graphed:                      # building the graph draws taus during warm-up: build first,
@@ -145,11 +146,13 @@ def test_fused_act_epilogue_argmax_and_exploration(torch):
     assert 0.70 < frac_greedy < 0.76
 
 
-def test_g7_reference_vectors_on_device(torch):
+@pytest.mark.parametrize("fused_train", [True, False])
+def test_g7_reference_vectors_on_device(torch, fused_train):
     """Golden vectors produced by the reference's own thirdparty/IQN code (tests/golden/make_golden.py, G7), on
     the GPU: (1) the fused MFMA act kernel reproduces the reference's Q-values for injected taus (seeded init and
     the shipped checkpoint), (2) one `IQNAgent.train` step on the device reproduces the reference's loss, clipped
-    gradients and post-Adam parameters.  Tolerances = the CPU test's (tests/test_iqn_cpu.py), f32 throughout."""
+    gradients and post-Adam parameters -- through the fused HIP step (csrc/iqn_train.hip) and through PyTorch autograd.
+    Tolerances = the CPU test's (tests/test_iqn_cpu.py), f32 throughout."""
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     from distributional_rl_navigation_amd.iqn.fused_act import fused_qvals
     from distributional_rl_navigation_amd.iqn.model import ObsEncoder
@@ -165,6 +168,8 @@ def test_g7_reference_vectors_on_device(torch):
     np.testing.assert_allclose(q, Z["pretrained_quantiles"].mean(axis=1), rtol=1e-5, atol=1e-4)
 
     agent = IQNAgent(26, 9, BATCH_SIZE=16, seed=7, BUFFER_SIZE=64, device=dev)
+    assert agent.use_fused_train          # the HIP step is the default on the GPU
+    agent.use_fused_train = fused_train
     agent.qnetwork_target.load_state_dict({k[4:]: torch.from_numpy(Z[k]).to(dev) for k in Z.files if k.startswith("tgt_")})
     exp = tuple(torch.from_numpy(Z[k]).to(dev) for k in ("obs", "actions", "rewards", "next_obs", "dones"))
     loss = agent.train(exp, taus_target=torch.from_numpy(Z["taus8_target"]).to(dev),
@@ -173,3 +178,84 @@ def test_g7_reference_vectors_on_device(torch):
     for k, p in agent.qnetwork_local.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), Z["grad_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
         np.testing.assert_allclose(p.detach().cpu().numpy(), Z["after_" + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def _random_batch(torch, B, g):
+    dev = "cuda:0"
+    obs = torch.randn(B, 26, device=dev, generator=g) * 5
+    obs[:, 4:] = torch.where(torch.rand(B, 22, device=dev, generator=g) < 0.5, torch.zeros((), device=dev), obs[:, 4:])
+    return (obs, torch.randint(0, 9, (B, 1), device=dev, generator=g), torch.randn(B, 1, device=dev, generator=g) * 3,
+            obs + 0.3 * torch.randn(B, 26, device=dev, generator=g), (torch.rand(B, 1, device=dev, generator=g) < 0.1).float())
+
+
+@pytest.mark.parametrize("B", [2, 32, 256])
+def test_fused_train_step_equals_pytorch(torch, B):
+    """One optimizer step, same batch / taus / weights, fused HIP kernels vs PyTorch autograd + clip_grad_norm_ + Adam:
+    loss to 1e-6 relative, clipped gradient to 1e-6 of its largest entry, post-Adam parameters to 2e-6 (float32
+    rounding only: both are exact-f32 products with different summation orders).  A second step from the updated
+    weights checks the Adam moments / bias correction (step counter) carried on the device."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    g = torch.Generator(device=dev); g.manual_seed(100 + B)
+    a = IQNAgent(26, 9, BATCH_SIZE=B, seed=3, BUFFER_SIZE=1024, device=dev); a.use_fused_train = False
+    b = IQNAgent(26, 9, BATCH_SIZE=B, seed=3, BUFFER_SIZE=1024, device=dev); b.use_fused_train = True
+    with torch.no_grad():                       # a target network that differs from the local one
+        for p in a.qnetwork_target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=g))
+    b.qnetwork_target.load_state_dict(a.qnetwork_target.state_dict())
+    for step in range(2):
+        exp = _random_batch(torch, B, g)
+        tt, tl = torch.rand(B, 8, device=dev, generator=g), torch.rand(B, 8, device=dev, generator=g)
+        b.qnetwork_local.load_state_dict(a.qnetwork_local.state_dict())     # same starting weights for this step
+        la, lb = float(a.train(exp, tt, tl)), float(b.train(exp, tt, tl))
+        assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)
+        ga = torch.cat([p.grad.reshape(-1) for p in a.qnetwork_local.parameters()])
+        gb = torch.cat([p.grad.reshape(-1) for p in b.qnetwork_local.parameters()])
+        assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max()), step
+        assert abs(float(torch.linalg.vector_norm(gb)) - min(0.5, float(torch.linalg.vector_norm(gb)))) < 1e-6   # clipped
+        if step == 0:      # identical Adam state only on the first step (b's weights are re-synchronised, its moments are its own)
+            pa = torch.cat([p.detach().reshape(-1) for p in a.qnetwork_local.parameters()])
+            pb = torch.cat([p.detach().reshape(-1) for p in b.qnetwork_local.parameters()])
+            assert float((pa - pb).abs().max()) <= 2e-6      # first Adam step = lr * g / (|g| + eps): gradients of ~eps size amplify rounding
+    assert int(b._fused.step_dev.item()) == 2 and b.grad_steps == 2
+
+
+def test_fused_train_from_replay_ring(torch):
+    """train_from_memory(): the HIP step gathers its batch from the ring by the sampled indices -- same result as
+    handing it the gathered tensors; indices are distinct, in range, differ between calls; the parameters stay
+    views of the flat buffers (checkpoint / soft_update / act kernel see the update)."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    B = 64
+    a = IQNAgent(26, 9, BATCH_SIZE=B, seed=4, BUFFER_SIZE=500, device=dev)
+    b = IQNAgent(26, 9, BATCH_SIZE=B, seed=4, BUFFER_SIZE=500, device=dev)
+    for ag in (a, b):
+        g.manual_seed(5)
+        for _ in range(3):
+            s_, ac, r, ns, d = _random_batch(torch, 150, g)
+            ag.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
+    assert len(a.memory) == 450
+    before = [p.detach().clone() for p in a.qnetwork_local.parameters()]
+    la = a.train_from_memory()
+    ft = a._fused
+    idx, taus = ft._idx[B].clone(), ft._taus[B].clone()
+    assert idx.unique().numel() == B and int(idx.min()) >= 0 and int(idx.max()) < 450
+    m = b.memory
+    lb = b.train((m.states[idx], m.actions[idx], m.rewards[idx], m.next_states[idx], m.dones[idx]), taus[0], taus[1])
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la))
+    for p, q, p0 in zip(a.qnetwork_local.parameters(), b.qnetwork_local.parameters(), before):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 and float((p.detach() - p0).abs().max()) > 0
+        assert p.data_ptr() >= ft.local.data_ptr() and p.data_ptr() < ft.local.data_ptr() + ft.local.numel() * 4
+    a.train_from_memory()
+    assert not torch.equal(ft._idx[B], idx) and not torch.equal(ft._taus[B], taus)
+    a.soft_update(a.qnetwork_local, a.qnetwork_target)
+    assert torch.equal(ft.target, ft.local)
+    # sampling without replacement is uniform: inclusion frequency of every row -> B / size
+    cnt = torch.zeros(450, device=dev)
+    for _ in range(1500):
+        i2, t2 = ft.sample(450, B)
+        cnt[i2] += 1
+    freq = (cnt / 1500).cpu().numpy()
+    assert abs(freq.mean() - B / 450) < 1e-6 and freq.std() < 1.5 * np.sqrt(B / 450 * (1 - B / 450) / 1500)
+    assert 0.49 < float(t2.mean()) < 0.51 and float(t2.min()) >= 0.0 and float(t2.max()) < 1.0
