@@ -3,7 +3,8 @@
 
 One "step" = one vector step of the hot path on one GPU: IQN act (K = 32 quantile samples) for
 65 536 envs -> HIP step kernel -> replay append -> HIP reset of finished envs -> (every 4th vector
-step) one IQN grad step (batch 256, 8 quantiles, replay 100 000).  This is BASELINE.json configs[2],
+step) one IQN grad step (batch 256, 8 quantiles, replay 100 000; fused HIP step csrc/iqn_train.hip, or PyTorch
+autograd + Adam with --torch-train).  This is BASELINE.json configs[2],
 the configuration its metric is quoted on.  With --gpus N every rank runs the same per-GPU workload
 on its own env shard (weak scaling; no data-path collective; --shared-learner adds the RCCL gradient
 all-reduce of configs[4]).

@@ -454,27 +454,31 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finalise
 constexpr int MAX_BATCH = 1024;
 __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, uint64_t *__restrict__ state,
                                                          int64_t *__restrict__ idx, float *__restrict__ taus, int n_taus) {
-    __shared__ int64_t val[MAX_BATCH];
+    __shared__ __align__(16) int val[MAX_BATCH];
     const uint64_t seed = state[0], ctr = state[1];
     const uint64_t base = mix64(seed + 0x9E3779B97F4A7C15ull * (ctr + 1));
     for (int e = threadIdx.x; e < n_taus; e += 256) {
         const uint64_t x = mix64(base ^ (0xD1B54A32D192ED03ull * (uint64_t)(e + 1)));
         taus[e] = (float)(x >> 40) * (1.0f / 16777216.0f);          // 24-bit uniform in [0, 1), like torch.rand
     }
+    const int padded = (batch + 3) & ~3;
     int attempt[MAX_BATCH / 256];
-    for (int k = threadIdx.x, q = 0; k < batch; k += 256, ++q) {
+    for (int k = threadIdx.x, q = 0; k < padded; k += 256, ++q) {
         attempt[q] = 0;
         const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1));
-        val[k] = (int64_t)__umul64hi(x, (uint64_t)n);
+        val[k] = k < batch ? (int)__umul64hi(x, (uint64_t)n) : -1;
     }
     __syncthreads();
     for (;;) {
         int clash = 0;
         bool redo[MAX_BATCH / 256];
         for (int k = threadIdx.x, q = 0; k < batch; k += 256, ++q) {
-            const int64_t v = val[k];
+            const int v = val[k];
             bool c = false;
-            for (int j = 0; j < k; ++j) c |= (val[j] == v);
+            for (int j = 0; j < k; j += 4) {      // wave-uniform broadcast reads, four candidates each
+                const int4 w = *reinterpret_cast<const int4 *>(&val[j]);
+                c |= (w.x == v) | ((w.y == v) & (j + 1 < k)) | ((w.z == v) & (j + 2 < k)) | ((w.w == v) & (j + 3 < k));
+            }
             redo[q] = c;
             clash |= c;
         }
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, u
             if (!redo[q]) continue;
             ++attempt[q];
             const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1) + 0x9FB21C651E98DF25ull * (uint64_t)attempt[q]);
-            val[k] = (int64_t)__umul64hi(x, (uint64_t)n);
+            val[k] = (int)__umul64hi(x, (uint64_t)n);
         }
         __syncthreads();
     }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, u
 extern "C" int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out,
                              int32_t n_taus_total, void *stream) {
     if (!rng_state_dev || !idx_out || (n_taus_total > 0 && !taus_out) || n_taus_total < 0) return MN_ERR_INVALID;
-    if (batch <= 0 || batch > MAX_BATCH || ring_size < batch) return MN_ERR_INVALID;
+    if (batch <= 0 || batch > MAX_BATCH || ring_size < batch || ring_size > 0x7fffffff) return MN_ERR_INVALID;
     hipLaunchKernelGGL(iqn_sample_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ring_size, batch, rng_state_dev, idx_out,
                        taus_out, n_taus_total);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
