@@ -91,6 +91,7 @@ def main():
                     help="threads for the multi-thread oracle baseline (-1 = host CPUs this process may use, capped at 64; 0 = skip)")
     ap.add_argument("--act-chunk", type=int, default=8192)
     ap.add_argument("--no-train-graph", action="store_true", help="eager grad step instead of the captured hipGraph")
+    ap.add_argument("--no-learner-only", action="store_true", help="skip the learner-alone measurement after the timed loop (cleaner profiles)")
     ap.add_argument("--torch-train", action="store_true", help="grad step through PyTorch autograd + Adam instead of the fused HIP step")
     ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
     ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
@@ -180,7 +181,7 @@ def main():
     # Eager = what the loop uses (there the ~130 launches hide behind the act kernel); back to back the eager step is
     # CPU-launch-bound, which is where the captured hipGraph (IQNAgent.use_train_graph) pays.
     learner_only = {}
-    if agent is not None and len(agent.memory) > agent.BATCH_SIZE:
+    if agent is not None and len(agent.memory) > agent.BATCH_SIZE and not args.no_learner_only:
         was_fused = agent.use_fused_train
         for mode in ("fused_hip", "eager", "hipgraph"):       # the torch modes last: they advance torch's own Adam state
             if mode == "hipgraph" and agent.distributed:
