@@ -43,8 +43,13 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
     assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous()
     n = states.shape[0]
     dev = states.device
-    t = _taus(net, n, dev, cvar, taus, generator)
-    u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
+    if taus is None and eps > 0.0:      # one RNG launch for the n x K taus and the n exploration uniforms
+        buf = torch.rand(n * (net.K + 1), device=dev, generator=generator)
+        t = _taus(net, n, dev, cvar, buf[:n * net.K].view(n, net.K), None)
+        u = buf[n * net.K:]
+    else:
+        t = _taus(net, n, dev, cvar, taus, generator)
+        u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
