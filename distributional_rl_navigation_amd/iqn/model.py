@@ -80,7 +80,9 @@ class ObsEncoder(nn.Module):
 
     def save(self, directory):
         """model.py:198-207: network_params.pth + constructor_params.json."""
-        torch.save(self.state_dict(), os.path.join(directory, "network_params.pth"))
+        # clone: the parameters may be views of one flat buffer (iqn/fused_train.py); upstream checkpoints hold one
+        # independent storage per tensor
+        torch.save({k: v.detach().clone() for k, v in self.state_dict().items()}, os.path.join(directory, "network_params.pth"))
         with open(os.path.join(directory, "constructor_params.json"), mode="w") as f:
             json.dump(self.get_constructor_parameters(), f)
 

@@ -55,7 +55,7 @@ def create_eval_configs(device, seed=348):
 
 
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
-              update_every=4, grad_steps=1):
+              update_every=4, grad_steps=1, torch_train=False):
     """train_IQN_model.py:74-121 on the vector env."""
     import torch
     from .iqn.agent import IQNAgent
@@ -85,6 +85,8 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
                      seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
                      UPDATE_EVERY=update_every)
     agent.grad_steps_per_update = grad_steps
+    if torch_train:
+        agent.use_fused_train = False          # PyTorch autograd + Adam instead of csrc/iqn_train.hip
     vec_steps = int(np.ceil((params["total_timesteps"] + 1) / total))
     eval_every = max(1, int(round(params["eval_freq"] / total)))
     agent.learn_vec(total_vector_steps=vec_steps, train_env=train_env, eval_env=eval_env, eval_config=eval_config,
@@ -109,6 +111,7 @@ def main(argv=None):
     ap.add_argument("--shared-learner", action="store_true")
     ap.add_argument("--update-every", type=int, default=4, help="vector steps between training events (UPDATE_EVERY)")
     ap.add_argument("--grad-steps", type=int, default=1, help="grad steps per training event")
+    ap.add_argument("--torch-train", action="store_true", help="gradient step through PyTorch instead of the fused HIP kernels")
     args = ap.parse_args(argv)
     params = json.load(args.config_file)
     import torch
@@ -123,7 +126,7 @@ def main(argv=None):
     for p in trial_params(params):
         p["training_time"] = stamp
         run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay,
-                  update_every=args.update_every, grad_steps=args.grad_steps)
+                  update_every=args.update_every, grad_steps=args.grad_steps, torch_train=args.torch_train)
     if world > 1:
         dist.destroy_process_group()
 
