@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = {(8, 10): 406, (8, 5): 346, (4, 6): 310}   # 190 + 12 * (n_cores + n_obs)
 HBM_PEAK_GBS = 8000.0
-# IQN act, K = 32 taus: 2 * 32 * (64*208 + 208*64 + 64*64 + 64*9) FLOP per env-step ("~2.0 MFLOP")
+# IQN act, K = 32 taus: 2 * 32 * (64*208 + 208*64 + 64*64 + 64*9) ALGORITHMIC FLOP per env-step ("~2.0 MFLOP";
+# the kernel takes the tau-mean before the linear output layer, so it executes 960 MFMAs = 1.966 MFLOP + a 9x64 mat-vec)
 ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at

@@ -271,35 +271,32 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = relu4(acc3[mt][nt] + bias);
         }
-        // ---- layer 4 (9 outputs padded to one 16-row tile) -------------------------------------------
-        f32x4 acc4[NT];
+        // ---- layer 4 + mean over the 32 taus (model.py:185,190).  The output layer is linear, so
+        // mean_tau(W4 h3(tau) + b4) = W4 mean_tau(h3(tau)) + b4: the tau mean is taken FIRST (DPP row sums of the
+        // layer-3 accumulators) and the 9 x 64 output layer becomes one small VALU mat-vec per environment
+        // instead of 32 MFMAs on a padded 16-row tile (3 % of the kernel's matrix work).
+        // After row_sum16 every lane of row group g holds sum_tau h3[16mt + 4g + r]; lane (g, col) then forms the
+        // part of action `col` that comes from its 16 features (W4p[mt][lane][r] = W4[col][16mt + 4g + r], zero rows
+        // for col >= 9) and the four row groups are added with two cross-row shuffles.
+        float part = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 a = ldsv[(OFF_W4 >> 2) + mt * 64 + lane];
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-            const f32x4 a = ldsv[(OFF_W4 >> 2) + t2 * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc4[nt] = mfma(a[r], acc3[t2][nt][r], acc4[nt]);
+            for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(acc3[mt][0][r] + acc3[mt][1][r]), part);
         }
-        // ---- mean over the 32 taus (model.py:190); action = 4g + r -----------------------------------
-        const f32x4 bias4 = ldsv[(OFF_B4 >> 2) + g];
-        float qa[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            qa[r] = row_sum16(acc4[0][r] + acc4[1][r]) * (1.0f / K_TAUS) + bias4[r];
-            const int action = 4 * g + r;
-            if (qvals && col == 0 && action < A_OUT) qvals[(size_t)e * A_OUT + action] = qa[r];
-        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
+        if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {
-            // lane 16g holds actions 4g..4g+3; gather the 9 values (first maximum wins, like np.argmax)
+            // lane a holds action a; gather the 9 values (first maximum wins, like np.argmax)
             float best = -INFINITY;
             int arg = 0;
 #pragma unroll
             for (int a = 0; a < A_OUT; ++a) {
-                const float v = __shfl(qa[a & 3], 16 * (a >> 2));
+                const float v = __shfl(qv, a);
                 if (v > best) { best = v; arg = a; }
             }
             if (lane == 0) {
