@@ -280,3 +280,32 @@ def test_fused_train_is_deterministic_and_seeded(torch):
     assert l0 == l1 and torch.equal(p0, p1) and torch.equal(i0, i1) and torch.equal(t0, t1)
     assert not torch.equal(i0, i2) and not torch.equal(t0, t2)
     assert all(np.isfinite(l0)) and bool(torch.isfinite(p0).all())
+
+
+def test_iqn_c_abi_argument_checks(torch):
+    """Error behaviour of the IQN entry points: integer status codes, nothing launched on bad arguments."""
+    import ctypes as C
+    from distributional_rl_navigation_amd import _capi
+    L = _capi.lib()
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35786 + 140
+    assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
+    dev = "cuda:0"
+    st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
+    taus = torch.zeros(64, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    INVALID = -1
+    assert L.mn_iqn_sample(100, 256, p(st), p(idx), p(taus), 64, None) == INVALID       # ring smaller than the batch
+    assert L.mn_iqn_sample(10000, 2048, p(st), p(idx), p(taus), 64, None) == INVALID    # batch > 1024
+    assert L.mn_iqn_sample(10000, 16, None, p(idx), p(taus), 64, None) == INVALID
+    assert L.mn_iqn_sample(10000, 16, p(st), p(idx), None, 0, None) == 0                # taus optional
+    torch.cuda.synchronize()
+    assert int(st[1]) == 1 and idx[:16].unique().numel() == 16
+    f = torch.zeros(35785, device=dev); ws = torch.zeros(L.mn_iqn_train_workspace_floats(2), device=dev)
+    ring = (torch.zeros(4, 26, device=dev), torch.zeros(4, 26, device=dev), torch.zeros(4, 1, dtype=torch.int64, device=dev),
+            torch.zeros(4, 1, device=dev), torch.zeros(4, 1, device=dev))
+    args = lambda B, K: (p(ring[0]), p(ring[1]), p(ring[2]), p(ring[3]), p(ring[4]), p(idx), p(taus), p(taus), p(f), p(f), p(ws),
+                         p(f), p(taus), B, K, C.c_float(0.99), None)
+    assert L.mn_iqn_train_grad(*args(3, 8)) == INVALID      # odd batch
+    assert L.mn_iqn_train_grad(*args(2, 32)) == INVALID     # training uses 8 taus
+    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, None) == INVALID
+    assert L.mn_iqn_act(p(ring[0]), p(taus), None, None, None, C.c_float(0.0), p(idx), 4, 32, None) == INVALID
