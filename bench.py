@@ -254,7 +254,7 @@ def main():
             }
         else:
             out["roofline"] = out["roofline_env_step"]
-        if args.cpu_steps > 0:
+        if args.cpu_steps > 0 and world == 1:      # reported baseline: rank 0 at N = 1 only
             v, dt = cpu_baseline(args.cpu_steps, (args.cores, args.obstacles, min_dis))
             out["cpu_baseline"] = {
                 "value": v, "unit": "env steps/s", "cores": 1, "kind": "port",
