@@ -196,7 +196,8 @@ int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launche
  *   explore_u_dev [n] f32 : uniform [0,1) draws for exploration (may be NULL = greedy); env i takes the
  *                           greedy action iff u_i > eps (agent.py:200), else action floor(u_i / eps * 9)
  *   actions_dev [n] i32   : chosen actions (may be NULL if only Q-values are wanted)
- * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32. */
+ * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32.  The permuted weight image is a per-device scratch buffer
+ * rebuilt by every call: calls for the same device must be stream-ordered (one stream, or serialised by events). */
 int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
                const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus, void *stream);
 
