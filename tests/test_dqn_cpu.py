@@ -65,3 +65,30 @@ def test_closed_loop_reproduces_recorded_evaluation():
             assert (info == 4) == bool(g["eval_successes"][i])          # 4 = "reach goal"
             full += 1
     assert full >= 15, full
+
+
+def test_train_step_matches_reference_dqn_train():
+    """G11: one step of the reference's own `DQN.train` (dqn/dqn.py:188-230, run on its own ObsEncoderPolicy by
+    tests/golden/make_golden_dqn.py) -> loss, clipped gradients and post-Adam parameters of `DQNAgent.train`."""
+    from distributional_rl_navigation_amd.dqn import DQNAgent
+    Z = np.load(os.path.join(G, "g11_dqn_train.npz"))
+    ag = DQNAgent(device="cpu", buffer_size=64, batch_size=32)
+    ag.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"))
+    ag.q_net_target.load_state_dict({k[len("tgt_"):]: torch.from_numpy(Z[k]) for k in Z.files if k.startswith("tgt_")})
+    exp = tuple(torch.from_numpy(Z["batch_" + k]) for k in ("observations", "actions", "rewards", "next_observations", "dones"))
+    loss = ag.train(exp)
+    np.testing.assert_allclose(float(loss), float(Z["loss"]), rtol=1e-6)
+    for k, p in ag.q_net.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), Z["grad_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(p.detach().numpy(), Z["after_" + k], rtol=0, atol=2e-6, err_msg=k)
+    assert ag.n_updates == 1
+    sd = ag.state_dict()
+    assert len(sd) == 36 and "q_net_target.q_net.4.bias" in sd and "q_net.features_extractor.goal_encoder.weight" in sd
+
+
+def test_exploration_schedule_is_sb3s_linear_fn():
+    from distributional_rl_navigation_amd.dqn import DQNAgent
+    ag = DQNAgent(device="cpu", buffer_size=64)
+    for t, want in ((0, 1.0), (150_000, 0.525), (300_000, 0.05), (2_000_000, 0.05)):
+        ag.num_timesteps = t
+        assert abs(ag.exploration_rate(3_000_000) - want) < 1e-12
