@@ -128,12 +128,61 @@ __global__ __launch_bounds__(256) void iqn_pack_kernel(IqnWeights w, float *__re
     if (i < OFF_FB) packed[i] = pack_element(w, i);
 }
 
+// Counter-based uniform draws: draw number `idx` of call `ctr` is a double murmur3-fmix32 of the index under two 32-bit
+// keys derived from (seed, ctr) -- no generator state per element, any element can be produced by any thread.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint32_t idx, uint32_t k0, uint32_t k1) {      // 24-bit uniform in [0, 1), like torch.rand
+    return (float)(fmix32(fmix32(idx ^ k0) + k1) >> 8) * (1.0f / 16777216.0f);
+}
+
+constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;
+
+// The same weight image PLUS the random numbers of the call in one launch: blocks [0, PACK_BLOCKS) pack, the others
+// fill draws[0 .. 32 n) with tau = U[0,1) * cvar (model.py:149-153; per-row cvar if cvar_row) and draws[32 n .. 33 n)
+// with the exploration uniforms of IQNAgent.act (agent.py:199).  rng_state = {seed, call counter}; the counter is
+// advanced by the act kernel that follows in the stream.
+__global__ __launch_bounds__(256) void iqn_prep_kernel(IqnWeights w, float *__restrict__ packed, const uint64_t *__restrict__ rng_state,
+                                                       float *__restrict__ draws, int n, const float *__restrict__ cvar_row,
+                                                       float cvar) {
+    if (blockIdx.x < PACK_BLOCKS) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < OFF_FB) packed[i] = pack_element(w, i);
+        return;
+    }
+    const uint64_t base = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 1));
+    const uint32_t k0 = (uint32_t)base, k1 = (uint32_t)(base >> 32);
+    const long total4 = ((long)n * (K_TAUS + 1) + 3) / 4;          // float4 groups
+    const long stride = (long)(gridDim.x - PACK_BLOCKS) * 256;
+    for (long q = (long)(blockIdx.x - PACK_BLOCKS) * 256 + threadIdx.x; q < total4; q += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long idx = 4 * q + j;
+            float u = u01((uint32_t)idx, k0, k1);
+            if (idx < (long)n * K_TAUS) u *= cvar_row ? cvar_row[idx / K_TAUS] : cvar;
+            v[j] = u;
+        }
+        if (4 * q + 3 < (long)n * (K_TAUS + 1)) *reinterpret_cast<float4 *>(draws + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int j = 0; j < 4 && 4 * q + j < (long)n * (K_TAUS + 1); ++j) draws[4 * q + j] = v[j];
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                            const float *__restrict__ packed, float *__restrict__ qvals,
                                                            const float *__restrict__ explore_u, float eps,
-                                                           int32_t *__restrict__ actions, int n) {
+                                                           int32_t *__restrict__ actions, int n,
+                                                           uint64_t *__restrict__ rng_state) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
+    if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by iqn_prep_kernel
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(packed);
         f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
@@ -345,10 +394,11 @@ extern "C" int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launch
     return MN_OK;
 }
 
-extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
-                          const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
-                          void *stream) {
-    if (!obs_dev || !taus_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
+static int launch_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+                      const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
+                      uint64_t *rng_state_dev, float *draws_dev, const float *cvar_row_dev, float cvar, void *stream) {
+    if (!obs_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
+    if (rng_state_dev ? !draws_dev : !taus_dev) return MN_ERR_INVALID;
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
     static int n_cu_of[64] = {0};       // per device: CU count (0 = not initialised)
@@ -370,11 +420,37 @@ extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const flo
                     weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
     if (blocks > n_cu) blocks = n_cu;
+    hipStream_t s = (hipStream_t)stream;
     const bool prof = g_prof_n < g_prof_max;
-    if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], (hipStream_t)stream);
-    hipLaunchKernelGGL(iqn_pack_kernel, dim3((OFF_FB + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, packed);
-    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), (hipStream_t)stream, obs_dev,
-                       taus_dev, packed, qvals_dev, explore_u_dev, eps, actions_dev, n);
-    if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], (hipStream_t)stream); ++g_prof_n; }
+    if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], s);
+    if (rng_state_dev) {
+        long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
+        int rng_blocks = (int)((groups + 255) / 256);
+        if (rng_blocks > 8 * n_cu) rng_blocks = 8 * n_cu;
+        hipLaunchKernelGGL(iqn_prep_kernel, dim3(PACK_BLOCKS + rng_blocks), dim3(256), 0, s, w, packed,
+                           (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar);
+        taus_dev = draws_dev;
+        explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
+    } else {
+        hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, packed);
+    }
+    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev, packed,
+                       qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+    if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], s); ++g_prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+                          const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
+                          void *stream) {
+    return launch_act(obs_dev, taus_dev, weights, qvals_dev, explore_u_dev, eps, actions_dev, n, num_taus, nullptr, nullptr,
+                      nullptr, 1.0f, stream);
+}
+
+extern "C" int mn_iqn_act_rng(const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev, float *draws_dev,
+                              const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev, float *qvals_dev,
+                              int32_t n, int32_t num_taus, void *stream) {
+    if (!rng_state_dev) return MN_ERR_INVALID;
+    return launch_act(obs_dev, nullptr, weights, qvals_dev, nullptr, eps, actions_dev, n, num_taus, rng_state_dev, draws_dev,
+                      cvar_row_dev, cvar, stream);
 }

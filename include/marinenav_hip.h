@@ -201,6 +201,15 @@ int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launche
 int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
                const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus, void *stream);
 
+/* Same act kernel, with the random numbers of the call drawn by the library in the SAME launch that builds the weight
+ * image (no separate generator kernels): draws_dev [33 n] f32 (caller-owned scratch) receives tau[e][j] = U[0,1) * cvar
+ * (cvar_row_dev[e] if given, else the scalar `cvar`; model.py:149-153) in its first 32 n entries and the exploration
+ * uniforms of agent.py:199 in the last n; the act kernel then consumes them.  Counter-based generator keyed by
+ * rng_state_dev = u64[2] {seed, call counter} on the device; the counter is advanced by the call. */
+int mn_iqn_act_rng(const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev, float *draws_dev,
+                   const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev, float *qvals_dev, int32_t n,
+                   int32_t num_taus, void *stream);
+
 /* ---- replay ring ------------------------------------------------------------------------------
  * ReplayBuffer.add (thirdparty/IQN/replay_buffer.py:26-34) for n transitions in one launch: batch row i
  * goes to ring slot (ptr + i) mod capacity (FIFO eviction like deque(maxlen); if n > capacity only the

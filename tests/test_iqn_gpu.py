@@ -309,3 +309,49 @@ def test_iqn_c_abi_argument_checks(torch):
     assert L.mn_iqn_train_grad(*args(2, 32)) == INVALID     # training uses 8 taus
     assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, None) == INVALID
     assert L.mn_iqn_act(p(ring[0]), p(taus), None, None, None, C.c_float(0.0), p(idx), 4, 32, None) == INVALID
+
+
+def test_act_with_library_drawn_taus(torch):
+    """`mn_iqn_act_rng`: the launch that packs the weights also draws the call's taus and exploration uniforms.
+    (1) Feeding the draws it left in the scratch buffer back through the injected-taus path reproduces Q-values and
+    actions bitwise; (2) taus are U[0,1) * cvar (scalar and per-row), fresh on every call, reproducible from the seed;
+    (3) exploration happens with probability eps and is uniform over the 9 actions."""
+    from distributional_rl_navigation_amd.iqn.fused_act import ActRng, fused_act, fused_qvals
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    dev = "cuda:0"
+    net = ObsEncoder.load(os.path.join(G, "pretrained_IQN_seed3"), dev)
+    n = 30001
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    obs = torch.randn(n, 26, device=dev, generator=g) * 5.0
+    rng = ActRng(123, dev)
+    a, q = fused_act(net, obs, 0.0, 1.0, rng=rng, want_qvals=True)
+    d = rng.draws(n, 32).clone()
+    taus, u = d[:n * 32].view(n, 32), d[n * 32:]
+    assert int(rng.state[1]) == 1
+    assert float(taus.min()) >= 0.0 and float(taus.max()) < 1.0 and abs(float(taus.mean()) - 0.5) < 2e-3
+    assert abs(float(taus.var()) - 1 / 12) < 2e-3 and abs(float(u.mean()) - 0.5) < 1e-2
+    assert abs(float(torch.corrcoef(torch.stack((taus[:, 0], taus[:, 1])))[0, 1])) < 0.02       # neighbouring draws uncorrelated
+    a2, q2 = fused_act(net, obs, 0.0, 1.0, taus=taus, want_qvals=True)
+    assert torch.equal(q, q2) and torch.equal(a, a2)
+    # fresh draws on the next call; same seed -> same sequence
+    fused_act(net, obs, 0.0, 1.0, rng=rng)
+    assert not torch.equal(rng.draws(n, 32), d) and int(rng.state[1]) == 2
+    rng2 = ActRng(123, dev)
+    fused_act(net, obs, 0.0, 1.0, rng=rng2)
+    assert torch.equal(rng2.draws(n, 32), d)
+    # cvar scaling: scalar and per-row
+    fused_act(net, obs, 0.0, 0.25, rng=rng)
+    t = rng.draws(n, 32)[:n * 32]
+    assert float(t.max()) < 0.25 and abs(float(t.mean()) - 0.125) < 1e-3
+    cv = torch.rand(n, device=dev, generator=g)
+    fused_act(net, obs, 0.0, cv, rng=rng)
+    t = rng.draws(n, 32)[:n * 32].view(n, 32)
+    assert bool((t <= cv.view(-1, 1)).all()) and abs(float((t / cv.view(-1, 1)).mean()) - 0.5) < 2e-3
+    # epsilon-greedy from the library's own uniforms
+    greedy = fused_act(net, obs, 0.0, 1.0, taus=taus)
+    acts = fused_act(net, obs, 0.3, 1.0, rng=rng)
+    u = rng.draws(n, 32)[n * 32:]
+    explored = ~(u > 0.3)
+    assert abs(float(explored.float().mean()) - 0.3) < 0.01
+    hist = torch.bincount(acts[explored].long(), minlength=9).float()
+    assert float((hist / hist.sum() - 1 / 9).abs().max()) < 0.01
