@@ -43,6 +43,7 @@ class IQNAgent:
         self.grad_steps_per_update = 1               # vectorised loop only: grad steps per training event
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
         self._act_rng = None                         # the act path's own counter-based tau / exploration draws (fused_act.ActRng)
+        self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
@@ -175,6 +176,8 @@ class IQNAgent:
         argmax, exploration); exploration draws come from a device generator."""
         if states.is_cuda and self.use_fused_act:
             from .fused_act import fused_act
+            if not self.use_library_rng:
+                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen)
             if self._act_rng is None:
                 from .fused_act import ActRng
                 self._act_rng = ActRng(self.gen.initial_seed(), states.device)

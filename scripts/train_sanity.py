@@ -15,8 +15,11 @@ sched = dict(timesteps=[0, 1000000, 2000000], num_cores=[4, 6, 8], num_obstacles
 total = n_envs * steps
 env = VecMarineNavEnv(n_envs, seed=0, schedule=sched, timestep_scale=3_000_000 / total, device="cuda:0")  # whole curriculum over the run
 eval_env = VecMarineNavEnv(30, device="cuda:0")
-agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=1_000_000, device="cuda:0", seed=100, learning_starts=n_envs * 4,
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=1_000_000, device="cuda:0", seed=seed, learning_starts=n_envs * 4,
                  target_update_interval=500, UPDATE_EVERY=1)
+if os.environ.get("MN_ACT_TORCH_RNG") == "1":
+    agent.use_library_rng = False
 def ev(tag):
     r = agent.evaluation_vec(eval_env, cfg, greedy=True)
     print(f"[{tag}] eval: success {sum(r['successes'])}/30  mean return {np.mean(r['rewards']):.2f}", flush=True)
