@@ -399,6 +399,7 @@ static int launch_act(const float *obs_dev, const float *taus_dev, const float *
                       uint64_t *rng_state_dev, float *draws_dev, const float *cvar_row_dev, float cvar, void *stream) {
     if (!obs_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
     if (rng_state_dev ? !draws_dev : !taus_dev) return MN_ERR_INVALID;
+    if (rng_state_dev && (long)n * (K_TAUS + 1) >= (1L << 32)) return MN_ERR_INVALID;   // 32-bit draw index
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
     static int n_cu_of[64] = {0};       // per device: CU count (0 = not initialised)
