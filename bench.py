@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--torch-act", action="store_true", help="act through eager PyTorch instead of the fused HIP kernel")
     ap.add_argument("--robot-n", type=int, default=10, help="sub-steps per action (robot.N; 10 = reference; ablation only)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per env in the step kernel (0 = library default)")
+    ap.add_argument("--update-every", type=int, default=4, help="vector steps between training events (UPDATE_EVERY; SURVEY 8d C3: 4)")
+    ap.add_argument("--grad-steps", type=int, default=1, help="gradient steps per training event (1 = the reference's cadence)")
+    ap.add_argument("--eps", type=float, default=None, help="fixed exploration rate (default: the reference's linear schedule at the start of training, ~1.0)")
+    ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
 
     import torch
@@ -119,10 +123,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # under torch.distributed.run: RCCL, even for 1 rank
+    # under torch.distributed.run: RCCL, even for 1 rank; a plain `python bench.py --shared-learner` (N = 1) forms a
+    # single-rank RCCL group itself so that configs[4]'s gradient all-reduce executes
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or args.shared_learner
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if "MASTER_ADDR" in os.environ and "RANK" in os.environ:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
 
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
@@ -133,7 +146,9 @@ def main():
     if not args.no_learner:
         agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device=device,
                          seed=100 if args.shared_learner else 100 + rank, learning_starts=0,
-                         distributed=args.shared_learner and use_dist, act_chunk=args.act_chunk)
+                         distributed=args.shared_learner and use_dist, act_chunk=args.act_chunk,
+                         UPDATE_EVERY=args.update_every, rank=rank if args.shared_learner else 0)
+        agent.grad_steps_per_update = args.grad_steps
     if agent is not None and args.torch_act:
         agent.use_fused_act = False
     if agent is not None and args.no_train_graph:
@@ -144,13 +159,24 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(rank)
 
+    class _NoAppend:      # --separate-append: hide step_append so that vec_step takes the two-launch path
+        def __init__(self, e):
+            self._e = e
+        def __getattr__(self, k):
+            if k == "step_append":
+                raise AttributeError(k)
+            return getattr(self._e, k)
+    loop_env = _NoAppend(env) if args.separate_append else env
+    eps_seen = []
+
     def one_step(o):
         if agent is None:
             a = torch.randint(0, 9, (n,), device=device, dtype=torch.int32, generator=gen)
             env.step(a)
             return env.reset_done()
-        eps = agent.linear_eps(total_timesteps)
-        return agent.vec_step(env, o, eps, args.cvar, per_iter=n * world)[0]
+        eps = agent.linear_eps(total_timesteps) if args.eps is None else args.eps
+        eps_seen.append(eps)
+        return agent.vec_step(loop_env, o, eps, args.cvar, per_iter=n * world)[0]
 
     def fence():
         torch.cuda.synchronize(device)
@@ -171,7 +197,8 @@ def main():
     from distributional_rl_navigation_amd import _capi
     fused = agent is not None and agent.use_fused_act
     if fused:
-        _capi.lib().mn_iqn_profile_begin(n_prof)
+        from distributional_rl_navigation_amd.iqn.fused_act import act_context
+        act_context(agent.qnetwork_local).profile_begin(n_prof)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         obs = one_step(obs)
@@ -180,9 +207,7 @@ def main():
     step_kernel_ms, launches = env.profile_end()
     act_ms, act_launches = 0.0, 0
     if fused:
-        ms, nl = C.c_double(), C.c_int32()
-        _capi.lib().mn_iqn_profile_end(C.c_void_p(torch.cuda.current_stream(device).cuda_stream), C.byref(ms), C.byref(nl))
-        act_ms, act_launches = ms.value, nl.value
+        act_ms, act_launches = act_context(agent.qnetwork_local).profile_end()
     grad_steps = (agent.grad_steps - g0) if agent else 0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -232,10 +257,18 @@ def main():
             "config": {
                 "workload": ("step kernel only, random policy" if agent is None else
                              f"{n} envs/GPU + IQN training (act K=32, 8 quantiles, replay {args.replay}, batch {args.batch}, "
-                             f"train every 4 vector steps)"),
+                             f"{args.grad_steps} grad step(s) every {args.update_every} vector steps)"),
                 "envs_per_gpu": n, "n_cores": args.cores, "n_obstacles": args.obstacles,
                 "learner": "none" if agent is None else ("shared, RCCL grad all-reduce" if args.shared_learner else "independent per GPU"),
                 "cvar": args.cvar,
+                "process_group": dist.get_backend() if use_dist else None,
+                # exploration rate of the timed steps: the reference's schedule at the start of a run (the policy is
+                # ~uniformly random; the act kernel evaluates every Q-value regardless of eps), or --eps
+                "eps": None if agent is None else (sum(eps_seen[-args.steps:]) / max(1, len(eps_seen[-args.steps:]))),
+                "update_every_vector_steps": None if agent is None else args.update_every,
+                "grad_steps_per_event": None if agent is None else args.grad_steps,
+                "replay_append": "none" if agent is None else ("separate launch" if args.separate_append else "fused into the step kernel (mn_step_append)"),
+                "ablation": bool(_capi.lib().mn_build_info() & 1),     # from the loaded library: False = full kernels
             },
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region

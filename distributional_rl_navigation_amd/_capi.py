@@ -61,6 +61,8 @@ SIGNATURES = [
     ("mn_set_start_goal", C.c_int, [_vp, _i32, _pd, _pd]),
     ("mn_reset", C.c_int, [_vp, _pu8, _pf, _vp]),
     ("mn_step", C.c_int, [_vp, _vp, _pf, _pf, _pu8, _pu8, _vp]),
+    ("mn_step_append", C.c_int, [_vp, _vp, _pf, _pf, _pf, _pu8, _pu8, _pf, _pf, _vp, _pf, _pf, _i64, _i64, _vp]),
+    ("mn_build_info", _i32, []),
     ("mn_reset_done", C.c_int, [_vp, _pf, _vp]),
     ("mn_load_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _pf, _vp]),
     ("mn_get_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd]),
@@ -68,19 +70,24 @@ SIGNATURES = [
     ("mn_set_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
     ("mn_get_obs64", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_get_reward64", C.c_int, [_vp, _i32, _i32, _pd]),
+    ("mn_enable_trajectory", C.c_int, [_vp, _i32]),
+    ("mn_get_trajectory", C.c_int, [_vp, _i32, _i32, _i32, _pd]),
     ("mn_peek_next_double", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_last_done_count", C.c_int, [_vp, _vp, _pi32]),
     ("mn_profile_begin", C.c_int, [_vp, _i32]),
     ("mn_profile_end", C.c_int, [_vp, _vp, _pd, _pi32]),
-    ("mn_iqn_act", C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, C.c_float, _vp, _i32, _i32, _vp]),
-    ("mn_iqn_act_rng", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _i32, _i32, _vp]),
+    ("mn_iqn_create", C.c_int, [C.POINTER(_vp)]),
+    ("mn_iqn_destroy", C.c_int, [_vp]),
+    ("mn_iqn_weights_changed", C.c_int, [_vp]),
+    ("mn_iqn_act", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, C.c_float, _vp, _vp, _i32, _i32, _vp]),
+    ("mn_iqn_act_rng", C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _i32, _i32, _vp]),
     ("mn_replay_append", C.c_int, [_vp] * 10 + [_i64, _i64, _i64, _vp]),
     ("mn_iqn_train_workspace_floats", C.c_int64, [_i32]),
     ("mn_iqn_sample", C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     ("mn_iqn_train_grad", C.c_int, [_vp] * 13 + [_i32, _i32, C.c_float, _vp]),
     ("mn_iqn_train_adam", C.c_int, [_vp] * 6 + [_i32] + [C.c_double] * 5 + [_vp]),
-    ("mn_iqn_profile_begin", C.c_int, [_i32]),
-    ("mn_iqn_profile_end", C.c_int, [_vp, _pd, _pi32]),
+    ("mn_iqn_profile_begin", C.c_int, [_vp, _i32]),
+    ("mn_iqn_profile_end", C.c_int, [_vp, _vp, _pd, _pi32]),
 ]
 
 
@@ -95,6 +102,8 @@ def lib():
         for name, res, args in SIGNATURES:
             fn = getattr(L, name)      # AttributeError if the header and the library disagree
             fn.restype, fn.argtypes = res, args
+        if L.mn_build_info() != 0:
+            raise MarineNavHipError(f"{LIB_PATH} is an ablation build (mn_build_info() != 0); the package only runs the full kernels")
         _lib = L
     return _lib
 

@@ -150,8 +150,9 @@ constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;
 // advanced by the act kernel that follows in the stream.
 __global__ __launch_bounds__(256) void iqn_prep_kernel(IqnWeights w, float *__restrict__ packed, const uint64_t *__restrict__ rng_state,
                                                        float *__restrict__ draws, int n, const float *__restrict__ cvar_row,
-                                                       float cvar) {
-    if (blockIdx.x < PACK_BLOCKS) {
+                                                       float cvar, int pack_blocks) {
+    // pack_blocks = PACK_BLOCKS when the cached weight image is stale (mn_iqn_weights_changed), else 0
+    if ((int)blockIdx.x < pack_blocks) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i < OFF_FB) packed[i] = pack_element(w, i);
         return;
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void iqn_prep_kernel(IqnWeights w, float *__re
     const uint64_t base = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 1));
     const uint32_t k0 = (uint32_t)base, k1 = (uint32_t)(base >> 32);
     const long total4 = ((long)n * (K_TAUS + 1) + 3) / 4;          // float4 groups
-    const long stride = (long)(gridDim.x - PACK_BLOCKS) * 256;
-    for (long q = (long)(blockIdx.x - PACK_BLOCKS) * 256 + threadIdx.x; q < total4; q += stride) {
+    const long stride = (long)((int)gridDim.x - pack_blocks) * 256;
+    for (long q = (long)((int)blockIdx.x - pack_blocks) * 256 + threadIdx.x; q < total4; q += stride) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -175,11 +176,15 @@ __global__ __launch_bounds__(256) void iqn_prep_kernel(IqnWeights w, float *__re
     }
 }
 
+// QUANT = false: the training / acting hot path (tau-mean before the linear output layer, 960 MFMAs per env).
+// QUANT = true : IQNAgent.act_eval (agent.py:217-236): the output layer runs per tau on the matrix pipe (+32 MFMAs on a
+//                padded 16-row tile), the [n][32][9] quantile values are written out and Q is their mean.
+template <bool QUANT>
 __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                            const float *__restrict__ packed, float *__restrict__ qvals,
                                                            const float *__restrict__ explore_u, float eps,
                                                            int32_t *__restrict__ actions, int n,
-                                                           uint64_t *__restrict__ rng_state) {
+                                                           uint64_t *__restrict__ rng_state, float *__restrict__ quantiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by iqn_prep_kernel
@@ -327,16 +332,53 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
         // After row_sum16 every lane of row group g holds sum_tau h3[16mt + 4g + r]; lane (g, col) then forms the
         // part of action `col` that comes from its 16 features (W4p[mt][lane][r] = W4[col][16mt + 4g + r], zero rows
         // for col >= 9) and the four row groups are added with two cross-row shuffles.
-        float part = 0.f;
+        float qv;
+        if constexpr (!QUANT) {
+            float part = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 a = ldsv[(OFF_W4 >> 2) + mt * 64 + lane];
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 a = ldsv[(OFF_W4 >> 2) + mt * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(acc3[mt][0][r] + acc3[mt][1][r]), part);
+                for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(acc3[mt][0][r] + acc3[mt][1][r]), part);
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
+        } else {
+            // quantile values Z(tau, a) = W4 h3(tau) + b4 (model.py:185): C tile [16 padded actions x 16 taus] per tau tile;
+            // lane (g, col) holds actions 4g + r of tau 16 nt + col
+            f32x4 acc4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const f32x4 a = ldsv[(OFF_W4 >> 2) + t2 * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc4[nt] = mfma(a[r], acc3[t2][nt][r], acc4[nt]);
+            }
+            const f32x4 b4 = ldsv[(OFF_B4 >> 2) + g];
+            float mine = 0.f;      // lane `a` (< 9) ends up with Q(s, a) = mean over the 32 taus
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a_idx = 4 * g + r;
+                float sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float z = acc4[nt][r] + b4[r];
+                    if (a_idx < A_OUT) quantiles[((size_t)e * K_TAUS + 16 * nt + col) * A_OUT + a_idx] = z;
+                    sum += z;
+                }
+                sum = row_sum16(sum);                    // over the 16 tau columns of the row group
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {         // hand action 4 gg + r to lane (4 gg + r)
+                    const float v = __shfl(sum, 16 * gg);
+                    if (lane == 4 * gg + r) mine = v;
+                }
+            }
+            qv = mine * (1.0f / K_TAUS);
         }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const float qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
         if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {
@@ -363,95 +405,138 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 }  // namespace
 
 // C-ABI ----------------------------------------------------------------------------------------------
-namespace {
-hipEvent_t g_ev[2 * 4096];
-int g_prof_max = 0, g_prof_n = 0, g_ev_made = 0;
-}  // namespace
+#include <vector>
 
-extern "C" int mn_iqn_profile_begin(int32_t max_launches) {
-    if (max_launches < 0 || max_launches > 4096) return MN_ERR_INVALID;
-    while (g_ev_made < 2 * max_launches) {
-        if (hipEventCreate(&g_ev[g_ev_made]) != hipSuccess) return MN_ERR_HIP;
-        ++g_ev_made;
-    }
-    g_prof_max = max_launches;
-    g_prof_n = 0;
+// Per-caller state of the act path: the permuted LDS weight image (cached between calls until the caller says the
+// weights changed), the profiling events.  One context per agent / per stream: two contexts never share a buffer, so
+// agents acting on different streams of one device cannot race on the image.
+struct mn_iqn_ctx {
+    int device = -1;
+    int n_cu = 0;
+    float *packed = nullptr;
+    bool dirty = true;
+    std::vector<hipEvent_t> ev;
+    int prof_max = 0, prof_n = 0;
+};
+
+extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
+    if (!out) return MN_ERR_INVALID;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MN_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
+    // per-device function attribute; setting it again for another context is harmless and has no shared host state
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+        return MN_ERR_HIP;
+    mn_iqn_ctx *c = new mn_iqn_ctx();
+    c->device = dev;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipMalloc(reinterpret_cast<void **>(&c->packed), OFF_FB * sizeof(float)) != hipSuccess) { delete c; return MN_ERR_ALLOC; }
+    *out = c;
     return MN_OK;
 }
 
-extern "C" int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches) {
+extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
+    if (!c) return MN_ERR_INVALID;
+    int cur = -1;
+    const bool moved = hipGetDevice(&cur) == hipSuccess && cur != c->device;
+    if (moved) (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    (void)hipFree(c->packed);
+    if (moved) (void)hipSetDevice(cur);
+    delete c;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_weights_changed(mn_iqn_ctx *c) {
+    if (!c) return MN_ERR_INVALID;
+    c->dirty = true;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_profile_begin(mn_iqn_ctx *c, int32_t max_launches) {
+    if (!c || max_launches < 0 || max_launches > 65536) return MN_ERR_INVALID;
+    while ((int)c->ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return MN_ERR_HIP;
+        c->ev.push_back(e);
+    }
+    c->prof_max = max_launches;
+    c->prof_n = 0;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_profile_end(mn_iqn_ctx *c, void *stream, double *mean_ms, int32_t *launches) {
+    if (!c) return MN_ERR_INVALID;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MN_ERR_HIP;
     double sum = 0.0;
-    for (int i = 0; i < g_prof_n; ++i) {
+    for (int i = 0; i < c->prof_n; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) return MN_ERR_HIP;
+        if (hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]) != hipSuccess) return MN_ERR_HIP;
         sum += ms;
     }
-    if (mean_ms) *mean_ms = g_prof_n ? sum / g_prof_n : 0.0;
-    if (launches) *launches = g_prof_n;
-    g_prof_max = 0;
-    g_prof_n = 0;
+    if (mean_ms) *mean_ms = c->prof_n ? sum / c->prof_n : 0.0;
+    if (launches) *launches = c->prof_n;
+    c->prof_max = 0;
+    c->prof_n = 0;
     return MN_OK;
 }
 
-static int launch_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
-                      const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
-                      uint64_t *rng_state_dev, float *draws_dev, const float *cvar_row_dev, float cvar, void *stream) {
-    if (!obs_dev || !weights || (!qvals_dev && !actions_dev)) return MN_ERR_INVALID;
+static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+                      const float *explore_u_dev, float eps, int32_t *actions_dev, float *quantiles_dev, int32_t n,
+                      int32_t num_taus, uint64_t *rng_state_dev, float *draws_dev, const float *cvar_row_dev, float cvar,
+                      void *stream) {
+    if (!c || !obs_dev || !weights || (!qvals_dev && !actions_dev && !quantiles_dev)) return MN_ERR_INVALID;
     if (rng_state_dev ? !draws_dev : !taus_dev) return MN_ERR_INVALID;
     if (rng_state_dev && (long)n * (K_TAUS + 1) >= (1L << 32)) return MN_ERR_INVALID;   // 32-bit draw index
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     if (n <= 0 || num_taus != K_TAUS) return MN_ERR_INVALID;
-    static int n_cu_of[64] = {0};       // per device: CU count (0 = not initialised)
-    static float *packed_of[64] = {nullptr};   // per device: LDS weight image built by iqn_pack_kernel
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
-    if (n_cu_of[dev] == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
-            return MN_ERR_HIP;
-        if (hipMalloc(reinterpret_cast<void **>(&packed_of[dev]), OFF_FB * sizeof(float)) != hipSuccess) return MN_ERR_ALLOC;
-        n_cu_of[dev] = prop.multiProcessorCount;
-    }
-    const int n_cu = n_cu_of[dev];
-    float *packed = packed_of[dev];
-    IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
-                    weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MN_ERR_INVALID;   // context lives on another device
+    const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
+                          weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
-    if (blocks > n_cu) blocks = n_cu;
+    if (blocks > c->n_cu) blocks = c->n_cu;
     hipStream_t s = (hipStream_t)stream;
-    const bool prof = g_prof_n < g_prof_max;
-    if (prof) (void)hipEventRecord(g_ev[2 * g_prof_n], s);
+    const bool prof = c->prof_n < c->prof_max;
+    if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
+    const int pack_blocks = c->dirty ? PACK_BLOCKS : 0;
     if (rng_state_dev) {
         long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
         int rng_blocks = (int)((groups + 255) / 256);
-        if (rng_blocks > 8 * n_cu) rng_blocks = 8 * n_cu;
-        hipLaunchKernelGGL(iqn_prep_kernel, dim3(PACK_BLOCKS + rng_blocks), dim3(256), 0, s, w, packed,
-                           (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar);
+        if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
+        hipLaunchKernelGGL(iqn_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, c->packed,
+                           (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
         taus_dev = draws_dev;
         explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
-    } else {
-        hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, packed);
+    } else if (pack_blocks) {
+        hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, c->packed);
     }
-    hipLaunchKernelGGL(iqn_qvals_kernel, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev, packed,
-                       qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
-    if (prof) { (void)hipEventRecord(g_ev[2 * g_prof_n + 1], s); ++g_prof_n; }
+    c->dirty = false;
+    if (quantiles_dev)
+        hipLaunchKernelGGL(iqn_qvals_kernel<true>, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                           c->packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev);
+    else
+        hipLaunchKernelGGL(iqn_qvals_kernel<false>, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                           c->packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
+    if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 
-extern "C" int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
-                          const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus,
-                          void *stream) {
-    return launch_act(obs_dev, taus_dev, weights, qvals_dev, explore_u_dev, eps, actions_dev, n, num_taus, nullptr, nullptr,
-                      nullptr, 1.0f, stream);
+extern "C" int mn_iqn_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights,
+                          float *qvals_dev, const float *explore_u_dev, float eps, int32_t *actions_dev,
+                          float *quantiles_dev, int32_t n, int32_t num_taus, void *stream) {
+    return launch_act(c, obs_dev, taus_dev, weights, qvals_dev, explore_u_dev, eps, actions_dev, quantiles_dev, n, num_taus,
+                      nullptr, nullptr, nullptr, 1.0f, stream);
 }
 
-extern "C" int mn_iqn_act_rng(const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev, float *draws_dev,
-                              const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev, float *qvals_dev,
-                              int32_t n, int32_t num_taus, void *stream) {
+extern "C" int mn_iqn_act_rng(mn_iqn_ctx *c, const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev,
+                              float *draws_dev, const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev,
+                              float *qvals_dev, float *quantiles_dev, int32_t n, int32_t num_taus, void *stream) {
     if (!rng_state_dev) return MN_ERR_INVALID;
-    return launch_act(obs_dev, nullptr, weights, qvals_dev, nullptr, eps, actions_dev, n, num_taus, rng_state_dev, draws_dev,
-                      cvar_row_dev, cvar, stream);
+    return launch_act(c, obs_dev, nullptr, weights, qvals_dev, nullptr, eps, actions_dev, quantiles_dev, n, num_taus,
+                      rng_state_dev, draws_dev, cvar_row_dev, cvar, stream);
 }

@@ -34,6 +34,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "marinenav_hip.h"
 
 namespace {
@@ -219,13 +221,14 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
     if (tid < 2 * ROWS) S[S_TAU + tid] = (tid < ROWS ? taus_t : taus_l)[b0 * NQ + (tid & (ROWS - 1))];
     __syncthreads();
 
-    // ---- waves 0-3: local network on states; waves 4-7: target network on next_states (agent.py:279-286)
-    if (tid < 256) {
-        const PassBufs L = {S + S_C, S + S_H1, S + S_X, S + S_H2, S + S_H3, S + S_FEAT, S + S_Q};
-        forward_pass(L, PL, S + S_OBS, S + S_TAU + ROWS);
-    } else {
-        const PassBufs T = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
-        forward_pass(T, PT, S + S_OBS + BE * 28, S + S_TAU);
+    // ---- waves 0-3: local network on states; waves 4-7: target network on next_states (agent.py:279-286).
+    // ONE call from uniform control flow -- the half a thread belongs to only selects its buffers / parameters / inputs,
+    // so all 512 threads reach the same five barrier sites inside forward_pass.
+    {
+        const bool tgt = tid >= 256;
+        const PassBufs B = {S + (tgt ? T_C : S_C), tgt ? nullptr : S + S_H1, S + (tgt ? T_X : S_X), S + (tgt ? T_H2 : S_H2),
+                            S + (tgt ? T_H3 : S_H3), S + (tgt ? T_FEAT : S_FEAT), S + (tgt ? T_Q : S_Q)};
+        forward_pass(B, tgt ? PT : PL, S + S_OBS + (tgt ? BE * 28 : 0), S + S_TAU + (tgt ? 0 : ROWS));
     }
     // TD targets: r + gamma * max_a Q_target(next, tau_j) * (1 - done)   (agent.py:281-283)
     if (tid < ROWS) {
@@ -520,14 +523,18 @@ extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_nex
         !taus_local_dev || !params_local || !params_target || !workspace || !grad_out || !loss_out)
         return MN_ERR_INVALID;
     if (batch <= 0 || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
-            return MN_ERR_HIP;
-        attr_set[dev] = true;
+    {   // raise the dynamic-LDS limit once per device; guarded so that concurrent first calls from two threads are safe
+        static std::mutex mu;
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    LDS_BYTES) != hipSuccess)
+                return MN_ERR_HIP;
+            attr_set[dev] = true;
+        }
     }
     const int n_part = batch / BE;
     float *partial = workspace, *loss_partial = workspace + (size_t)n_part * P_TOTAL;

@@ -80,6 +80,7 @@ extern "C" int mn_default_params(mn_params *p) {
 
 // Host-side constants, evaluated in the reference's (python) expression order.
 static int derive(mn_handle *h, const mn_params &p) {
+    const int32_t keep_skip = h->P.debug_skip;   // only ever non-zero in -DMN_ABLATION builds (mn_set_debug_skip)
     if (p.num_beams != MN_NUM_BEAMS) return fail(h, MN_ERR_INVALID, "num_beams must be 11");
     if (p.num_cores < 0 || p.num_cores > MN_MAX_CORES) return fail(h, MN_ERR_INVALID, "num_cores out of [0, 8]");
     if (p.num_obs < 0 || p.num_obs > MN_MAX_OBS) return fail(h, MN_ERR_INVALID, "num_obs out of [0, 10]");
@@ -123,7 +124,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     d.random_reset_state = p.random_reset_state; d.set_boundary = p.set_boundary;
     d.max_episode_steps = p.max_episode_steps; d.N = p.N;
     d.n_stages = keep_n;
-    { const char *dbg = getenv("MN_DEBUG_SKIP"); d.debug_skip = dbg ? atoi(dbg) : 0; }
+    d.debug_skip = keep_skip;
     h->params = p;
     return MN_OK;
 }
@@ -281,21 +282,55 @@ extern "C" int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, v
     return MN_OK;
 }
 
-extern "C" int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
-                       uint8_t *info_dev, void *stream) {
+static int step_common(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                       uint8_t *info_dev, const MnRing *ring, void *stream) {
     if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return MN_ERR_INVALID;
     MN_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int parity = h->step_parity;
     const bool prof = h->prof_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev[2 * h->prof_n], s);
-    mn_launch_step(h->A, h->P, h->params.precision, h->params.step_lanes, actions_dev, obs_dev, reward_dev, done_dev, info_dev, parity, s);
+    mn_launch_step(h->A, h->P, h->params.precision, h->params.step_lanes, actions_dev, obs_dev, reward_dev, done_dev, info_dev, parity, ring, s);
     if (prof) { (void)hipEventRecord(h->ev[2 * h->prof_n + 1], s); h->prof_n++; }
     MN_HIP(h, hipGetLastError());
     h->last_parity = parity;
     h->step_parity = parity ^ 1;
     return MN_OK;
 }
+
+extern "C" int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+                       uint8_t *info_dev, void *stream) {
+    return step_common(h, actions_dev, obs_dev, reward_dev, done_dev, info_dev, nullptr, stream);
+}
+
+extern "C" int mn_step_append(mn_handle *h, const int32_t *actions_dev, const float *prev_obs_dev, float *obs_dev,
+                              float *reward_dev, uint8_t *done_dev, uint8_t *info_dev, float *ring_states,
+                              float *ring_next_states, int64_t *ring_actions, float *ring_rewards, float *ring_dones,
+                              int64_t ptr, int64_t capacity, void *stream) {
+    if (!h || !prev_obs_dev || !ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones)
+        return MN_ERR_INVALID;
+    if (prev_obs_dev == obs_dev) return fail(h, MN_ERR_INVALID, "mn_step_append: obs_t and obs_t+1 must be different buffers");
+    if (capacity <= 0 || ptr < 0 || ptr >= capacity) return fail(h, MN_ERR_INVALID, "mn_step_append: ptr out of [0, capacity)");
+    const MnRing R = {prev_obs_dev, ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, ptr, capacity};
+    return step_common(h, actions_dev, obs_dev, reward_dev, done_dev, info_dev, &R, stream);
+}
+
+extern "C" int32_t mn_build_info(void) {
+#ifdef MN_ABLATION
+    return MN_BUILD_ABLATION;
+#else
+    return 0;
+#endif
+}
+
+#ifdef MN_ABLATION
+// Developer builds only (libmarinenav_hip_ablation.so): removes parts of the step kernel to attribute its time.
+extern "C" int mn_set_debug_skip(mn_handle *h, int32_t mask) {
+    if (!h) return MN_ERR_INVALID;
+    h->P.debug_skip = mask;
+    return MN_OK;
+}
+#endif
 
 extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return MN_ERR_INVALID;
@@ -477,6 +512,30 @@ extern "C" int mn_get_reward64(mn_handle *h, int32_t first, int32_t count, doubl
     if (!h->A.rew64) return fail(h, MN_ERR_INVALID, "float64 rewards are kept only with MN_PRECISION_F64");
     MN_HIP(h, hipDeviceSynchronize());
     MN_HIP(h, hipMemcpy(out, h->A.rew64 + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return MN_OK;
+}
+
+extern "C" int mn_enable_trajectory(mn_handle *h, int32_t max_substeps) {
+    if (!h || max_substeps < 1 || max_substeps > 1000) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
+    if (h->params.precision != MN_PRECISION_F64) return fail(h, MN_ERR_INVALID, "sub-step trajectories are recorded only with MN_PRECISION_F64");
+    if (h->A.traj && h->A.traj_n >= max_substeps) return MN_OK;
+    MN_HIP(h, hipDeviceSynchronize());
+    int rc = dev_alloc(h, &h->A.traj, (size_t)h->A.npad * max_substeps * 2);   // an earlier, smaller buffer stays owned by the handle
+    if (rc) return rc;
+    h->A.traj_n = max_substeps;
+    return MN_OK;
+}
+
+extern "C" int mn_get_trajectory(mn_handle *h, int32_t first, int32_t count, int32_t n_substeps, double *out) {
+    int rc = range_ok(h, first, count);
+    if (rc) return rc;
+    if (count == 0) return MN_OK;
+    if (!out || n_substeps < 1) return MN_ERR_INVALID;
+    if (!h->A.traj || n_substeps > h->A.traj_n) return fail(h, MN_ERR_INVALID, "call mn_enable_trajectory(h, >= n_substeps) before stepping");
+    MN_HIP(h, hipDeviceSynchronize());
+    MN_HIP(h, hipMemcpy2D(out, (size_t)n_substeps * 16, h->A.traj + (size_t)first * h->A.traj_n * 2, (size_t)h->A.traj_n * 16,
+                          (size_t)n_substeps * 16, count, hipMemcpyDeviceToHost));
     return MN_OK;
 }
 

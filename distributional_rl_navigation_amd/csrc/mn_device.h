@@ -45,15 +45,28 @@ __device__ __forceinline__ void mn_beam_geom(double mrx, double mry, double r2, 
 template <typename M>
 struct MnBeam {
     M dist, limit;
-    __device__ __forceinline__ void init() { dist = M(0); limit = (M)INFINITY; }
+    double atc, ah2;   // float64 geometry (t_c, h^2) of the ACCEPTED candidate: lets the caller re-derive the accepted
+                       // range in float64 after a float32 scan has made the discrete choices (dead code when unused)
+    __device__ __forceinline__ void init() { dist = M(0); limit = (M)INFINITY; atc = 0.0; ah2 = 0.0; }
     __device__ __forceinline__ bool hit() const { return limit != (M)INFINITY; }
-    __device__ __forceinline__ void update(M tc, M h2, M range) {
+    __device__ __forceinline__ void update(double tc64, double h264, M range) {
+        const M tc = (M)tc64, h2 = (M)h264;
         const M h = MnMath<M>::sqrt_(h2);
         const M t = tc > M(0) ? tc - h : tc + h;
         const bool in_range = (t >= M(0)) && (t <= range);
         const bool acc = in_range && (t < limit);
         dist = acc ? t : dist;
+        atc = acc ? tc64 : atc;
+        ah2 = acc ? h264 : ah2;
         limit = in_range ? (acc ? t : -(M)INFINITY) : limit;
+    }
+    // Accepted range re-derived in float64 from the accepted candidate's float64 geometry: sqrt(h^2) by one Newton step
+    // on the float32 root (relative error ~1e-14), same root choice as update() (robot.py:184).
+    __device__ __forceinline__ double dist64() const {
+        const float h0f = __builtin_amdgcn_sqrtf((float)ah2);
+        double h = (double)h0f;
+        if (h0f > 0.f) h += (ah2 - h * h) * (0.5 * (double)__builtin_amdgcn_rcpf(h0f));
+        return (M)atc > M(0) ? atc - h : atc + h;
     }
 };
 

@@ -37,6 +37,10 @@ struct MnArrays {
     // float64 copy of the observations (parity precision only), [npad][26]
     double *obs64;
     double *rew64;  // float64 copy of the last reward (parity precision only), [npad]
+    // per-sub-step positions of the last step, [npad][traj_n][2] (parity precision only, allocated by
+    // mn_enable_trajectory): what marinenav_env.py:211-212 appends to robot.trajectory
+    double *traj;
+    int32_t traj_n;
     // done-queue filled by the step kernel, drained by the reset kernel
     uint32_t *queue_count;  // [2], alternating per step
     int32_t *queue;         // [npad]
@@ -65,15 +69,26 @@ struct MnDev {
     double timestep_scale;
     int32_t num_cores, num_obs, reset_start_and_goal, random_reset_state, set_boundary, max_episode_steps, N;
     int32_t n_stages;
-    int32_t debug_skip;  // developer ablation hook (env MN_DEBUG_SKIP): 1 = sub-steps, 2 = sonar, 4 = obstacle rotation
+    int32_t debug_skip;  // read ONLY by -DMN_ABLATION builds (mn_set_debug_skip): 1 = sub-steps, 2 = sonar scan, 4 = sincos, 8 = obstacle rotation, 16 = beam stores
     int64_t sched_t[MN_MAX_STAGES];
     int32_t sched_nc[MN_MAX_STAGES], sched_no[MN_MAX_STAGES];
     double sched_md[MN_MAX_STAGES];
 };
 
+// Replay ring the step kernel appends the transition (obs_t, a_t, r_t, obs_t+1, done_t) to (mn_step_append): the
+// layout ReplayBuffer.sample hands to the learner (thirdparty/IQN/replay_buffer.py:49-57).  Env e goes to slot
+// (ptr + e - first) mod cap for e >= first = max(0, n - cap) (deque(maxlen) keeps only the newest cap rows).
+struct MnRing {
+    const float *prev_obs;   // [n][26] observations the actions were chosen from (obs_t)
+    float *states, *next_states;   // [cap][26]
+    int64_t *actions;        // [cap]
+    float *rewards, *dones;  // [cap]
+    int64_t ptr, cap;
+};
+
 // kernels (defined in mn_step.hip / mn_reset.hip)
 void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, int lanes, const int32_t *actions, float *obs,
-                    float *reward, uint8_t *done, uint8_t *info, int parity, hipStream_t s);
+                    float *reward, uint8_t *done, uint8_t *info, int parity, const MnRing *ring, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
                      const int32_t *list_dev, int mode, float *obs, hipStream_t s);

@@ -23,6 +23,14 @@
 //     transpose to 16-byte coalesced rows was measured: its two barriers cost more than it saves).
 #include "mn_device.h"
 
+// Developer ablation (profiling only): compiled in ONLY with -DMN_ABLATION, into libmarinenav_hip_ablation.so
+// (make ablation).  The shipped library has no switch that removes work from the kernel.
+#ifdef MN_ABLATION
+#define MN_SKIP(bit) ((P.debug_skip & (bit)) != 0)
+#else
+#define MN_SKIP(bit) false
+#endif
+
 #ifndef MN_STEP_BLOCK
 #define MN_STEP_BLOCK 64    // threads per workgroup (npad is a multiple of 256, so 64 / 128 / 256 all tile it); measured: same at 65 536 envs, 64 is 4 % faster at 1 M
 #endif
@@ -56,11 +64,11 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
-template <typename M, bool PARITY, int L>
+template <typename M, bool PARITY, int L, bool APPEND>
 __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, MnDev P, const int32_t *__restrict__ actions,
                                                       float *__restrict__ obs_out, float *__restrict__ reward_out,
                                                       uint8_t *__restrict__ done_out, uint8_t *__restrict__ info_out,
-                                                      int parity) {
+                                                      int parity, MnRing R) {
     constexpr int CPL = MN_MAX_CORES / L;            // vortex cores per lane
     constexpr int BPL = (MN_NUM_BEAMS + L - 1) / L;  // sonar beams per lane
     static_assert(MN_MAX_CORES % L == 0, "L must divide 8");
@@ -79,6 +87,20 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     const int ep_t = A.ep_t[e];
     int action = active ? actions[e] : 0;
     action = action < 0 ? 0 : (action > 8 ? 8 : action);
+
+    // Fused replay append (mn_step_append): this lane's share of the obs_t row -- the same float2 columns it will
+    // write of obs_t+1 -- is loaded here with everything else, so the transition leaves in this launch instead of a
+    // separate append kernel that re-reads both observation tiles.
+    float2 prev_head[2], prev_beam[BPL];
+    if constexpr (APPEND) {
+        const float2 *prow = reinterpret_cast<const float2 *>(R.prev_obs + (size_t)(active ? e : 0) * MN_OBS_DIM);
+        prev_head[0] = prow[0]; prev_head[1] = prow[1];
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const int b = q + L * j;
+            prev_beam[j] = prow[2 + (b < MN_NUM_BEAMS ? b : MN_NUM_BEAMS - 1)];
+        }
+    }
 
     // World tables: every load below is UNCONDITIONAL (rows beyond the placed count hold zeros), so
     // all ~70 loads of a lane are in flight together and the kernel pays one memory latency, not a
@@ -155,11 +177,11 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     while (theta < 0.0) theta += two_pi;
     while (theta >= two_pi) theta -= two_pi;
     double sn = 0.0, cs = 1.0;
-    if (!(P.debug_skip & 4)) sincos(theta, &sn, &cs);
+    if (!MN_SKIP(4)) sincos(theta, &sn, &cs);
 
     // ---- N kinematic sub-steps (marinenav_env.py:208-212) -------------------------------------
     M velx = 0, vely = 0;
-    const int nsub = (P.debug_skip & 1) ? 0 : P.N;
+    const int nsub = MN_SKIP(1) ? 0 : P.N;
     if constexpr (!PARITY && CPL >= 2) {
         // Mixed precision: the core positions RELATIVE to the robot are formed once in float64, then
         // tracked in float32 (d -= v*dt): the rounding of a relative position is relative to the
@@ -222,6 +244,12 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
             vely = (M)(speed * sn) + cvy;
             x += (double)velx * dt;
             y += (double)vely * dt;
+            if constexpr (PARITY) {   // marinenav_env.py:211-212: robot.trajectory gets one point per sub-step
+                if (A.traj && q == 0 && active && s < A.traj_n) {
+                    A.traj[((size_t)e * A.traj_n + s) * 2] = x;
+                    A.traj[((size_t)e * A.traj_n + s) * 2 + 1] = y;
+                }
+            }
             // robot.py:113-114: drag + clip
             speed += (acc - P.k_drag * speed) * dt;
             speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     int nrel = 0;
     double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
     const double reach0 = P.sonar_range + 0.05;
-    if (!(P.debug_skip & 8))
+    if (!MN_SKIP(8))
 #pragma unroll
     for (int k = 0; k < MN_MAX_OBS; ++k) {
         const double mx = obx[k] - x, my = oby[k] - y;
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
         }
         beam[j].init();
     }
-    if (!(P.debug_skip & 2))
+    if (!MN_SKIP(2))
     for (int s_ = 0; __any(s_ < nrel); ++s_) {
         const bool v = s_ < nrel;
         const double ox_ = lst_x[s_][tl], oy_ = lst_y[s_][tl];
@@ -301,14 +329,18 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
         for (int j = 0; j < BPL; ++j) {
             double tc, h2;
             mn_beam_geom(ox_, oy_, r2o, bdx[j], bdy[j], tc, h2);
-            beam[j].update((M)tc, (M)h2, range);
+            beam[j].update(tc, h2, range);
         }
     }
 #pragma unroll
     for (int j = 0; j < BPL; ++j) {
         const bool hit = beam[j].hit();
-        bxo[j] = hit ? beam[j].dist * (M)bdx[j] : M(0);  // misses are (0,0): marinenav_env.py:315-316
-        byo[j] = hit ? beam[j].dist * (M)bdy[j] : M(0);
+        // Mixed precision: the float32 scan above made the discrete choices (which obstacle, hit / miss, `break`); the
+        // accepted range itself is re-derived in float64 from that candidate's float64 geometry, so the returned point
+        // is as accurate as the pose it was cast from (north-star: 1e-5 absolute on float32 outputs).
+        const double td = PARITY ? (double)beam[j].dist : beam[j].dist64();
+        bxo[j] = hit ? (M)(td * bdx[j]) : M(0);  // misses are (0,0): marinenav_env.py:315-316
+        byo[j] = hit ? (M)(td * bdy[j]) : M(0);
     }
 
     // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
@@ -328,6 +360,14 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     if (active) {
         float *orow = obs_out + (size_t)e * MN_OBS_DIM;
         double *orow64 = PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr;
+        // replay slot of this env's transition (FIFO ring; only the newest `cap` rows of a launch survive)
+        int64_t slot = -1;
+        if constexpr (APPEND) {
+            const int64_t first = (int64_t)A.n > R.cap ? (int64_t)A.n - R.cap : 0;
+            if (e >= first) { slot = R.ptr + (e - first); slot = slot >= R.cap ? slot - R.cap : slot; }
+        }
+        float2 *rs = APPEND && slot >= 0 ? reinterpret_cast<float2 *>(R.states + slot * MN_OBS_DIM) : nullptr;
+        float2 *rn = APPEND && slot >= 0 ? reinterpret_cast<float2 *>(R.next_states + slot * MN_OBS_DIM) : nullptr;
         if (q == 0) {
             A.x[e] = x; A.y[e] = y; A.theta[e] = theta; A.speed[e] = speed;
             A.vx[e] = (double)velx; A.vy[e] = (double)vely;
@@ -342,17 +382,29 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
             const M o2 = (M)(cs * dax + sn * day), o3 = (M)(-sn * dax + cs * day);
             *reinterpret_cast<float2 *>(orow) = make_float2((float)o0, (float)o1);
             *reinterpret_cast<float2 *>(orow + 2) = make_float2((float)o2, (float)o3);
+            if constexpr (APPEND) {
+                if (rs) {
+                    rs[0] = prev_head[0]; rs[1] = prev_head[1];
+                    rn[0] = make_float2((float)o0, (float)o1); rn[1] = make_float2((float)o2, (float)o3);
+                    R.actions[slot] = (int64_t)actions[e];      // as chosen (replay_buffer.py:50 stores the agent's action)
+                    R.rewards[slot] = (float)reward;
+                    R.dones[slot] = done ? 1.0f : 0.0f;
+                }
+            }
             if (PARITY) {
                 A.rew64[e] = reward;
                 orow64[0] = (double)o0; orow64[1] = (double)o1; orow64[2] = (double)o2; orow64[3] = (double)o3;
             }
         }
-        if (!(P.debug_skip & 16))
+        if (!MN_SKIP(16))
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
             const int b = q + L * j;
             if (b < MN_NUM_BEAMS) {
                 *reinterpret_cast<float2 *>(orow + 4 + 2 * b) = make_float2((float)bxo[j], (float)byo[j]);
+                if constexpr (APPEND) {
+                    if (rs) { rs[2 + b] = prev_beam[j]; rn[2 + b] = make_float2((float)bxo[j], (float)byo[j]); }
+                }
                 if (PARITY) { orow64[4 + 2 * b] = (double)bxo[j]; orow64[5 + 2 * b] = (double)byo[j]; }
             }
         }
@@ -372,13 +424,13 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     }
 }
 
-template <typename M, bool PARITY>
+template <typename M, bool PARITY, bool APPEND>
 void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actions, float *obs, float *reward,
-              uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
+              uint8_t *done, uint8_t *info, int parity, const MnRing &R, hipStream_t s) {
     const dim3 block(MN_STEP_BLOCK);
 #define MN_LAUNCH(LL)                                                                                              \
-    hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / MN_STEP_BLOCK)), block, 0, s, A, P, \
-                       actions, obs, reward, done, info, parity)
+    hipLaunchKernelGGL((mn_step_kernel<M, PARITY, LL, APPEND>), dim3((unsigned)((size_t)A.npad * LL / MN_STEP_BLOCK)), block, 0, s, A, P, \
+                       actions, obs, reward, done, info, parity, R)
     // Default (lanes == 0), measured on MI355X: up to ~128 K envs the launch is latency-bound and two lanes per env
     // win (19.6 vs 20.5 us at 65 536); beyond that several rounds of waves hide latency by themselves and the
     // mapping with the least total work wins (1 M envs: 121 us at L = 1 -> 44 % of the HBM roofline, 165 us at L = 2).
@@ -395,9 +447,13 @@ void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actio
 }  // namespace
 
 void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, int lanes, const int32_t *actions, float *obs,
-                    float *reward, uint8_t *done, uint8_t *info, int parity, hipStream_t s) {
-    if (precision == MN_PRECISION_F64)
-        launch_l<double, true>(lanes, A, P, actions, obs, reward, done, info, parity, s);
-    else
-        launch_l<float, false>(lanes, A, P, actions, obs, reward, done, info, parity, s);
+                    float *reward, uint8_t *done, uint8_t *info, int parity, const MnRing *ring, hipStream_t s) {
+    static const MnRing none = {};
+    if (precision == MN_PRECISION_F64) {
+        if (ring) launch_l<double, true, true>(lanes, A, P, actions, obs, reward, done, info, parity, *ring, s);
+        else launch_l<double, true, false>(lanes, A, P, actions, obs, reward, done, info, parity, none, s);
+    } else {
+        if (ring) launch_l<float, false, true>(lanes, A, P, actions, obs, reward, done, info, parity, *ring, s);
+        else launch_l<float, false, false>(lanes, A, P, actions, obs, reward, done, info, parity, none, s);
+    }
 }

@@ -37,12 +37,45 @@ def generate_worlds(num, n_obs, n_cores, seed=15, device="cuda:0"):
     return worlds
 
 
+def _episode_record(world, params, name, actions, traj, cvars=None, quantiles=None, taus=None, seed=15):
+    """One `ep_data` entry of the reference's exp_data JSON: MarineNavEnv.episode_data() (marinenav_env.py:557-622) of
+    the finished episode plus, for the IQN policies, robot.actions_cvars / actions_quantiles / actions_taus
+    (run_experiments.py:62-69)."""
+    p = params
+    ep = {"env": {}, "robot": {}}
+    e = ep["env"]
+    e["seed"] = seed
+    e["width"], e["height"], e["r"], e["v_rel_max"], e["p"] = p.width, p.height, p.core_r, p.v_rel_max, p.p
+    e["v_range"] = [p.v_range[0], p.v_range[1]]; e["obs_r_range"] = [p.obs_r_range[0], p.obs_r_range[1]]
+    e["clear_r"] = p.clear_r
+    e["start"] = [float(v) for v in world["start"]]; e["goal"] = [float(v) for v in world["goal"]]
+    e["goal_dis"], e["timestep_penalty"], e["collision_penalty"] = p.goal_dis, p.timestep_penalty, p.collision_penalty
+    e["goal_reward"], e["discount"] = p.goal_reward, p.discount
+    c, o = world["cores"], world["obstacles"]
+    e["cores"] = {"positions": [[float(r[0]), float(r[1])] for r in c], "clockwise": [int(r[2]) for r in c],
+                  "Gamma": [float(r[3]) for r in c]}
+    e["obstacles"] = {"positions": [[float(r[0]), float(r[1])] for r in o], "r": [float(r[2]) for r in o]}
+    ep["robot"] = {"dt": p.dt, "N": p.N, "length": 1.0, "width": 0.5, "r": p.robot_r, "max_speed": p.max_speed,
+                   "a": [p.a[0], p.a[1], p.a[2]], "w": [p.w[0], p.w[1], p.w[2]],
+                   "init_theta": float(world["init_theta"]), "init_speed": float(world["init_speed"]),
+                   "sonar": {"range": p.sonar_range, "angle": p.sonar_angle, "num_beams": p.num_beams},
+                   "action_history": [int(a) for a in actions], "trajectory": [[float(q[0]), float(q[1])] for q in traj]}
+    if cvars is not None:
+        ep["robot"]["actions_cvars"] = [float(v) for v in cvars]
+        ep["robot"]["actions_quantiles"] = [q.tolist() for q in quantiles]       # each [1][32][9], as act_eval returns
+        ep["robot"]["actions_taus"] = [t.tolist() for t in taus]                 # each [1][32][1]
+    return ep
+
+
 @torch.no_grad()
-def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000, dqn=None):
+def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000, dqn=None,
+                   capture=False):
     """run_experiments.py:213-282 for the IQN policies, the classical APF / BA baselines and (when `dqn`, a
     `dqn.DQNPolicy`, is given and "DQN" is in `policies`) the greedy DQN baseline.  Returns {policy: dict(success, time, energy,
-    out_of_area, reward, actions)} with one entry per world (the reference's exp_data schema minus the
-    per-step quantile dumps and wall-clock timings)."""
+    out_of_area, reward, actions)} with one entry per world.  With `capture` each policy also gets the reference's `ep_data`
+    list (run_experiments.py:26-69,262-282): per episode the episode_data() dict incl. the sub-step trajectory, and for the
+    IQN policies the per-action CVaR level, quantile values [1,32,9] and taus [1,32,1] of IQNAgent.act_eval -- the whole
+    `exp_data` JSON the reference dumps, minus wall-clock `computation_times` (batched: meaningless per env)."""
     worlds = generate_worlds(num, n_obs, n_cores, seed, device)
     n = num * len(policies)
     env = VecMarineNavEnv(n, device=device, precision="f64")
@@ -73,6 +106,9 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     length = torch.zeros(n, dtype=torch.int64, device=dev)
     last_info = torch.zeros(n, dtype=torch.uint8, device=dev)
     acts = torch.full((max_steps, n), -1, dtype=torch.int32, device=dev)
+    cap_cv, cap_q, cap_t, cap_traj = [], [], [], []
+    if capture:
+        env.enable_trajectory()
     if agent is not None:
         agent.qnetwork_local.eval()
     for t in range(max_steps):
@@ -80,7 +116,12 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
         if iqn_idx.numel():
             o = obs[iqn_idx]
             cv = torch.where(adaptive[iqn_idx], agent.adjust_cvar_batch(o), fixed[iqn_idx])   # agent.py:249-267 per row
-            a[iqn_idx] = agent.act_batch(o, 0.0, cv)
+            if capture:      # act_eval / act_adaptive_eval (agent.py:217-247): the action AND what it was chosen from
+                a_iqn, quant, taus = agent.act_eval_batch(o.contiguous(), 0.0, cv)
+                a[iqn_idx] = a_iqn
+                cap_cv.append(cv.cpu().numpy()); cap_q.append(quant.cpu().numpy()); cap_t.append(taus.cpu().numpy())
+            else:
+                a[iqn_idx] = agent.act_batch(o, 0.0, cv)
         for name, rows in classical.items():                                 # APF.py:17-78 / BA.py:14-72
             if name == "DQN":                                                # run_experiments.py:86 (greedy predict)
                 a[rows] = dqn.act_batch(obs[rows])
@@ -88,6 +129,8 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
             fn = apf_act_batch if name == "APF" else ba_act_batch
             a[rows] = fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32)
         obs, reward, done, info = env.step(a)
+        if capture:
+            cap_traj.append(env.get_trajectory())
         ret += torch.where(alive, (env.discount ** t) * reward.double(), torch.zeros_like(ret))
         length += alive.long()
         energy += torch.where(alive, energy_tab[a.long()].double(), torch.zeros_like(energy))
@@ -108,5 +151,20 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
                          time=[float(dtN * l) for l in length_h[sl]], energy=[float(v) for v in energy_h[sl]],
                          reward=[float(v) for v in ret_h[sl]],
                          actions=[[int(x) for x in acts_h[:length_h[i], i]] for i in range(p * num, (p + 1) * num)])
+        if capture:
+            iqn_pos = {int(g_): k for k, g_ in enumerate(iqn_idx.cpu().numpy())}     # env row -> row of the IQN captures
+            eps_ = []
+            for i in range(p * num, (p + 1) * num):
+                L = int(length_h[i])
+                traj = [q for t_ in range(L) for q in cap_traj[t_][i]]
+                if i in iqn_pos:
+                    k = iqn_pos[i]
+                    eps_.append(_episode_record(worlds[i - p * num], env.params, name, acts_h[:L, i], traj,
+                                                cvars=[cap_cv[t_][k] for t_ in range(L)],
+                                                quantiles=[cap_q[t_][k:k + 1] for t_ in range(L)],
+                                                taus=[cap_t[t_][k:k + 1] for t_ in range(L)], seed=seed))
+                else:
+                    eps_.append(_episode_record(worlds[i - p * num], env.params, name, acts_h[:L, i], traj, seed=seed))
+            out[name]["ep_data"] = eps_
     env.close()
     return out, worlds

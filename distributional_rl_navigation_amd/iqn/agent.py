@@ -26,7 +26,7 @@ class IQNAgent:
     def __init__(self, state_size, action_size, layer_size=64, n_step=1, BATCH_SIZE=32, BUFFER_SIZE=1_000_000,
                  LR=1e-4, TAU=1.0, GAMMA=0.99, UPDATE_EVERY=4, learning_starts=10000, target_update_interval=10000,
                  exploration_fraction=0.1, initial_eps=1.0, final_eps=0.05, device="cpu", seed=0,
-                 distributed=False, act_chunk=8192):
+                 distributed=False, act_chunk=8192, rank=0):
         self.state_size = state_size
         self.action_size = action_size
         self.device = torch.device(device)
@@ -39,6 +39,8 @@ class IQNAgent:
         self.exploration_fraction = exploration_fraction
         self.initial_eps, self.final_eps = initial_eps, final_eps
         self.N = 8                                   # train-time quantile samples (agent.py:286,290)
+        self.rank = int(rank)                        # shared learner: same `seed` (identical init) on every rank, but
+                                                     # rank-specific exploration / tau / replay-sampling streams
         self.act_chunk = act_chunk
         self.grad_steps_per_update = 1               # vectorised loop only: grad steps per training event
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
@@ -57,7 +59,13 @@ class IQNAgent:
         self.memory = ReplayBuffer(BUFFER_SIZE, BATCH_SIZE, device, seed, GAMMA, n_step, state_size)
         random.seed(seed)                            # replay_buffer.py:21 seeds python `random` (eps-greedy)
         self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(int(seed) + 12345)
+        self.gen.manual_seed(int(seed) + 12345 + 7919 * self.rank)
+        if self.rank:
+            self.memory.gen.manual_seed(int(seed) + 104729 * self.rank)
+        self.target_sync_grad_steps = None           # vectorised loop: hard target copy every this many grad steps
+                                                     # (None: every target_update_interval vector steps, see vec_step)
+        self._last_sync_at = 0
+        self._train_path = None                      # "hip" / "torch": which gradient step ran last (Adam step-count hand-over)
 
         self.current_timestep = 0
         self.learning_timestep = 0
@@ -85,6 +93,7 @@ class IQNAgent:
         self.qnetwork_target = ObsEncoder.load(path, device)
         self.device = torch.device(device)
         self.optimizer = self._make_adam()
+        self._train_path = None
 
     # ---- schedules -----------------------------------------------------------------------------
     def linear_eps(self, total_timesteps):
@@ -150,6 +159,28 @@ class IQNAgent:
     def act_adaptive_eval(self, state, eps=0.0):
         cvar = self.adjust_cvar(state)
         return self.act_eval(state, eps, cvar), cvar
+
+    @torch.no_grad()
+    def act_eval_batch(self, states, eps=0.0, cvar=1.0, taus=None):
+        """Batched act_eval (agent.py:217-236): states [n,26] on the device -> (actions [n] i32, quantiles [n,32,9],
+        taus [n,32,1]) -- the per-action return distribution samples and the (cvar-scaled) quantile fractions they
+        were evaluated at, as run_experiments.py:26-69 records them.  `cvar` is a float or a per-row tensor."""
+        if states.is_cuda and self.use_fused_act:
+            from .fused_act import fused_act, ActRng
+            if taus is None and self.use_library_rng:
+                if self._act_rng is None:
+                    self._act_rng = ActRng(self.gen.initial_seed(), states.device)
+                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, want_quantiles=True)
+            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, taus=taus, generator=self.gen,
+                             want_quantiles=True)
+        quantiles, t = self.qnetwork_local.forward(states, self.qnetwork_local.K, cvar, taus=taus)
+        greedy = quantiles.mean(dim=1).argmax(dim=1).to(torch.int32)
+        if eps > 0.0:
+            n = states.shape[0]
+            u = torch.rand(n, device=states.device, generator=self.gen)
+            rnd = torch.randint(0, self.action_size, (n,), device=states.device, dtype=torch.int32, generator=self.gen)
+            greedy = torch.where(u > eps, greedy, rnd)
+        return greedy, quantiles, t
 
     @torch.no_grad()
     def qvals_batch(self, states, cvar=1.0, taus=None):
@@ -231,12 +262,26 @@ class IQNAgent:
             self._fused = FusedTrainer(self)
         return self._fused
 
+    def _enter_train_path(self, path):
+        """Both gradient-step paths update ONE Adam state (the moments are shared memory, iqn/fused_train.py); the step
+        count is handed over whenever the path changes, so flipping `use_fused_train` mid-run continues the same
+        optimizer instead of restarting its bias correction."""
+        if self._train_path == path:
+            return
+        if self._fused is not None and self._fused.owns(self):
+            if path == "torch" and self._train_path == "hip":
+                self._fused.sync_to_optimizer(self.optimizer)
+            elif path == "hip" and self._train_path == "torch":
+                self._fused.sync_from_optimizer(self.optimizer)
+        self._train_path = path
+
     def train_from_memory(self):
         """`self.train(self.memory.sample())` (agent.py:131-133).  With `use_fused_train` the HIP step gathers its batch
         straight from the device ring (no sampled copies)."""
         if self.use_fused_train and self.device.type == "cuda":
             m = self.memory
             ft = self._fused_trainer()
+            self._enter_train_path("hip")
             idx, taus = ft.sample(m.size, self.BATCH_SIZE)                   # replay_buffer.py:47 + model.py:149
             loss = ft.step((m.states, m.actions, m.rewards, m.next_states, m.dones), idx, taus[0], taus[1])
             self.grad_steps += 1
@@ -245,13 +290,18 @@ class IQNAgent:
 
     def train(self, experiences, taus_target=None, taus_local=None):
         """agent.py:269-304: one optimizer step; returns the loss (device scalar tensor).
-        On the GPU (single learner, taus not injected) the whole step -- forward, backward, clip, Adam,
-        ~100 tiny kernels -- is replayed from one captured hipGraph."""
+        GPU tensors with `use_fused_train` (the default on the GPU): the hand-written HIP step (csrc/iqn_train.hip:
+        both forwards, quantile-Huber loss, backward, clip, Adam in four launches).  Otherwise PyTorch autograd +
+        torch.optim.Adam -- the definition the HIP step is tested against and the only path on the CPU; with
+        `use_train_graph` (opt-in, single learner, taus not injected) replayed from one captured hipGraph."""
         if self.use_fused_train and experiences[0].is_cuda:
             exp = tuple(t.contiguous() for t in experiences)
-            loss = self._fused_trainer().step(exp, None, taus_target, taus_local)
+            ft = self._fused_trainer()
+            self._enter_train_path("hip")
+            loss = ft.step(exp, None, taus_target, taus_local)
             self.grad_steps += 1
             return loss
+        self._enter_train_path("torch")
         if (self.use_train_graph and experiences[0].is_cuda and not self.distributed
                 and taus_target is None and taus_local is None and experiences[0].shape[0] == self.BATCH_SIZE):
             return self._train_graphed(experiences)
@@ -321,6 +371,15 @@ class IQNAgent:
     def soft_update(self, local_model, target_model):
         """agent.py:307-317 (TAU = 1.0 -> hard copy)."""
         with torch.no_grad():
+            ft = self._fused
+            if (ft is not None and ft.owns(self) and local_model is self.qnetwork_local
+                    and target_model is self.qnetwork_target):
+                # both networks are views of two flat buffers (iqn/fused_train.py): one copy instead of 14
+                if self.TAU == 1.0:
+                    ft.target.copy_(ft.local)
+                else:
+                    ft.target.mul_(1.0 - self.TAU).add_(ft.local, alpha=self.TAU)
+                return
             for tp, lp in zip(target_model.parameters(), local_model.parameters()):
                 tp.data.copy_(self.TAU * lp.data + (1.0 - self.TAU) * tp.data)
 
@@ -391,7 +450,7 @@ class IQNAgent:
     # ---- batched loop on the HIP vector env ----------------------------------------------------------
     def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,
                   eval_log_path=None, total_timesteps=None, world_size=1, cvar=1.0, verbose=True,
-                  train_every=None, on_step=None):
+                  train_every=None, on_step=None, report_timestep_scale=1.0):
         """Vectorised agent.py:94-173.  One iteration = one vector step of `train_env` (n_envs env
         steps): act_batch -> mn_step -> replay.add_batch -> mn_reset_done -> (every UPDATE_EVERY vector
         steps) sample + train.  `current_timestep` counts env steps over all ranks, so eps, the
@@ -400,6 +459,9 @@ class IQNAgent:
         target_update_interval and eval_freq are applied to it)."""
         n = train_env.n_envs
         per_iter = n * world_size
+        # evaluation npz `timesteps` are reported as current_timestep * report_timestep_scale (train_iqn: reference-
+        # equivalent timesteps, so scripts/plot_eval_returns.py keeps its x axis)
+        self._report_scale = float(report_timestep_scale)
         if total_timesteps is None:
             total_timesteps = total_vector_steps * per_iter
         train_every = self.UPDATE_EVERY if train_every is None else train_every
@@ -440,19 +502,29 @@ class IQNAgent:
         train_every = self.UPDATE_EVERY if train_every is None else train_every
         per_iter = train_env.n_envs if per_iter is None else per_iter
         actions = self.act_batch(obs, eps, cvar)
-        next_obs, reward, done, info = train_env.step(actions)          # other half of the double buffer
-        if obs.is_cuda:   # terminal obs, appended before the reset overwrites the finished rows
-            self.memory.add_vector_step(obs, actions, reward, next_obs, done)
+        if obs.is_cuda and hasattr(train_env, "step_append"):
+            # mn_step_append: the step kernel itself writes (obs_t, a, r, obs_t+1 incl. terminal observations, done)
+            # into the replay ring -- no separate append launch, obs_t+1 is not re-read
+            next_obs, reward, done, info = train_env.step_append(actions, obs, self.memory)
         else:
-            self.memory.add_batch(obs, actions, reward, next_obs, done.float())
+            next_obs, reward, done, info = train_env.step(actions)      # other half of the double buffer
+            if obs.is_cuda:   # terminal obs, appended before the reset overwrites the finished rows
+                self.memory.add_vector_step(obs, actions, reward, next_obs, done)
+            else:
+                self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         obs = train_env.reset_done()                                    # first observations where done
         loss = None
         if self.current_timestep >= self.learning_starts:
             if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
                 for _ in range(self.grad_steps_per_update):      # 1 = the reference's cadence (agent.py:129-133)
                     loss = self.train_from_memory()
-            if self.learning_timestep % self.target_update_interval == 0:
+            if self.target_sync_grad_steps is None:
+                if self.learning_timestep % self.target_update_interval == 0:
+                    self.soft_update(self.qnetwork_local, self.qnetwork_target)
+            elif self.learning_timestep == 0 or self.grad_steps - self._last_sync_at >= self.target_sync_grad_steps:
+                # cadence in GRADIENT steps (the reference: every 10 000 learning steps = 2 500 grad steps, agent.py:136)
                 self.soft_update(self.qnetwork_local, self.qnetwork_target)
+                self._last_sync_at = self.grad_steps
             self.learning_timestep += 1
         self.current_timestep += per_iter
         return obs, reward, done, info, loss
@@ -514,7 +586,7 @@ class IQNAgent:
             print(f"Avg time: {avg_t:.2f}")
             print(f"Avg energy: {avg_e:.2f}")
             print(f"++++++++ Evaluation info ({policy} IQN) ++++++++\n")
-        self.eval_timesteps[policy].append(self.current_timestep)
+        self.eval_timesteps[policy].append(int(round(self.current_timestep * getattr(self, "_report_scale", 1.0))))
         self.eval_actions[policy].append(action_data)
         self.eval_rewards[policy].append(reward_data)
         self.eval_successes[policy].append(success_data)

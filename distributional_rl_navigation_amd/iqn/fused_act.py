@@ -1,5 +1,12 @@
-"""Python side of the fused IQN act kernel (csrc/iqn_act.hip, `mn_iqn_act`)."""
+"""Python side of the fused IQN act kernel (csrc/iqn_act.hip, `mn_iqn_act` / `mn_iqn_act_rng`).
+
+Every network that acts through the kernel owns one `ActContext` (C-ABI `mn_iqn_ctx`): the permuted weight image
+the kernel stages into LDS is cached there and rebuilt only after the weights changed.  Changes made through
+PyTorch (optimizer.step, load_state_dict, copy_) are detected from the parameters' version counters; writers that
+bypass PyTorch (the fused HIP Adam step, csrc/iqn_train.hip) call `weights_changed(net)`.
+"""
 import ctypes as C
+import weakref
 
 import torch
 
@@ -9,19 +16,79 @@ _ORDER = ("velocity_encoder", "goal_encoder", "sensor_encoder", "cos_embedding",
 
 
 def _p(t):
-    return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _weight_ptrs(net):
-    ptrs = (C.c_void_p * 14)()
-    i = 0
-    for name in _ORDER:
-        m = getattr(net, name)
-        for t in (m.weight, m.bias):
-            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
-            ptrs[i] = t.data_ptr()
-            i += 1
-    return ptrs
+def _params(net):
+    return [t for name in _ORDER for t in (getattr(net, name).weight, getattr(net, name).bias)]
+
+
+class ActContext:
+    """`mn_iqn_ctx` of one network on one device."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _capi.lib().mn_iqn_create(C.byref(h))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_create failed ({rc})")
+        self.h = h
+        self._sig = None
+        self._ptrs = (C.c_void_p * 14)()
+        self._fin = weakref.finalize(self, _capi.lib().mn_iqn_destroy, h)
+
+    def __deepcopy__(self, memo):      # a copied network gets its own context lazily (act_context)
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+    def weights(self, net):
+        """HOST array of the 14 device pointers; marks the cached image stale when a parameter was re-allocated or
+        written through PyTorch since the last call."""
+        ps = _params(net)
+        sig = tuple((t.data_ptr(), t._version) for t in ps)
+        if sig != self._sig:
+            for i, t in enumerate(ps):
+                assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+                self._ptrs[i] = t.data_ptr()
+            self._sig = sig
+            self.invalidate()
+        return self._ptrs
+
+    def invalidate(self):
+        _capi.lib().mn_iqn_weights_changed(self.h)
+
+    def profile_begin(self, max_launches):
+        rc = _capi.lib().mn_iqn_profile_begin(self.h, int(max_launches))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_profile_begin failed ({rc})")
+
+    def profile_end(self):
+        ms, nl = C.c_double(), C.c_int32()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_iqn_profile_end(self.h, stream, C.byref(ms), C.byref(nl))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_profile_end failed ({rc})")
+        return ms.value, nl.value
+
+
+def act_context(net):
+    """The network's own act context (created on first use, on the device its parameters live on)."""
+    dev = net.output_layer.weight.device
+    ctx = getattr(net, "_act_ctx", None)
+    if ctx is None or ctx.device != dev:
+        ctx = ActContext(dev)
+        object.__setattr__(net, "_act_ctx", ctx)      # not a Module / Parameter: keep it out of state_dict
+    return ctx
+
+
+def weights_changed(net):
+    """Tell the act path that `net`'s weights were written outside PyTorch's version tracking (HIP kernels)."""
+    ctx = getattr(net, "_act_ctx", None)
+    if ctx is not None:
+        ctx.invalidate()
 
 
 def _taus(net, n, device, cvar, taus, generator):
@@ -51,43 +118,48 @@ class ActRng:
 
 
 @torch.no_grad()
-def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None):
+def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None, want_quantiles=False):
     """IQNAgent.act for states [n, 26] on the GPU in ONE kernel: encoders, cosine embedding, Hadamard
     product, hidden layers, mean over K = 32 taus, argmax and epsilon-greedy.
-    Returns actions [n] int32 (and Q-values [n, 9] if want_qvals).  `taus` [n, 32] may be injected; otherwise, with
-    `rng` (an ActRng) the library draws taus and exploration uniforms in the launch that prepares the weights (no
-    torch.rand kernels; the draws of the last call stay readable in rng.draws(n, 32)), and without it they come from
-    torch.rand on `generator`."""
+    Returns actions [n] int32; with want_qvals (actions, Q [n, 9]); with want_quantiles -- the batched
+    IQNAgent.act_eval (agent.py:217-236) -- (actions, quantiles [n, 32, 9], taus [n, 32, 1]) (+ Q if want_qvals).
+    `taus` [n, 32] may be injected; otherwise, with `rng` (an ActRng) the library draws taus and exploration uniforms
+    in its own preparation launch (no torch.rand kernels), and without it they come from torch.rand on `generator`."""
     assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous()
     n = states.shape[0]
     dev = states.device
-    if taus is None and rng is not None:
-        actions = torch.empty(n, dtype=torch.int32, device=dev)
-        q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
-        cv_row = cvar.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(cvar) else None
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = _capi.lib().mn_iqn_act_rng(_p(states), _weight_ptrs(net), _p(rng.state), _p(rng.draws(n, net.K)),
-                                        _p(cv_row) if cv_row is not None else None,
-                                        C.c_float(1.0 if cv_row is not None else float(cvar)), C.c_float(float(eps)), _p(actions),
-                                        _p(q) if q is not None else None, n, net.K, stream)
-        if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_act_rng failed ({rc})")
-        return (actions, q) if want_qvals else actions
-    if taus is None and eps > 0.0:      # one RNG launch for the n x K taus and the n exploration uniforms
-        buf = torch.rand(n * (net.K + 1), device=dev, generator=generator)
-        t = _taus(net, n, dev, cvar, buf[:n * net.K].view(n, net.K), None)
-        u = buf[n * net.K:]
-    else:
-        t = _taus(net, n, dev, cvar, taus, generator)
-        u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
+    ctx = act_context(net)
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
+    quant = torch.empty(n, net.K, net.action_size, dtype=torch.float32, device=dev) if want_quantiles else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    rc = _capi.lib().mn_iqn_act(_p(states), _p(t), _weight_ptrs(net), _p(q) if q is not None else None,
-                                _p(u) if u is not None else None, C.c_float(float(eps)), _p(actions), n, net.K, stream)
-    if rc:
-        raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
-    return (actions, q) if want_qvals else actions
+    if taus is None and rng is not None:
+        cv_row = cvar.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(cvar) else None
+        draws = rng.draws(n, net.K)
+        rc = _capi.lib().mn_iqn_act_rng(ctx.h, _p(states), ctx.weights(net), _p(rng.state), _p(draws), _p(cv_row),
+                                        C.c_float(1.0 if cv_row is not None else float(cvar)), C.c_float(float(eps)),
+                                        _p(actions), _p(q), _p(quant), n, net.K, stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_act_rng failed ({rc})")
+        t = draws[:n * net.K].view(n, net.K)
+    else:
+        if taus is None and eps > 0.0:      # one RNG launch for the n x K taus and the n exploration uniforms
+            buf = torch.rand(n * (net.K + 1), device=dev, generator=generator)
+            t = _taus(net, n, dev, cvar, buf[:n * net.K].view(n, net.K), None)
+            u = buf[n * net.K:]
+        else:
+            t = _taus(net, n, dev, cvar, taus, generator)
+            u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
+        rc = _capi.lib().mn_iqn_act(ctx.h, _p(states), _p(t), ctx.weights(net), _p(q), _p(u), C.c_float(float(eps)),
+                                    _p(actions), _p(quant), n, net.K, stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
+    out = (actions,)
+    if want_quantiles:
+        out += (quant, t.clone().view(n, net.K, 1))
+    if want_qvals:
+        out += (q,)
+    return out if len(out) > 1 else actions
 
 
 @torch.no_grad()
@@ -96,10 +168,12 @@ def fused_qvals(net, states, cvar=1.0, taus=None, generator=None):
     assert states.is_cuda and states.dtype == torch.float32
     states = states.contiguous()
     n = states.shape[0]
+    ctx = act_context(net)
     t = _taus(net, n, states.device, cvar, taus, generator)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=states.device)
     stream = C.c_void_p(torch.cuda.current_stream(states.device).cuda_stream)
-    rc = _capi.lib().mn_iqn_act(_p(states), _p(t), _weight_ptrs(net), _p(q), None, C.c_float(0.0), None, n, net.K, stream)
+    rc = _capi.lib().mn_iqn_act(ctx.h, _p(states), _p(t), ctx.weights(net), _p(q), None, C.c_float(0.0), None, None, n, net.K,
+                                stream)
     if rc:
         raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
     return q

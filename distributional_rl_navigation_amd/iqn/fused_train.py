@@ -4,14 +4,17 @@ as three kernels behind `mn_iqn_train_grad` / `mn_iqn_train_adam`.
 The kernels work on FLAT parameter vectors (35 785 floats, `named_parameters()` order).  `FusedTrainer` allocates one
 flat buffer per network and re-points every `nn.Parameter` at a view of it, so the PyTorch modules (checkpoints,
 `soft_update`, the fused act kernel, eager evaluation) and the HIP step always see the same memory.  The Adam
-moments / step counter live in flat device buffers owned by the trainer (the reference never checkpoints the
-optimizer, agent.py:86-92).
+moments live in two more flat buffers that are ALSO `agent.optimizer`'s `exp_avg` / `exp_avg_sq` state (views), and the
+step counter is copied between the device counter of the HIP step and the optimizer's per-parameter `step` whenever
+the agent switches between the HIP and the PyTorch gradient step (`sync_to_optimizer` / `sync_from_optimizer`): one
+optimizer state, whichever path runs.
 """
 import ctypes as C
 
 import torch
 
 from .. import _capi
+from .fused_act import weights_changed
 
 P_TOTAL = 35785
 _ORDER = ("velocity_encoder", "goal_encoder", "sensor_encoder", "cos_embedding", "hidden_layer", "hidden_layer_2",
@@ -55,6 +58,7 @@ class FusedTrainer:
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
         self.rng_state = torch.tensor([int(agent.memory.gen.initial_seed()) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
                                       device=self.device)
+        self.rng_state[0] += 0x9E3779B1 * int(getattr(agent, "rank", 0))     # decorrelate the ranks of a shared learner
         self._idx, self._taus = {}, {}
         self._arange = {}
         off = 0
@@ -62,6 +66,41 @@ class FusedTrainer:
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
             off += p.numel()
         self._nets = (agent.qnetwork_local, agent.qnetwork_target)
+        self._adopt_optimizer_state(agent.optimizer)
+
+    # ---- one Adam state for both gradient-step paths ---------------------------------------------------------------
+    def _adopt_optimizer_state(self, opt):
+        """Make `opt.state[p]['exp_avg' / 'exp_avg_sq']` views of the flat moment buffers (keeping what the optimizer
+        had accumulated so far) and take over its step count."""
+        step = 0
+        off = 0
+        for p in self.agent.qnetwork_local.parameters():
+            n = p.numel()
+            st = opt.state.get(p, None)
+            m_view = self.exp_avg[off:off + n].view(p.shape)
+            v_view = self.exp_avg_sq[off:off + n].view(p.shape)
+            if st is not None and "exp_avg" in st:
+                m_view.copy_(st["exp_avg"]); v_view.copy_(st["exp_avg_sq"])
+                step = int(float(st["step"]))
+            else:
+                st = opt.state[p]
+                # same kind of `step` tensor torch.optim.Adam would create lazily (device tensor for fused / capturable)
+                on_dev = any(g.get("fused") or g.get("capturable") for g in opt.param_groups)
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device if on_dev else "cpu")
+            st["exp_avg"], st["exp_avg_sq"] = m_view, v_view
+            off += n
+        self.step_dev.fill_(step)
+
+    def sync_to_optimizer(self, opt):
+        """HIP path -> PyTorch path: hand the step count to torch.optim.Adam (the moments are shared memory)."""
+        t = float(int(self.step_dev.item()))
+        for p in self.agent.qnetwork_local.parameters():
+            opt.state[p]["step"].fill_(t)
+
+    def sync_from_optimizer(self, opt):
+        """PyTorch path -> HIP path."""
+        p0 = next(iter(self.agent.qnetwork_local.parameters()))
+        self.step_dev.fill_(int(float(opt.state[p0]["step"])))
 
     def owns(self, agent):
         return self._nets == (agent.qnetwork_local, agent.qnetwork_target)
@@ -119,11 +158,18 @@ class FusedTrainer:
             raise _capi.MarineNavHipError(f"mn_iqn_train_grad failed ({rc})")
         if ag.distributed:
             import torch.distributed as dist
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)            # one 143 KB bucket over RCCL/xGMI
+            if dist.get_backend() == "gloo":
+                # debugging / single-GPU multi-process tests only: gloo reduces on the host
+                g = self.grad.cpu()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                self.grad.copy_(g)
+            else:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)        # one 143 KB bucket over RCCL/xGMI
             self.grad.div_(dist.get_world_size())
         rc = L.mn_iqn_train_adam(_p(self.local), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev),
                                  _p(self._workspace(B)), B, C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5),
                                  stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_adam failed ({rc})")
+        weights_changed(ag.qnetwork_local)      # the HIP Adam kernel wrote the weights: the act path's cached image is stale
         return self.loss[0]

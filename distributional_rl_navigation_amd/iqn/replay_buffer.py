@@ -75,10 +75,36 @@ class ReplayBuffer:
         self.ptr = end % self.capacity
         self.size = min(self.capacity, self.size + n)
 
+    def advance(self, n):
+        """Ring bookkeeping after `n` transitions were written at `ptr` by a kernel (mn_step_append)."""
+        m = min(int(n), self.capacity)
+        self.ptr = (self.ptr + m) % self.capacity
+        self.size = min(self.capacity, self.size + m)
+
+    def sample_indices(self, b):
+        """`b` distinct uniform row indices in [0, size) (random.sample, replay_buffer.py:47) without a full
+        permutation of the ring: draw with replacement, keep first occurrences, top up until b are distinct (each
+        accepted index is uniform over what the earlier ones left, i.e. sequential sampling without replacement)."""
+        assert self.size >= b
+        if self.size <= 4 * b:      # dense case: a permutation is the cheap way
+            return torch.randperm(self.size, device=self.device, generator=self.gen)[:b]
+        chosen = torch.empty(0, dtype=torch.int64, device=self.device)
+        while chosen.numel() < b:
+            cand = torch.randint(0, self.size, (2 * b,), device=self.device, generator=self.gen)
+            allv = torch.cat([chosen, cand])
+            # stable first-occurrence filter
+            srt, order = torch.sort(allv, stable=True)
+            first = torch.ones_like(srt, dtype=torch.bool)
+            first[1:] = srt[1:] != srt[:-1]
+            keep = torch.zeros_like(first)
+            keep[order] = first
+            chosen = allv[keep][:b]
+        return chosen
+
     def sample(self, batch_size=None):
         """Uniform without replacement (random.sample, replay_buffer.py:47) -> float32 / int64 tensors."""
         b = self.batch_size if batch_size is None else batch_size
-        idx = torch.randperm(self.size, device=self.device, generator=self.gen)[:b]
+        idx = self.sample_indices(b)
         return (self.states[idx], self.actions[idx], self.rewards[idx], self.next_states[idx], self.dones[idx])
 
     def __len__(self):

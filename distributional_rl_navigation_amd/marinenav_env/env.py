@@ -76,7 +76,7 @@ class _RobotView:
 
     def __init__(self, env):
         self._env = env
-        self.dt = 0.1
+        self._dt = 0.1
         self._N = 10
         self.sonar = _Sonar()
         self.length, self.width, self.r, self.max_speed = 1.0, 0.5, 0.8, 2.0
@@ -95,6 +95,16 @@ class _RobotView:
     def N(self, v):
         self._N = int(v)
         self._env._venv.set_attrs(N=int(v))      # e.g. run_experiments.py:204 sets robot.N = 5
+        self._env._venv.enable_trajectory(max(64, int(v)))
+
+    @property
+    def dt(self):
+        return self._dt
+
+    @dt.setter
+    def dt(self, v):
+        self._dt = float(v)
+        self._env._venv.set_attrs(dt=float(v))   # robot.py:28: the integration step is a device parameter
 
     def compute_k(self):
         self.k = np.max(self.a) / self.max_speed
@@ -147,6 +157,7 @@ class MarineNavEnv(_Base):
         self.set_boundary = False
         object.__setattr__(self, "_ready", True)
         self._push()
+        self._venv.enable_trajectory(64)
 
     # attribute writes propagate to the device parameters lazily (before the next reset/step)
     def __setattr__(self, k, v):
@@ -192,8 +203,18 @@ class MarineNavEnv(_Base):
         """marinenav_env.py:86-186 -> float64 observation [26]."""
         if self._dirty:
             self._push()
-        if self.schedule is not None:   # the reference prints its curriculum stage on every reset (:100-104)
-            pass
+        if self.schedule is not None:
+            # curriculum lookup + the print block of marinenav_env.py:89-104 (the device does the same lookup for the
+            # world it generates; mirrored here so the attributes and the log read as upstream)
+            steps = np.array(self.schedule["timesteps"])
+            idx = int(np.count_nonzero(steps - self.total_timesteps <= 0)) - 1
+            for k, key in (("num_cores", "num_cores"), ("num_obs", "num_obstacles"), ("min_start_goal_dis", "min_start_goal_dis")):
+                object.__setattr__(self, k, self.schedule[key][idx])
+            print("======== training schedule ========")
+            print("num of cores: ", self.num_cores)
+            print("num of obstacles: ", self.num_obs)
+            print("min start goal dis: ", self.min_start_goal_dis)
+            print("======== training schedule ========\n")
         self._venv.reset()
         self._pull_world()
         self.robot.action_history.clear(); self.robot.trajectory.clear()
@@ -207,10 +228,59 @@ class MarineNavEnv(_Base):
         a = torch.tensor([int(action)], dtype=torch.int32, device=self._venv.device)
         _, r, d, info = self._venv.step(a)
         obs = self._venv.get_obs64(0, 1)[0]
-        s = self._venv.get_state(0, 1)[0][0]
-        self.robot.trajectory.append([float(s[0]), float(s[1])])
+        for p_ in self._venv.get_trajectory(0, 1)[0]:            # one point per sub-step (marinenav_env.py:211-212)
+            self.robot.trajectory.append([float(p_[0]), float(p_[1])])
         reward = float(self._venv.get_reward64(0, 1)[0])
         return obs, reward, bool(d[0].item()), {"state": INFO_STRINGS[int(info[0].item())]}
+
+    # ---- host-side queries of the current state (marinenav_env.py:264-342, 422-465) ---------------------------------
+    def compute_speed(self, Gamma, d):
+        """marinenav_env.py:461-465 (Rankine vortex profile)."""
+        return Gamma / (2 * np.pi * self.r * self.r) * d if d <= self.r else Gamma / (2 * np.pi * d)
+
+    def get_velocity(self, x, y):
+        """marinenav_env.py:422-455: current velocity at (x, y).  All cores superpose (the reference's "occlusion" test
+        never skips a core), summed nearest first like the reference's KDTree order."""
+        if len(self.cores) == 0:
+            return np.zeros(2)
+        v = np.zeros(2)
+        for c in sorted(self.cores, key=lambda c: (c.x - x) ** 2 + (c.y - y) ** 2):
+            rad = np.array([c.x - x, c.y - y])
+            dis = np.linalg.norm(rad)
+            rad = rad / dis
+            tangent = np.array([-rad[1], rad[0]]) if c.clockwise else np.array([rad[1], -rad[0]])
+            v += tangent * self.compute_speed(c.Gamma, dis)
+        return v
+
+    def out_of_boundary(self):
+        x, y = self.robot.x, self.robot.y
+        return bool(x < 0.0 or x > self.width or y < 0.0 or y > self.height)
+
+    def dist_to_goal(self):
+        return float(np.linalg.norm(np.asarray(self.goal) - np.array([self.robot.x, self.robot.y])))
+
+    def check_collision(self):
+        """marinenav_env.py:329-336: nearest-CENTRE obstacle only."""
+        if len(self.obstacles) == 0:
+            return False
+        p = np.array([self.robot.x, self.robot.y])
+        d = [np.linalg.norm(p - np.array([o.x, o.y])) for o in self.obstacles]
+        i = int(np.argmin(d))
+        return bool(d[i] <= self.obstacles[i].r + self.robot.r)
+
+    def check_reach_goal(self):
+        return bool(self.dist_to_goal() <= self.goal_dis)
+
+    def get_observation(self, for_visualize=False):
+        """marinenav_env.py:273-326: the observation of the CURRENT state (what the last reset / step returned).
+        for_visualize: (velocity_r [2], sonar points [3, 11] = robot-frame x, y and the hit flag, goal_r [2]); misses
+        are reported as (0, 0, 0) (upstream leaves the transformed end-of-range point there)."""
+        obs = self._venv.get_obs64(0, 1)[0]
+        if not for_visualize:
+            return obs
+        pts = obs[4:].reshape(11, 2)
+        hit = ~((pts[:, 0] == 0) & (pts[:, 1] == 0))
+        return obs[:2].copy(), np.vstack([pts[:, 0], pts[:, 1], hit.astype(np.float64)]), obs[2:4].copy()
 
     def reset_with_eval_config(self, eval_config):
         """marinenav_env.py:467-555."""
@@ -221,7 +291,7 @@ class MarineNavEnv(_Base):
             object.__setattr__(self, k, e[k])
         object.__setattr__(self, "v_range", copy.deepcopy(e["v_range"]))
         object.__setattr__(self, "obs_r_range", copy.deepcopy(e["obs_r_range"]))
-        self.robot.dt, self.robot._N = r["dt"], r["N"]
+        self.robot._dt, self.robot._N = r["dt"], r["N"]
         self.robot.length, self.robot.width, self.robot.r, self.robot.max_speed = r["length"], r["width"], r["r"], r["max_speed"]
         self.robot.a, self.robot.w = np.array(r["a"]), np.array(r["w"])
         self.robot.compute_k(); self.robot.compute_actions()
@@ -276,9 +346,18 @@ def make(id="marinenav_env:marinenav_env-v0", **kw):
     return MarineNavEnv(**kw)
 
 
-if _gym is not None:  # pragma: no cover
+def register_with_gym():
+    """Register the facade under the reference's id (marinenav_env/__init__.py:3-6) when gym is importable; the
+    repo-root `marinenav_env` shim package calls this, so `gym.make('marinenav_env:marinenav_env-v0', seed=, schedule=)`
+    (train_IQN_model.py:96,100) resolves to this class."""
+    if _gym is None:
+        return False
     try:
         from gym.envs.registration import register
         register(id="marinenav_env-v0", entry_point="distributional_rl_navigation_amd.marinenav_env.env:MarineNavEnv")
-    except Exception:  # noqa: BLE001
-        pass
+        return True
+    except Exception:  # noqa: BLE001  (already registered)
+        return False
+
+
+register_with_gym()

@@ -31,6 +31,16 @@ def _np_ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+def shard_seeds(n_envs, seed=0, first_index=0):
+    """Default per-env seeds of a shard: env i of the shard is global env `first_index + i` and is seeded with
+    `seed + first_index + i` (mod 2^32, np.random.RandomState's seed range), so rank r of a multi-GPU run
+    (first_index = r * n_envs) generates exactly the worlds of rows [r n, (r+1) n) of a one-GPU run."""
+    if n_envs <= 0 or first_index < 0:
+        raise ValueError("shard_seeds: n_envs must be positive and first_index non-negative")
+    return ((np.arange(int(n_envs), dtype=np.uint64) + np.uint64(int(seed) % (1 << 32)) + np.uint64(int(first_index)))
+            & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
 class VecMarineNavEnv:
     """n_envs independent MarineNavEnv instances stepped by one kernel launch.
 
@@ -56,8 +66,9 @@ class VecMarineNavEnv:
         if rc:
             raise _capi.MarineNavHipError(f"mn_create failed ({rc}): {self.L.mn_last_error(None).decode()}")
         self.h = h
+        self.first_index = int(first_index)
         if seeds is None:
-            seeds = (np.arange(self.n_envs, dtype=np.uint64) + np.uint64(seed) + np.uint64(first_index)) & np.uint64(0xFFFFFFFF)
+            seeds = shard_seeds(self.n_envs, seed, first_index)
         self.seed(seeds)
         self.schedule = None
         if schedule is not None:
@@ -166,6 +177,24 @@ class VecMarineNavEnv:
             a = a.to(device=self.device, dtype=torch.int32).contiguous()
         self._check(self.L.mn_step(self.h, _ptr(a), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), _ptr(self.info),
                                    self._stream()))
+        return self.obs, self.reward, self.done, self.info
+
+    def step_append(self, actions, prev_obs, replay):
+        """`step` + `replay.add` for every env in ONE launch (C-ABI mn_step_append): the transition
+        (prev_obs[i], actions[i], reward, obs, done) of env i is written straight into the device ring of `replay`
+        (iqn.replay_buffer.ReplayBuffer) by the step kernel.  `prev_obs` must be the tensor the last step()/reset()
+        returned (the other half of the observation double buffer)."""
+        self._cur ^= 1
+        self.obs = self._obs_bufs[self._cur]
+        a = actions
+        if a.dtype != torch.int32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        assert prev_obs.data_ptr() != self.obs.data_ptr() and prev_obs.is_contiguous() and prev_obs.dtype == torch.float32
+        self._check(self.L.mn_step_append(self.h, _ptr(a), _ptr(prev_obs), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                                          _ptr(self.info), _ptr(replay.states), _ptr(replay.next_states), _ptr(replay.actions),
+                                          _ptr(replay.rewards), _ptr(replay.dones), int(replay.ptr), int(replay.capacity),
+                                          self._stream()))
+        replay.advance(self.n_envs)
         return self.obs, self.reward, self.done, self.info
 
     def reset_done(self, keep_terminal_obs=False):
@@ -284,6 +313,18 @@ class VecMarineNavEnv:
         out = np.zeros(cnt)
         torch.cuda.synchronize(self.device)
         self._check(self.L.mn_get_reward64(self.h, int(first_env), cnt, _np_ptr(out, C.c_double)))
+        return out
+
+    def enable_trajectory(self, max_substeps=None):
+        """Record the per-sub-step positions of every step (robot.trajectory, marinenav_env.py:211-212); f64 handles."""
+        self._check(self.L.mn_enable_trajectory(self.h, int(self.params.N if max_substeps is None else max_substeps)))
+
+    def get_trajectory(self, first_env=0, count=None):
+        """[count, N, 2] positions after each of the N sub-steps of the last step()."""
+        cnt = self.n_envs - first_env if count is None else count
+        out = np.zeros((cnt, int(self.params.N), 2))
+        torch.cuda.synchronize(self.device)
+        self._check(self.L.mn_get_trajectory(self.h, int(first_env), cnt, int(self.params.N), _np_ptr(out, C.c_double)))
         return out
 
     def peek_next_double(self, first_env=0, count=None):

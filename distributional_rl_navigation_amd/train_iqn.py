@@ -8,6 +8,13 @@ GPUs (independent learners per rank by default, `--shared-learner` for one IQN w
 gradient all-reduce).
 
     python -m distributional_rl_navigation_amd.train_iqn -C config_IQN.json --n-envs 65536
+
+Cadence.  The reference does one batch-32 gradient step per 4 env steps (replay ratio 8 sampled per generated
+transition).  With 65 536 envs a vector step IS 65 536 env steps, so that ratio is out of reach (16 384 gradient
+steps per vector step); the batched loop instead spends the reference's LEARNER budget (750 000 x 32 samples =
+93 750 gradient steps of batch 256) at G gradient steps per vector step (default 16 per 65 536 envs: learner ~ half of
+the GPU time, replay ratio 0.06) and rescales every run-fraction cadence (exploration ramp, curriculum, evaluations)
+-- `plan_cadence`.  profiles/r02_train_headline.txt has the measured learning curves.
 """
 import argparse
 import itertools
@@ -54,9 +61,46 @@ def create_eval_configs(device, seed=348):
     return cfg
 
 
+def plan_cadence(total_timesteps, eval_freq, n_envs_total, batch, ref_batch=32, ref_update_every=4,
+                 ref_target_interval=10_000, grad_steps_per_vector_step=None, total_grad_steps=None, n_evals=None):
+    """Translate the reference's env-step cadences (config_IQN.json + agent.py defaults: 3 M timesteps, one batch-32
+    gradient step every 4 env steps, target copy every 10 000 learning steps, evaluation every 10 000) into the
+    batched loop's units.
+
+    The reference consumes total_timesteps / 4 gradient steps x 32 samples.  A vector step is n_envs_total env steps
+    at once, so the batched loop cannot keep the reference's replay ratio (that would be n_envs_total / 4 gradient
+    steps per vector step); it keeps the reference's LEARNER budget instead -- the same number of sampled transitions,
+    total_grad_steps = total_timesteps / 4 * 32 / batch -- and spreads it over as many vector steps as the chosen
+    gradient-steps-per-vector-step G needs.  Everything that the reference expresses as a fraction of the run
+    (exploration ramp, curriculum stages, evaluation points) keeps its fraction.
+    Returns a dict; `replay_ratio` = sampled transitions per generated env step (reference: 8)."""
+    ref_grad_steps = total_timesteps // ref_update_every
+    if total_grad_steps is None:
+        total_grad_steps = max(1, int(round(ref_grad_steps * ref_batch / batch)))
+    if grad_steps_per_vector_step is None:
+        # keep the learner at roughly half of the GPU time: one fused grad step ~ 57 us, one vector step ~ 16 ns / env
+        grad_steps_per_vector_step = int(min(32, max(1, round(n_envs_total / 65536 * 16))))
+    G = int(grad_steps_per_vector_step)
+    vector_steps = int(np.ceil(total_grad_steps / G))
+    if n_evals is None:
+        n_evals = int(min(30, max(1, total_timesteps // max(1, eval_freq))))
+    plan = dict(
+        vector_steps=vector_steps, grad_steps_per_vector_step=G, total_grad_steps=vector_steps * G,
+        reference_grad_steps=ref_grad_steps, reference_samples=ref_grad_steps * ref_batch, samples=vector_steps * G * batch,
+        env_steps=vector_steps * n_envs_total,
+        # target copy every 10 000 learning steps = 2 500 gradient steps x 32 samples -> same number of samples
+        target_sync_grad_steps=max(50, int(round(ref_target_interval / ref_update_every * ref_batch / batch))),
+        eval_every_vector_steps=max(1, vector_steps // n_evals), n_evals=n_evals,
+        # env.total_timesteps counts vector steps per env; the curriculum (and eps) see reference-scaled time
+        timestep_scale=total_timesteps / vector_steps,
+        replay_ratio=G * batch / n_envs_total, reference_replay_ratio=ref_batch / ref_update_every)
+    return plan
+
+
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
-              update_every=4, grad_steps=1, torch_train=False):
-    """train_IQN_model.py:74-121 on the vector env."""
+              grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0):
+    """train_IQN_model.py:74-121 on the vector env.  `params` is one trial of the reference's config grid
+    (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps."""
     import torch
     from .iqn.agent import IQNAgent
     from .marinenav_env.vec_env import VecMarineNavEnv
@@ -65,16 +109,27 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     if world > 1 and not shared:
         exp_dir = os.path.join(exp_dir, f"rank_{rank}")
     writer = rank == 0 or not shared
+    total = n_envs * world
+    plan = plan_cadence(params["total_timesteps"], params["eval_freq"], total, batch,
+                        grad_steps_per_vector_step=grad_steps, total_grad_steps=total_grad_steps, n_evals=n_evals)
+    if plan["total_grad_steps"] * batch < 0.1 * plan["reference_samples"]:
+        raise ValueError(f"planned learner budget ({plan['total_grad_steps']} grad steps x {batch}) is more than 10x below the "
+                         f"reference's ({plan['reference_grad_steps']} x 32): raise --total-grad-steps")
     if writer:
         os.makedirs(exp_dir, exist_ok=True)
         with open(os.path.join(exp_dir, "trial_config.json"), "w+") as f:
-            json.dump(params, f)
+            json.dump(dict(params, batched=dict(plan, n_envs=n_envs, world=world, batch=batch, replay=replay)), f)
         with open(os.path.join(exp_dir, "training_schedule.json"), "w+") as f:
             json.dump(TRAINING_SCHEDULE, f)
+        if verbose:
+            print(f"[train_iqn] {plan['vector_steps']} vector steps x {total} envs = {plan['env_steps']:.3g} env steps; "
+                  f"{plan['total_grad_steps']} grad steps of batch {batch} ({plan['grad_steps_per_vector_step']} per vector step; "
+                  f"reference: {plan['reference_grad_steps']} of 32); replay ratio {plan['replay_ratio']:.3g} sampled / generated "
+                  f"transition (reference {plan['reference_replay_ratio']:.0f}); target copy every {plan['target_sync_grad_steps']} "
+                  f"grad steps; evaluation every {plan['eval_every_vector_steps']} vector steps")
 
-    total = n_envs * world
     train_env = VecMarineNavEnv(n_envs, seed=params["seed"], first_index=rank * n_envs, schedule=TRAINING_SCHEDULE,
-                                timestep_scale=total, device=device)
+                                timestep_scale=plan["timestep_scale"], device=device)
     eval_config = create_eval_configs(device)
     if writer:
         with open(os.path.join(exp_dir, "eval_config.json"), "w+") as f:
@@ -83,15 +138,15 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
 
     agent = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
                      seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
-                     UPDATE_EVERY=update_every)
-    agent.grad_steps_per_update = grad_steps
+                     UPDATE_EVERY=1, learning_starts=0, rank=rank if shared else 0)
+    agent.grad_steps_per_update = plan["grad_steps_per_vector_step"]
+    agent.target_sync_grad_steps = plan["target_sync_grad_steps"]
     if torch_train:
         agent.use_fused_train = False          # PyTorch autograd + Adam instead of csrc/iqn_train.hip
-    vec_steps = int(np.ceil((params["total_timesteps"] + 1) / total))
-    eval_every = max(1, int(round(params["eval_freq"] / total)))
-    agent.learn_vec(total_vector_steps=vec_steps, train_env=train_env, eval_env=eval_env, eval_config=eval_config,
-                    eval_freq=eval_every, eval_log_path=exp_dir if writer else None,
-                    total_timesteps=params["total_timesteps"], world_size=world, verbose=False)
+    agent.learn_vec(total_vector_steps=plan["vector_steps"], train_env=train_env, eval_env=eval_env, eval_config=eval_config,
+                    eval_freq=plan["eval_every_vector_steps"], eval_log_path=exp_dir if writer else None,
+                    total_timesteps=plan["vector_steps"] * total, world_size=world, cvar=cvar, verbose=False,
+                    report_timestep_scale=params["total_timesteps"] / (plan["vector_steps"] * total))
     if writer:
         agent.qnetwork_local.save(exp_dir)
     train_env.close()
@@ -109,8 +164,12 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--replay", type=int, default=100_000)
     ap.add_argument("--shared-learner", action="store_true")
-    ap.add_argument("--update-every", type=int, default=4, help="vector steps between training events (UPDATE_EVERY)")
-    ap.add_argument("--grad-steps", type=int, default=1, help="grad steps per training event")
+    ap.add_argument("--grad-steps", type=int, default=None,
+                    help="gradient steps per vector step (default: 16 per 65 536 envs, i.e. learner ~ half of the GPU time)")
+    ap.add_argument("--total-grad-steps", type=int, default=None,
+                    help="learner budget (default: the reference's sample count, total_timesteps / 4 * 32 / batch)")
+    ap.add_argument("--n-evals", type=int, default=None, help="evaluation points over the run (default: min(30, total_timesteps / eval_freq))")
+    ap.add_argument("--cvar", type=float, default=1.0, help="CVaR level of the acting policy while training (configs[4]: 0.5)")
     ap.add_argument("--torch-train", action="store_true", help="gradient step through PyTorch instead of the fused HIP kernels")
     args = ap.parse_args(argv)
     params = json.load(args.config_file)
@@ -126,7 +185,8 @@ def main(argv=None):
     for p in trial_params(params):
         p["training_time"] = stamp
         run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay,
-                  update_every=args.update_every, grad_steps=args.grad_steps, torch_train=args.torch_train)
+                  grad_steps=args.grad_steps, torch_train=args.torch_train, total_grad_steps=args.total_grad_steps,
+                  n_evals=args.n_evals, cvar=args.cvar)
     if world > 1:
         dist.destroy_process_group()
 

@@ -92,6 +92,11 @@ typedef struct mn_params {
 
 typedef struct mn_handle mn_handle;
 
+/* Build flags of the loaded library.  The shipped libmarinenav_hip.so returns 0: its kernels have no switch that
+ * removes work.  libmarinenav_hip_ablation.so (make ablation; profiling scripts only) returns MN_BUILD_ABLATION. */
+#define MN_BUILD_ABLATION 1
+int32_t mn_build_info(void);
+
 /* Fills *p with the reference defaults (marinenav_env.py:40-73, robot.py:5-50). */
 int mn_default_params(mn_params *p);
 
@@ -135,6 +140,17 @@ int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stream
 int mn_step(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
             uint8_t *info_dev, void *stream);
 
+/* mn_step plus ReplayBuffer.add (thirdparty/IQN/replay_buffer.py:26-34, as called at agent.py:124) for every env, in
+ * the SAME launch: the transition (prev_obs_dev[i] = the observation actions_dev[i] was chosen from, action, reward,
+ * obs_dev[i] = terminal observation for finished envs, done) of env i goes to ring slot (ptr + i - first) mod capacity,
+ * first = max(0, n_envs - capacity) (deque(maxlen): only the newest `capacity` rows survive; envs below `first` are
+ * not stored).  Ring layout as mn_replay_append.  prev_obs_dev and obs_dev must be different buffers.  The caller
+ * advances ptr by min(n_envs, capacity). */
+int mn_step_append(mn_handle *h, const int32_t *actions_dev, const float *prev_obs_dev, float *obs_dev, float *reward_dev,
+                   uint8_t *done_dev, uint8_t *info_dev, float *ring_states, float *ring_next_states,
+                   int64_t *ring_actions, float *ring_rewards, float *ring_dones, int64_t ptr, int64_t capacity,
+                   void *stream);
+
 /* The caller-side `if done: state = train_env.reset()` (thirdparty/IQN/agent.py:152-170), batched:
  * resets exactly the envs the LAST mn_step flagged done and overwrites their rows of obs_dev
  * (which may or may not be the buffer given to mn_step). */
@@ -170,6 +186,12 @@ int mn_get_obs64(mn_handle *h, int32_t first_env, int32_t count, double *out);
 /* Float64 copy of the last reward (marinenav_env.py:220-255 computes it in float64); same rule. */
 int mn_get_reward64(mn_handle *h, int32_t first_env, int32_t count, double *out);
 
+/* robot.trajectory (marinenav_env.py:211-212: one [x, y] per kinematic SUB-step): after mn_enable_trajectory(h, max_N)
+ * every mn_step also records the N sub-step positions of each env; mn_get_trajectory copies out[count][n_substeps][2]
+ * of the LAST step.  MN_PRECISION_F64 handles only (the facade / evaluation path); off by default. */
+int mn_enable_trajectory(mn_handle *h, int32_t max_substeps);
+int mn_get_trajectory(mn_handle *h, int32_t first_env, int32_t count, int32_t n_substeps, double *out);
+
 /* Next double each env's RandomState would return, without consuming it (test hook pinning the
  * RNG stream position; cf. np.random.RandomState.random_sample). */
 int mn_peek_next_double(mn_handle *h, int32_t first_env, int32_t count, double *out);
@@ -183,7 +205,19 @@ int mn_profile_begin(mn_handle *h, int32_t max_launches);
 int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
 
 /* ---- IQN inference ---------------------------------------------------------------------------
- * Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
+ * Context of one acting agent (the counterpart of holding an `IQNAgent`, thirdparty/IQN/agent.py:10-84): owns the
+ * permuted copy of the network weights the act kernel stages into LDS, and the profiling events.  The copy is CACHED:
+ * it is rebuilt by the first act call after mn_iqn_create and by the first act call after mn_iqn_weights_changed, which
+ * the caller invokes whenever the weights behind the `weights` pointers were written (an optimizer step, a checkpoint
+ * load, soft_update into this network).  Calls that share a context must be stream-ordered; different contexts are
+ * independent (two agents may act concurrently on two streams of one device).  A context is bound to the HIP device
+ * that was current at mn_iqn_create; act calls made while another device is current return MN_ERR_INVALID. */
+typedef struct mn_iqn_ctx mn_iqn_ctx;
+int mn_iqn_create(mn_iqn_ctx **out);
+int mn_iqn_destroy(mn_iqn_ctx *c);
+int mn_iqn_weights_changed(mn_iqn_ctx *c);
+
+/* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
  * K = 32 quantile samples + mean over them (model.py:141-191), then argmax and the epsilon-greedy choice.
  *   obs_dev   [n][26] f32 : observations (row-major, as mn_step writes them)
  *   taus_dev  [n][32] f32 : quantile fractions, already multiplied by cvar (model.py:149-153)
@@ -191,24 +225,26 @@ int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launche
  *                           velocity_encoder.weight [16][2], .bias [16], goal_encoder.weight [16][2], .bias [16],
  *                           sensor_encoder.weight [176][22], .bias [176], cos_embedding.weight [208][64], .bias [208],
  *                           hidden_layer.weight [64][208], .bias [64], hidden_layer_2.weight [64][64], .bias [64],
- *                           output_layer.weight [9][64], .bias [9].  Read on every call (they change while training).
+ *                           output_layer.weight [9][64], .bias [9].  Read only when the cached image is stale.
  *   qvals_dev [n][9] f32  : mean over taus of the quantile values (may be NULL)
  *   explore_u_dev [n] f32 : uniform [0,1) draws for exploration (may be NULL = greedy); env i takes the
  *                           greedy action iff u_i > eps (agent.py:200), else action floor(u_i / eps * 9)
  *   actions_dev [n] i32   : chosen actions (may be NULL if only Q-values are wanted)
- * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32.  The permuted weight image is a per-device scratch buffer
- * rebuilt by every call: calls for the same device must be stream-ordered (one stream, or serialised by events). */
-int mn_iqn_act(const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
-               const float *explore_u_dev, float eps, int32_t *actions_dev, int32_t n, int32_t num_taus, void *stream);
+ *   quantiles_dev [n][32][9] f32 : IQNAgent.act_eval's `quantiles` (agent.py:217-236; model.py:185 before the mean), or
+ *                           NULL.  When given, the output layer runs per tau and Q is the mean of these values.
+ * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32. */
+int mn_iqn_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
+               const float *explore_u_dev, float eps, int32_t *actions_dev, float *quantiles_dev, int32_t n,
+               int32_t num_taus, void *stream);
 
-/* Same act kernel, with the random numbers of the call drawn by the library in the SAME launch that builds the weight
- * image (no separate generator kernels): draws_dev [33 n] f32 (caller-owned scratch) receives tau[e][j] = U[0,1) * cvar
- * (cvar_row_dev[e] if given, else the scalar `cvar`; model.py:149-153) in its first 32 n entries and the exploration
- * uniforms of agent.py:199 in the last n; the act kernel then consumes them.  Counter-based generator keyed by
+/* Same act kernel, with the random numbers of the call drawn by the library (no separate generator kernels):
+ * draws_dev [33 n] f32 (caller-owned scratch) receives tau[e][j] = U[0,1) * cvar (cvar_row_dev[e] if given, else the
+ * scalar `cvar`; model.py:149-153) in its first 32 n entries -- act_eval's `taus` -- and the exploration uniforms of
+ * agent.py:199 in the last n; the act kernel then consumes them.  Counter-based generator keyed by
  * rng_state_dev = u64[2] {seed, call counter} on the device; the counter is advanced by the call. */
-int mn_iqn_act_rng(const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev, float *draws_dev,
-                   const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev, float *qvals_dev, int32_t n,
-                   int32_t num_taus, void *stream);
+int mn_iqn_act_rng(mn_iqn_ctx *c, const float *obs_dev, const float *const *weights, uint64_t *rng_state_dev,
+                   float *draws_dev, const float *cvar_row_dev, float cvar, float eps, int32_t *actions_dev,
+                   float *qvals_dev, float *quantiles_dev, int32_t n, int32_t num_taus, void *stream);
 
 /* ---- replay ring ------------------------------------------------------------------------------
  * ReplayBuffer.add (thirdparty/IQN/replay_buffer.py:26-34) for n transitions in one launch: batch row i
@@ -253,9 +289,10 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
 int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
                       int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
 
-/* Benchmark hook: HIP events on the launch stream around the next mn_iqn_act launches. */
-int mn_iqn_profile_begin(int32_t max_launches);
-int mn_iqn_profile_end(void *stream, double *mean_ms, int32_t *launches);
+/* Benchmark hook: HIP events on the launch stream around the next act launches of this context (weight / random-number
+ * preparation launch included). */
+int mn_iqn_profile_begin(mn_iqn_ctx *c, int32_t max_launches);
+int mn_iqn_profile_end(mn_iqn_ctx *c, void *stream, double *mean_ms, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,11 @@ Outputs (all small, committed):
   g8_boundary_trace.npz set_boundary = True, robot.N = 5 trace (run_experiments.py settings)
   g9_planners.npz       APF / BA baseline actions for 2304 observations
   pretrained_IQN_seed3/ checkpoint data files shipped by the reference (weights only)
+  g12_replay.npz        the reference ReplayBuffer: 1500 adds into maxlen 1000, contents, one sample()
+  g13_learn_loop.npz    bookkeeping of the reference IQNAgent.learn loop over 400 timesteps on the reference env
+  g14_iqn_episodes.npz  run_experiments.py's evaluation_IQN loop on the reference env + pretrained agent, injected taus:
+                        per-step action / CVaR / quantiles / taus, per-episode outcome and trajectory
+  (g10 / g11: make_golden_dqn.py)
 """
 import contextlib
 import io
@@ -506,8 +511,178 @@ def g7_iqn():
     np.savez_compressed(os.path.join(OUT, "g7_iqn.npz"), **out)
 
 
+def _import_iqn():
+    th = types.ModuleType("thirdparty"); th.__path__ = [os.path.join(REF, "thirdparty")]
+    iq = types.ModuleType("thirdparty.IQN"); iq.__path__ = [os.path.join(REF, "thirdparty/IQN")]
+    sys.modules["thirdparty"] = th; sys.modules["thirdparty.IQN"] = iq
+    from thirdparty.IQN.agent import IQNAgent
+    from thirdparty.IQN.replay_buffer import ReplayBuffer
+    return IQNAgent, ReplayBuffer
+
+
+def g12_replay():
+    """The reference's ReplayBuffer (thirdparty/IQN/replay_buffer.py:6-59): 1500 adds into maxlen 1000, the deque
+    contents afterwards (oldest -> newest), and what sample() returns (shapes, dtypes, which rows)."""
+    _, ReplayBuffer = _import_iqn()
+    rng = np.random.RandomState(12)
+    n, cap, B = 1500, 1000, 32
+    states = rng.normal(0, 5, size=(n, 26))
+    nexts = rng.normal(0, 5, size=(n, 26))
+    actions = rng.randint(9, size=n)
+    rewards = rng.normal(0, 3, size=n)
+    dones = rng.uniform(size=n) < 0.2
+    buf = ReplayBuffer(cap, B, "cpu", seed=5, gamma=0.99)
+    sizes = []
+    for i in range(n):
+        buf.add(states[i], int(actions[i]), float(rewards[i]), nexts[i], bool(dones[i]))
+        sizes.append(len(buf))
+    mem = list(buf.memory)
+    out = dict(in_states=states, in_next=nexts, in_actions=actions, in_rewards=rewards, in_dones=dones,
+               capacity=np.array(cap), batch=np.array(B), sizes=np.array(sizes),
+               mem_states=np.stack([e.state for e in mem]), mem_next=np.stack([e.next_state for e in mem]),
+               mem_actions=np.array([e.action for e in mem]), mem_rewards=np.array([e.reward for e in mem]),
+               mem_dones=np.array([e.done for e in mem]))
+    s, a, r, ns, d = buf.sample()
+    out.update(sample_states=s.numpy(), sample_actions=a.numpy(), sample_rewards=r.numpy(), sample_next=ns.numpy(),
+               sample_dones=d.numpy())
+    for k in ("sample_states", "sample_actions", "sample_rewards", "sample_next", "sample_dones"):
+        out[k + "_dtype"] = np.array(str(out[k].dtype))
+    np.savez_compressed(os.path.join(OUT, "g12_replay.npz"), **out)
+
+
+def g13_learn_loop():
+    """The reference's IQNAgent.learn (thirdparty/IQN/agent.py:94-173) run on the reference env for 400 timesteps:
+    the trajectory-independent bookkeeping of the loop -- counters, at which learning steps train() / soft_update() /
+    evaluation() fire, what the evaluation npz records -- for the drop-in loop to reproduce."""
+    import tempfile
+    import torch
+    IQNAgent, _ = _import_iqn()
+    cfg = dict(total_timesteps=400, learning_starts=100, eval_freq=150, target_update_interval=64, UPDATE_EVERY=4,
+               BATCH_SIZE=32, BUFFER_SIZE=1000, seed=3, env_seed=11)
+    torch.manual_seed(0)
+    agent = IQNAgent(26, 9, BATCH_SIZE=cfg["BATCH_SIZE"], BUFFER_SIZE=cfg["BUFFER_SIZE"], UPDATE_EVERY=cfg["UPDATE_EVERY"],
+                     learning_starts=cfg["learning_starts"], target_update_interval=cfg["target_update_interval"],
+                     seed=cfg["seed"])
+    train_env = MarineNavEnv(seed=cfg["env_seed"])
+    eval_env = MarineNavEnv(seed=348)
+    eval_env.reset_start_and_goal = False
+    eval_env.start = np.array([5.0, 5.0]); eval_env.goal = np.array([45.0, 45.0])
+    eval_config = {}
+    for i, (nc, no) in enumerate(((4, 6), (8, 10))):
+        eval_env.num_cores, eval_env.num_obs = nc, no
+        quiet(eval_env.reset)
+        eval_config[f"env_{i}"] = eval_env.episode_data()
+    log = dict(train_at=[], train_mem=[], sync_at=[], eval_at=[], eval_ts=[], resets=0)
+    real_train, real_sync, real_eval, real_reset = agent.train, agent.soft_update, agent.evaluation, train_env.reset
+
+    def train(exp):
+        log["train_at"].append(agent.learning_timestep); log["train_mem"].append(len(agent.memory))
+        return real_train(exp)
+
+    def sync(a, b):
+        log["sync_at"].append(agent.learning_timestep)
+        return real_sync(a, b)
+
+    def evaluation(env, eval_config, greedy=True, eval_log_path=None):
+        log["eval_at"].append((agent.learning_timestep, int(greedy))); log["eval_ts"].append(agent.current_timestep)
+        return real_eval(env, eval_config=eval_config, greedy=greedy, eval_log_path=eval_log_path)
+
+    def reset():
+        log["resets"] += 1
+        return real_reset()
+
+    agent.train, agent.soft_update, agent.evaluation, train_env.reset = train, sync, evaluation, reset
+    # third numpy-2 shim: agent.py:390 hands np.savez ragged python lists (per-episode action sequences), which numpy < 1.24
+    # turned into object arrays silently and numpy 2 refuses
+    real_savez = np.savez
+
+    def savez(file, **kw):
+        fixed = {}
+        for k, v in kw.items():
+            try:
+                fixed[k] = np.asanyarray(v)
+            except ValueError:
+                fixed[k] = np.array(v, dtype=object)
+        return real_savez(file, **fixed)
+
+    np.savez = savez
+    with tempfile.TemporaryDirectory() as tmp:
+        quiet(agent.learn, total_timesteps=cfg["total_timesteps"], train_env=train_env, eval_env=eval_env,
+              eval_config=eval_config, eval_freq=cfg["eval_freq"], eval_log_path=tmp, verbose=False)
+        files = sorted(os.listdir(tmp))
+        zg = np.load(os.path.join(tmp, "greedy_evaluations.npz"), allow_pickle=True)
+        za = np.load(os.path.join(tmp, "adaptive_evaluations.npz"), allow_pickle=True)
+        out = dict(npz_keys=np.array(sorted(zg.files)), greedy_timesteps=zg["timesteps"], adaptive_timesteps=za["timesteps"],
+                   greedy_rewards_shape=np.array(zg["rewards"].shape), greedy_successes_shape=np.array(zg["successes"].shape))
+    np.savez = real_savez
+    out.update(files=np.array(files), current_timestep=np.array(agent.current_timestep),
+               learning_timestep=np.array(agent.learning_timestep), train_at=np.array(log["train_at"]),
+               train_mem=np.array(log["train_mem"]), sync_at=np.array(log["sync_at"]), eval_at=np.array(log["eval_at"]),
+               eval_ts=np.array(log["eval_ts"]), memory_len=np.array(len(agent.memory)),
+               env_total_timesteps=np.array(train_env.total_timesteps), train_resets=np.array(log["resets"]),
+               eval_config=np.array(json.dumps(eval_config)), cfg=np.array(json.dumps(cfg)))
+    np.savez_compressed(os.path.join(OUT, "g13_learn_loop.npz"), **out)
+
+
+def g14_iqn_episodes():
+    """run_experiments.py's evaluation_IQN loop (:19-72) restated around the reference's own env and agent
+    (act_eval / act_adaptive_eval, pretrained seed_3 checkpoint) under exp_setup_5 (:192-211), with the taus of every
+    act call injected from a seeded stream: per step the action, CVaR level, quantiles [1,32,9], taus [1,32,1]; per
+    episode the outcome and episode_data()."""
+    import torch
+    IQNAgent, _ = _import_iqn()
+    agent = IQNAgent(26, 9, seed=2)
+    agent.load_model(os.path.join(REF, "pretrained_models/IQN/seed_3"), "cpu")
+    real_rand = torch.rand
+    out = {}
+    for name, adaptive, cvar in (("adaptive", True, None), ("cvar0.5", False, 0.5), ("cvar1.0", False, 1.0)):
+        env = MarineNavEnv(seed=15)
+        env.reset_start_and_goal = False; env.random_reset_state = False; env.set_boundary = True
+        env.obs_r_range = [1, 3]; env.start = np.array([5.0, 5.0]); env.goal = np.array([45.0, 45.0])
+        env.robot.N = 5; env.num_cores, env.num_obs = 6, 8
+        rng = np.random.RandomState(77)
+        obs = env.reset()
+        if name == "adaptive":
+            c, o, n1, n2 = world_arrays(env)
+            out.update(world_cores=c[:n1], world_obs=o[:n2], obs0=obs)
+        rec = dict(actions=[], cvars=[], quantiles=[], taus=[], taus_in=[], obs=[])
+        length, done, ret, energy = 0, False, 0.0, 0.0
+        while not done and length < 1000:
+            t_in = rng.uniform(size=(1, 32)).astype(np.float32)
+            torch.rand = lambda *shape, **kw: torch.from_numpy(t_in.copy())
+            try:
+                if adaptive:
+                    (action, quantiles, taus), cv = agent.act_adaptive_eval(obs)
+                else:
+                    action, quantiles, taus = agent.act_eval(obs, cvar=cvar)
+                    cv = cvar
+            finally:
+                torch.rand = real_rand
+            rec["obs"].append(obs); rec["taus_in"].append(t_in[0]); rec["actions"].append(int(action)); rec["cvars"].append(cv)
+            rec["quantiles"].append(quantiles); rec["taus"].append(taus)
+            obs, reward, done, info = env.step(int(action))
+            ret += env.discount ** length * reward
+            length += 1
+            energy += env.robot.compute_action_energy_cost(int(action))
+        ep = env.episode_data()
+        for k, v in rec.items():
+            out[f"{name}_{k}"] = np.array(v)
+        out[f"{name}_success"] = np.array(info["state"] == "reach goal"); out[f"{name}_out_of_area"] = np.array(info["state"] == "out of boundary")
+        out[f"{name}_time"] = np.array(env.robot.dt * env.robot.N * length); out[f"{name}_energy"] = np.array(energy)
+        out[f"{name}_return"] = np.array(ret)
+        out[f"{name}_trajectory"] = np.array(ep["robot"]["trajectory"])
+        out[f"{name}_ep_keys"] = np.array(json.dumps({"env": sorted(ep["env"].keys()), "robot": sorted(ep["robot"].keys())}))
+    np.savez_compressed(os.path.join(OUT, "g14_iqn_episodes.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14"]
+    if "g12" in which:
+        g12_replay()
+    if "g13" in which:
+        g13_learn_loop()
+    if "g14" in which:
+        g14_iqn_episodes()
     if "g1" in which:
         g1_reset(); g1b_eval_worlds()
     if "g2" in which:

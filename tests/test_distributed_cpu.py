@@ -1,5 +1,5 @@
 """World-size-2 gloo tests (CPU) of the N>1 path: the flat-bucket gradient all-reduce of the shared
-learner, and the env-shard index arithmetic."""
+learner, and the env-shard seeding rule (the fused HIP step under a process group: tests/test_multigpu_paths_gpu.py)."""
 import os
 import socket
 
@@ -62,10 +62,26 @@ def test_shared_learner_allreduce_equals_big_batch(tmp_path):
     np.testing.assert_allclose(res["params"].numpy(), flat.numpy(), rtol=0, atol=2e-6)
 
 
-def test_shard_seed_arithmetic():
-    """Rank r owns global env indices [r*n, (r+1)*n): its default seeds are that slice of a 1-GPU run."""
-    n, world, base = 8, 4, 5
-    full = (np.arange(n * world, dtype=np.uint64) + np.uint64(base)) & np.uint64(0xFFFFFFFF)
+def test_shard_seeds_tile_the_single_gpu_run():
+    """`shard_seeds` (the function VecMarineNavEnv seeds its envs with): rank r of `world` ranks with
+    first_index = r * n gets exactly rows [r n, (r+1) n) of the one-GPU seed vector -- for BASELINE configs[3]'s
+    524 288 = 8 x 65 536 split, for a ragged last shard, and across the 2^32 wrap of RandomState's seed range."""
+    import pytest
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import shard_seeds
+    n, world = 65536, 8
+    full = shard_seeds(n * world, seed=0)
+    assert full.dtype == np.uint32 and full[0] == 0 and full[-1] == n * world - 1
     for r in range(world):
-        shard = (np.arange(n, dtype=np.uint64) + np.uint64(base) + np.uint64(r * n)) & np.uint64(0xFFFFFFFF)
-        assert np.array_equal(shard, full[r * n:(r + 1) * n])
+        assert np.array_equal(shard_seeds(n, seed=0, first_index=r * n), full[r * n:(r + 1) * n])
+    # base seed offsets every env; shards still tile
+    full = shard_seeds(1000, seed=348)
+    parts = [shard_seeds(m, seed=348, first_index=f) for f, m in ((0, 300), (300, 300), (600, 400))]
+    assert np.array_equal(np.concatenate(parts), full) and full[0] == 348
+    # wrap-around at 2^32
+    w = shard_seeds(8, seed=(1 << 32) - 3)
+    assert list(w) == [4294967293, 4294967294, 4294967295, 0, 1, 2, 3, 4]
+    assert np.array_equal(shard_seeds(4, seed=(1 << 32) - 3, first_index=4), w[4:])
+    with pytest.raises(ValueError):
+        shard_seeds(0)
+    with pytest.raises(ValueError):
+        shard_seeds(4, first_index=-1)

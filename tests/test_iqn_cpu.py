@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent, calculate_huber_loss
@@ -48,6 +49,19 @@ def test_train_step_loss_grads_and_update():
     for k, p in agent.qnetwork_local.named_parameters():
         np.testing.assert_allclose(p.grad.numpy(), Z["grad_" + k], rtol=1e-4, atol=1e-6, err_msg=k)   # clipped grads
         np.testing.assert_allclose(p.detach().numpy(), Z["after_" + k], rtol=0, atol=2e-6, err_msg=k)  # after Adam
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+def test_adjust_cvar_batch_matches_reference(device):
+    """adjust_cvar (agent.py:249-267) for a batch of states, on CPU tensors and -- under -m gpu -- on the device, against
+    the reference agent's own values (G7 `cvar_states` / `cvar_values`: no-return, sub-millimetre and regular cases)."""
+    if device != "cpu" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ag = IQNAgent(26, 9, seed=0, BUFFER_SIZE=64, device=device)
+    cvb = ag.adjust_cvar_batch(torch.from_numpy(Z["cvar_states"]).float().to(device)).cpu().numpy()
+    np.testing.assert_allclose(cvb, Z["cvar_values"], rtol=1e-6, atol=1e-6)
+    cv64 = ag.adjust_cvar_batch(torch.from_numpy(Z["cvar_states"]).to(device)).cpu().numpy()      # float64 states: exact rule
+    np.testing.assert_allclose(cv64, Z["cvar_values"], rtol=0, atol=1e-15)
 
 
 def test_huber_cvar_eps_energy_tables():
