@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--update-every", type=int, default=4, help="vector steps between training events (UPDATE_EVERY; SURVEY 8d C3: 4)")
     ap.add_argument("--grad-steps", type=int, default=1, help="gradient steps per training event (1 = the reference's cadence)")
     ap.add_argument("--eps", type=float, default=None, help="fixed exploration rate (default: the reference's linear schedule at the start of training, ~1.0)")
+    ap.add_argument("--rollout", type=int, default=0, metavar="T",
+                    help="with --no-learner: T vector steps per launch through mn_rollout (in-kernel random actions and resets); "
+                         "--steps must be a multiple of T.  0 = one mn_step + mn_reset_done launch pair per vector step")
+    ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
 
@@ -139,7 +143,8 @@ def main():
 
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
-    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed", step_lanes=args.lanes)
+    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed", step_lanes=args.lanes,
+                          rollout_lanes=args.lanes)
     env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
     obs = env.reset()
     agent = None
@@ -184,14 +189,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        obs = one_step(obs)
+    roll = args.rollout if (agent is None and args.rollout > 0) else 0
+    if roll and (args.steps % roll or args.warmup % roll):
+        raise SystemExit(f"--rollout {roll}: --steps and --warmup must be multiples of it")
+    trace = tuple(k for k in args.rollout_trace.split(",") if k)
+    step_ctr = [0]
+
+    def run_steps(k, o):
+        if not roll:
+            for _ in range(k):
+                o = one_step(o)
+            return o
+        for _ in range(k // roll):      # k vector steps as k / T launches of T steps each
+            env.rollout(roll, action_seed=rank, first_step=step_ctr[0], trace=trace)
+            step_ctr[0] += roll
+        return env.obs
+
+    obs = run_steps(args.warmup, obs)
     g0 = agent.grad_steps if agent else 0
     fence()
     # HIP-event pairs are recorded around the first n_prof act / step launches of the timed region; not around all of
     # them, because the four event records per vector step cost ~18 us of stream time (measured: 1.079 ms/step with
     # 200 instrumented steps, 1.067 with 50, 1.061 with 1) -- `launches_timed` in the roofline objects says how many
-    n_prof = min(args.steps, int(os.environ.get("MN_BENCH_NPROF", "50")))
+    n_prof = min(args.steps // max(1, roll), int(os.environ.get("MN_BENCH_NPROF", "50")))
     env.profile_begin(n_prof)
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
@@ -200,8 +220,7 @@ def main():
         from distributional_rl_navigation_amd.iqn.fused_act import act_context
         act_context(agent.qnetwork_local).profile_begin(n_prof)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        obs = one_step(obs)
+    obs = run_steps(args.steps, obs)
     fence()
     elapsed = time.perf_counter() - t0
     step_kernel_ms, launches = env.profile_end()
@@ -239,7 +258,9 @@ def main():
     if rank == 0:
         env_steps = n * world * args.steps
         bytes_per = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
-        achieved = bytes_per * n / (step_kernel_ms * 1e-3) / 1e9 if step_kernel_ms > 0 else 0.0
+        # one launch processes n env-steps (single step) or n * T env-steps (mn_rollout)
+        per_launch = n * max(1, roll)
+        achieved = bytes_per * per_launch / (step_kernel_ms * 1e-3) / 1e9 if step_kernel_ms > 0 else 0.0
         out = {
             "metric": "env steps/sec (whole node) at 65 536 envs; IQN grad-steps/sec",
             "value": env_steps / elapsed,
@@ -255,7 +276,8 @@ def main():
             "dtype_detail": "IQN act / train: f32 (exact-f32 MFMA); env kernels: f64 pose integration + f64 sonar geometry, f32 field",
             "data": "synthetic (seeded random worlds, random-init IQN)",
             "config": {
-                "workload": ("step kernel only, random policy" if agent is None else
+                "workload": ((f"step kernel only, random policy, {roll} vector steps per launch (mn_rollout: in-kernel actions + resets, traces: {','.join(trace) or 'none'})"
+                              if roll else "step kernel only, random policy, one mn_step + mn_reset_done launch pair per vector step") if agent is None else
                              f"{n} envs/GPU + IQN training (act K=32, 8 quantiles, replay {args.replay}, batch {args.batch}, "
                              f"{args.grad_steps} grad step(s) every {args.update_every} vector steps)"),
                 "envs_per_gpu": n, "n_cores": args.cores, "n_obstacles": args.obstacles,
@@ -273,7 +295,8 @@ def main():
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             "roofline_env_step": {
-                "kernel": "mn_step_kernel<float,false,L>",
+                "kernel": "mn_rollout_kernel<float,false,L>" if roll else "mn_step_kernel<float,false,L>",
+                "env_steps_per_launch": per_launch,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -284,7 +307,7 @@ def main():
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "launch_ms": step_kernel_ms,
                 "launches_timed": launches,
-                "kernel_only_env_steps_per_sec": n / (step_kernel_ms * 1e-3) if step_kernel_ms > 0 else None,
+                "kernel_only_env_steps_per_sec": per_launch / (step_kernel_ms * 1e-3) if step_kernel_ms > 0 else None,
             },
         }
         if fused and act_ms > 0:

@@ -26,7 +26,7 @@ class MnParams(C.Structure):
         ("sonar_angle", C.c_double), ("num_cores", C.c_int32), ("num_obs", C.c_int32),
         ("reset_start_and_goal", C.c_int32), ("random_reset_state", C.c_int32), ("set_boundary", C.c_int32),
         ("max_episode_steps", C.c_int32), ("N", C.c_int32), ("num_beams", C.c_int32), ("precision", C.c_int32),
-        ("step_lanes", C.c_int32),
+        ("step_lanes", C.c_int32), ("rollout_lanes", C.c_int32),
     ]
 
 
@@ -63,6 +63,8 @@ SIGNATURES = [
     ("mn_step", C.c_int, [_vp, _vp, _pf, _pf, _pu8, _pu8, _vp]),
     ("mn_step_append", C.c_int, [_vp, _vp, _pf, _pf, _pf, _pu8, _pu8, _pf, _pf, _vp, _pf, _pf, _i64, _i64, _vp]),
     ("mn_build_info", _i32, []),
+    ("mn_rollout", C.c_int, [_vp, _i32, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _pf, _pf, _pf, _pu8, _pu8, _vp, _vp]),
+    ("mn_random_actions", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, _i32, _vp, _vp]),
     ("mn_reset_done", C.c_int, [_vp, _pf, _vp]),
     ("mn_load_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _pf, _vp]),
     ("mn_get_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd]),

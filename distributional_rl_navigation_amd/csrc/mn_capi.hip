@@ -87,6 +87,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     if (p.N < 1 || p.N > 1000) return fail(h, MN_ERR_INVALID, "robot N out of range");
     if (p.precision != MN_PRECISION_F64 && p.precision != MN_PRECISION_MIXED) return fail(h, MN_ERR_INVALID, "bad precision");
     if (p.step_lanes != 0 && p.step_lanes != 1 && p.step_lanes != 2 && p.step_lanes != 4 && p.step_lanes != 8) return fail(h, MN_ERR_INVALID, "step_lanes must be 0 (default), 1, 2, 4 or 8");
+    if (p.rollout_lanes != 0 && p.rollout_lanes != 1 && p.rollout_lanes != 2 && p.rollout_lanes != 4 && p.rollout_lanes != 8) return fail(h, MN_ERR_INVALID, "rollout_lanes must be 0 (default), 1, 2, 4 or 8");
     MnDev &d = h->P;
     const int32_t keep_n = d.n_stages;
     d.width = p.width; d.height = p.height; d.core_r = p.core_r; d.v_rel_max = p.v_rel_max; d.p = p.p;
@@ -313,6 +314,33 @@ extern "C" int mn_step_append(mn_handle *h, const int32_t *actions_dev, const fl
     if (capacity <= 0 || ptr < 0 || ptr >= capacity) return fail(h, MN_ERR_INVALID, "mn_step_append: ptr out of [0, capacity)");
     const MnRing R = {prev_obs_dev, ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, ptr, capacity};
     return step_common(h, actions_dev, obs_dev, reward_dev, done_dev, info_dev, &R, stream);
+}
+
+extern "C" int mn_rollout(mn_handle *h, int32_t n_steps, const int32_t *actions_dev, uint64_t action_seed,
+                          uint64_t first_step_index, uint64_t first_env_index, float *obs_dev, float *obs_trace_dev,
+                          float *reward_trace_dev, uint8_t *done_trace_dev, uint8_t *info_trace_dev,
+                          int32_t *action_trace_dev, void *stream) {
+    if (!h || !obs_dev || n_steps < 1) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    const bool prof = h->prof_n < h->prof_max;
+    if (prof) (void)hipEventRecord(h->ev[2 * h->prof_n], s);
+    mn_launch_rollout(h->A, h->P, h->params.precision, h->params.rollout_lanes, n_steps, actions_dev, action_seed, first_step_index,
+                      first_env_index, obs_dev, obs_trace_dev, reward_trace_dev, done_trace_dev, info_trace_dev,
+                      action_trace_dev, s);
+    if (prof) { (void)hipEventRecord(h->ev[2 * h->prof_n + 1], s); h->prof_n++; }
+    MN_HIP(h, hipGetLastError());
+    // the kernel zeroed both done-queue counters: a following mn_reset_done has nothing to do, the next mn_step starts clean
+    h->step_parity = 0;
+    h->last_parity = 0;
+    return MN_OK;
+}
+
+extern "C" int mn_random_actions(uint64_t action_seed, uint64_t step_index, uint64_t first_env_index, int32_t n,
+                                 int32_t *actions_dev, void *stream) {
+    if (!actions_dev || n <= 0) return MN_ERR_INVALID;
+    mn_launch_random_actions(action_seed, step_index, first_env_index, n, actions_dev, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 
 extern "C" int32_t mn_build_info(void) {

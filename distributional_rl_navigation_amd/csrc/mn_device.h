@@ -1,4 +1,11 @@
-// Device helpers shared by the step and reset kernels (gfx950).
+// Device helpers shared by the step, reset and rollout kernels (gfx950).
+//
+// Floating-point contract: every translation unit of the library is compiled with -ffp-contract=off and fused
+// multiply-adds are written out (fma / fmaf / __builtin_elementwise_fma) where the arithmetic wants them.  World
+// generation (mn_reset_body.h) uses none, so it rounds exactly like numpy's float64 arithmetic; the step arithmetic
+// (mn_step_body.h, the helpers below) is the same instruction-level expression in every kernel it is inlined into --
+// single step, step + replay append, multi-step rollout, any lanes-per-env mapping -- so all of them produce
+// bit-identical results (the compiler is never free to pick a different contraction in a different instantiation).
 #pragma once
 #include "mn_internal.h"
 
@@ -11,14 +18,14 @@ template <>
 struct MnMath<double> {
     static __device__ __forceinline__ double sqrt_(double v) { return sqrt(v); }
     static __device__ __forceinline__ double rcp(double v) { return 1.0 / v; }
-    static __device__ __forceinline__ void sincos_(double a, double *s, double *c) { sincos(a, s, c); }
+    static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
 };
 
 template <>
 struct MnMath<float> {
     static __device__ __forceinline__ float sqrt_(float v) { return __builtin_amdgcn_sqrtf(v); }
     static __device__ __forceinline__ float rcp(float v) { return __builtin_amdgcn_rcpf(v); }
-    static __device__ __forceinline__ void sincos_(float a, float *s, float *c) { sincosf(a, s, c); }
+    static __device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 };
 
 // One beam against one obstacle (robot.py:147-198 restated in ray-parametric form, SURVEY App. A
@@ -29,9 +36,9 @@ struct MnMath<float> {
 // in the perpendicular offset by r/h, which float32 cannot hold to 1e-5; the 5 f64 FMAs per pair are
 // cheaper than any float32 compensation.  Everything after h^2 runs in M.
 __device__ __forceinline__ void mn_beam_geom(double mrx, double mry, double r2, double bx, double by, double &tc, double &h2) {
-    tc = bx * mrx + by * mry;
-    const double perp = mrx * by - mry * bx;
-    h2 = r2 - perp * perp;
+    tc = fma(bx, mrx, by * mry);
+    const double perp = fma(mrx, by, -(mry * bx));
+    h2 = fma(-perp, perp, r2);
 }
 
 // Per-beam scan state: `dist` = accepted range (valid when hit), `limit` = what the next candidate
@@ -65,7 +72,7 @@ struct MnBeam {
     __device__ __forceinline__ double dist64() const {
         const float h0f = __builtin_amdgcn_sqrtf((float)ah2);
         double h = (double)h0f;
-        if (h0f > 0.f) h += (ah2 - h * h) * (0.5 * (double)__builtin_amdgcn_rcpf(h0f));
+        if (h0f > 0.f) h = fma(fma(-h, h, ah2), 0.5 * (double)__builtin_amdgcn_rcpf(h0f), h);
         return (M)atc > M(0) ? atc - h : atc + h;
     }
 };
@@ -75,14 +82,15 @@ struct MnBeam {
 // core and (-dy,dx)/d * Gamma d/(2 pi r^2) inside; signed Gamma carries the spin direction.
 // The two branches of compute_speed (:461-465) meet at d = r, and Gamma/(2 pi d^2) <= Gamma/(2 pi r^2)
 // exactly when d >= r, so the profile is min(1/(2 pi r^2), 1/(2 pi d^2)) -- one v_min instead of a
-// compare + select, and d = 0 stays finite.
+// compare + select, and d = 0 stays finite.  Returns the contribution (ux, uy) as two rounded products: the caller
+// adds the cores up in a FIXED balanced tree (mn_step_body.h), which is what makes the result independent of how
+// many lanes share an environment.
 template <typename M>
-__device__ __forceinline__ void mn_core_velocity(M dx, M dy, M gs, M r2, M inv_two_pi_r2, M inv_two_pi, M &vx, M &vy) {
-    (void)r2;
-    const M d2 = dx * dx + dy * dy;
+__device__ __forceinline__ void mn_core_velocity(M dx, M dy, M gs, M inv_two_pi_r2, M inv_two_pi, M &ux, M &uy) {
+    const M d2 = MnMath<M>::fma_(dx, dx, dy * dy);
     M f = inv_two_pi * MnMath<M>::rcp(d2);
     f = f < inv_two_pi_r2 ? f : inv_two_pi_r2;
     f *= gs;
-    vx -= dy * f;
-    vy += dx * f;
+    ux = -dy * f;
+    uy = dx * f;
 }

@@ -89,6 +89,10 @@ struct MnRing {
 // kernels (defined in mn_step.hip / mn_reset.hip)
 void mn_launch_step(const MnArrays &A, const MnDev &P, int precision, int lanes, const int32_t *actions, float *obs,
                     float *reward, uint8_t *done, uint8_t *info, int parity, const MnRing *ring, hipStream_t s);
+void mn_launch_rollout(const MnArrays &A, const MnDev &P, int precision, int lanes, int n_steps, const int32_t *actions_in,
+                       uint64_t seed, uint64_t step0, uint64_t env0, float *obs_out, float *obs_trace, float *reward_trace,
+                       uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s);
+void mn_launch_random_actions(uint64_t seed, uint64_t step, uint64_t env0, int n, int32_t *out, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
                      const int32_t *list_dev, int mode, float *obs, hipStream_t s);

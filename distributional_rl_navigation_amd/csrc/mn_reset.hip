@@ -1,143 +1,9 @@
-// mn_reset.hip -- world generation / episode reset kernel for gfx950 (MI355X).
-//
-// Replaces MarineNavEnv.reset (marinenav_env.py:86-186) incl. check_core (:344-383),
-// check_obstacle (:385-420), reset_robot (:188-197) and the first get_observation (:273-326),
-// drawing from each env's own numpy-compatible MT19937 stream in the reference's exact order.
-//
-// Mapping: ONE WAVEFRONT PER ENVIRONMENT (a reset is sequential rejection sampling with a
-// data-dependent number of draws, so lane-per-env would serialise ~10^2 dependent DRAM-latency
-// RNG reads per lane).  Instead the env's 624-word MT19937 block lives in LDS, is regenerated by
-// all 64 lanes (the recurrence has a 227-word dependency distance), and each rejection loop
-// evaluates up to 64 candidates at once: lane i builds candidate i from stream words
-// [i*w, (i+1)*w), static checks run in parallel, and the order-dependent part (a candidate must
-// be compatible with every EARLIER ACCEPTED one) is resolved with a ballot loop that runs at most
-// `count` iterations.  The number of words consumed is exactly that of the sequential reference,
-// so the stream position after a reset is bit-identical (pinned by tests against the reference's
-// eval_config.json).  Waves pull env indices from the done-queue written by the step kernel.
-//
-// This file is compiled with -ffp-contract=off: the generated tables must be bit-identical to
-// numpy's float64 arithmetic (no FMA contraction anywhere in world generation).
-#include "mn_device.h"
+// mn_reset.hip -- world generation / episode reset kernel for gfx950 (MI355X): one wavefront per finished environment
+// (mn_reset_env, mn_reset_body.h), env indices pulled from the done-queue the step kernel filled -- plus the small
+// kernels around the RNG streams (seeding, mask -> queue, peek).
+#include "mn_reset_body.h"
 
 namespace {
-
-#define MT_N 624
-#define MT_M 397
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-
-__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
-    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
-    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-// Per-wave RNG window in LDS.
-struct MtLds {
-    uint32_t key[MT_N];
-    uint32_t carry[8];
-};
-
-// Regenerate the block with all 64 lanes.  Element i needs OLD key[i], OLD key[i+1] and
-// key[(i+397)%624], which is old for i < 227 and NEW (= element i-227) afterwards; processing i in
-// increasing chunks of 64 keeps every read on the right side of the frontier because the only
-// same-chunk hazard (key[i+1]) is read before the chunk's stores are issued.
-__device__ __forceinline__ void mt_regenerate(MtLds &S, int lane) {
-    for (int base = 0; base < MT_N - 1; base += MN_WAVE) {
-        const int i = base + lane;
-        uint32_t v = 0;
-        const bool ok = i < MT_N - 1;
-        if (ok) {
-            const int j = i + MT_M < MT_N ? i + MT_M : i + MT_M - MT_N;
-            v = mt_twist(S.key[i], S.key[i + 1], S.key[j]);
-        }
-        __syncthreads();
-        if (ok) S.key[i] = v;
-        __syncthreads();
-    }
-    if (lane == 0) S.key[MT_N - 1] = mt_twist(S.key[MT_N - 1], S.key[0], S.key[MT_M - 1]);
-    __syncthreads();
-}
-
-struct MtCursor {
-    int pos;      // words of the current block already consumed (0..624)
-    int carry_n;  // words saved from the previous block that precede key[pos]
-};
-
-// Make at least `w` words available (w <= 8); returns how many whole w-word candidates can be
-// read without crossing into the next block (>= 1, capped at 64).
-__device__ __forceinline__ int mt_ensure(MtLds &S, MtCursor &c, int w, int lane) {
-    int avail = c.carry_n + (MT_N - c.pos);
-    if (avail < w) {
-        const int rem = MT_N - c.pos;
-        if (lane < rem) S.carry[c.carry_n + lane] = mt_temper(S.key[c.pos + lane]);
-        __syncthreads();
-        c.carry_n += rem;
-        mt_regenerate(S, lane);
-        c.pos = 0;
-        avail = c.carry_n + MT_N;
-    }
-    const int n = avail / w;
-    return n < MN_WAVE ? n : MN_WAVE;
-}
-
-__device__ __forceinline__ uint32_t mt_word(const MtLds &S, const MtCursor &c, int j) {
-    return j < c.carry_n ? S.carry[j] : mt_temper(S.key[c.pos + j - c.carry_n]);
-}
-
-// numpy legacy random_sample: 53-bit double from two words
-__device__ __forceinline__ double mt_double_at(const MtLds &S, const MtCursor &c, int j) {
-    const uint32_t a = mt_word(S, c, j) >> 5, b = mt_word(S, c, j + 1) >> 6;
-    return (a * 67108864.0 + b) / 9007199254740992.0;
-}
-
-__device__ __forceinline__ void mt_advance(MtCursor &c, int words) {
-    // every consumption is >= one candidate > carry_n words, so the carry is always drained
-    c.pos += words - c.carry_n;
-    c.carry_n = 0;
-}
-
-__device__ __forceinline__ double norm2d(double a, double b) { return sqrt(a * a + b * b); }
-
-// first set bit of a 64-bit ballot
-__device__ __forceinline__ int first_lane(unsigned long long m) { return __ffsll((long long)m) - 1; }
-
-// value of `v` in lane `src` (wave-uniform index) for every lane: two v_readlane_b32 instead of a
-// ds_bpermute round trip through the LDS crossbar
-__device__ __forceinline__ double bcast(double v, int src) {
-    const int s_ = __builtin_amdgcn_readfirstlane(src);
-    const long long b = __builtin_bit_cast(long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), s_);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), s_);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
-}
-
-struct WorldLds {
-    double cx[MN_MAX_CORES], cy[MN_MAX_CORES], cg[MN_MAX_CORES];  // cg signed: + clockwise
-    double ox[MN_MAX_OBS], oy[MN_MAX_OBS], orad[MN_MAX_OBS];
-    double beam[MN_NUM_BEAMS][2];
-};
-
-// check_core pairwise rule (marinenav_env.py:361-381); symmetric in (i, j)
-__device__ __forceinline__ bool cores_compatible(const MnDev &P, double xi, double yi, double gi, double xj, double yj,
-                                                 double gj) {
-    const double dx = xi - xj, dy = yi - yj;
-    const double dis = sqrt(dx * dx + dy * dy);
-    const double Gi = fabs(gi), Gj = fabs(gj);
-    if ((gi > 0.0) == (gj > 0.0)) {
-        const double bi = Gi / P.two_pi_vrel, bj = Gj / P.two_pi_vrel;
-        return !(dis < bi + bj);
-    }
-    const double Gl = Gi > Gj ? Gi : Gj, Gs = Gi < Gj ? Gi : Gj;
-    const double v1 = Gl / (P.two_pi * (dis - 2 * P.core_r));
-    const double v2 = Gs / (P.two_pi * P.core_r);
-    return !(v1 > P.p * v2);
-}
 
 template <typename M, bool PARITY>
 __global__ __launch_bounds__(MN_WAVE) void mn_reset_kernel(MnArrays A, MnDev P, const uint32_t *__restrict__ count_dev,
@@ -145,276 +11,9 @@ __global__ __launch_bounds__(MN_WAVE) void mn_reset_kernel(MnArrays A, MnDev P, 
                                                            float *__restrict__ obs_out) {
     __shared__ MtLds S;
     __shared__ WorldLds W;
-    const int lane = threadIdx.x;
     const uint32_t count = count_dev ? *count_dev : count_host;
-    const int np = A.npad;
-
-    for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x) {
-        const int e = list ? list[qi] : (int)qi;
-        __syncthreads();  // previous iteration's LDS readers are done
-        int nc = 0, no = 0;
-        double sx, sy, gx, gy, th0, sp0;
-
-        if (mode == 0) {
-            // ---- curriculum lookup (marinenav_env.py:89-98) -------------------------------------
-            int want_c = P.num_cores, want_o = P.num_obs;
-            double min_dis = P.min_start_goal_dis;
-            if (P.n_stages > 0) {
-                const int64_t tt = (int64_t)((double)A.tot_t[e] * P.timestep_scale);
-                int cntle = 0;
-                for (int i = 0; i < P.n_stages; ++i) cntle += (P.sched_t[i] - tt <= 0) ? 1 : 0;
-                int idx = cntle - 1;
-                if (idx < 0) idx += P.n_stages;  // python negative index
-                want_c = P.sched_nc[idx]; want_o = P.sched_no[idx]; min_dis = P.sched_md[idx];
-            }
-            want_c = want_c > MN_MAX_CORES ? MN_MAX_CORES : want_c;
-            want_o = want_o > MN_MAX_OBS ? MN_MAX_OBS : want_o;
-
-            // ---- RNG block into LDS --------------------------------------------------------------
-            for (int j = lane; j < MT_N; j += MN_WAVE) S.key[j] = A.mt[(size_t)e * MT_N + j];
-            MtCursor cur;
-            cur.pos = A.mt_pos[e];
-            cur.carry_n = 0;
-            __syncthreads();
-
-            // ---- start / goal (marinenav_env.py:111-127): keep the farthest pair, stop at the
-            // first pair farther apart than min_dis or after 500 tries -----------------------------
-            sx = A.start_x[e]; sy = A.start_y[e]; gx = A.goal_x[e]; gy = A.goal_y[e];
-            if (P.reset_start_and_goal) {
-                int tried = 0;
-                double best = 0.0;
-                for (;;) {
-                    int nb = mt_ensure(S, cur, 8, lane);
-                    nb = nb < 500 - tried ? nb : 500 - tried;
-                    const bool mine = lane < nb;
-                    double s0 = 0, s1 = 0, g0 = 0, g1 = 0, d = -1.0;
-                    if (mine) {
-                        s0 = P.sg_lo_x + P.sg_span_x * mt_double_at(S, cur, 8 * lane);
-                        s1 = P.sg_lo_y + P.sg_span_y * mt_double_at(S, cur, 8 * lane + 2);
-                        g0 = P.sg_lo_x + P.sg_span_x * mt_double_at(S, cur, 8 * lane + 4);
-                        g1 = P.sg_lo_y + P.sg_span_y * mt_double_at(S, cur, 8 * lane + 6);
-                        d = norm2d(g0 - s0, g1 - s1);
-                    }
-                    const unsigned long long over = __ballot(mine && d > min_dis);
-                    int pick, used;
-                    bool finished;
-                    if (over) {
-                        pick = first_lane(over); used = pick + 1; finished = true;
-                    } else {
-                        // first occurrence of the batch maximum
-                        double bm = d;
-                        int bl = lane;
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const double od = __shfl_xor(bm, off);
-                            const int ol = __shfl_xor(bl, off);
-                            if (od > bm || (od == bm && ol < bl)) { bm = od; bl = ol; }
-                        }
-                        pick = bm > best ? bl : -1;
-                        used = nb; finished = (tried + nb) >= 500;
-                    }
-                    if (pick >= 0) {
-                        best = bcast(d, pick);
-                        sx = bcast(s0, pick); sy = bcast(s1, pick); gx = bcast(g0, pick); gy = bcast(g1, pick);
-                    }
-                    tried += used;
-                    mt_advance(cur, 8 * used);
-                    if (finished) break;
-                }
-            }
-
-            // ---- vortex cores (marinenav_env.py:130-143, check_core :344-383) -------------------
-            if (want_c > 0) {
-                int tried = 0;
-                for (;;) {
-                    int nb = mt_ensure(S, cur, 8, lane);
-                    nb = nb < 500 - tried ? nb : 500 - tried;
-                    const bool mine = lane < nb;
-                    double x = 0, y = 0, g = 1.0;
-                    bool valid = false;
-                    if (mine) {
-                        x = 0.0 + P.c_span_x * mt_double_at(S, cur, 8 * lane);
-                        y = 0.0 + P.c_span_y * mt_double_at(S, cur, 8 * lane + 2);
-                        const bool clockwise = mt_double_at(S, cur, 8 * lane + 4) > P.binom_q;
-                        const double v_edge = P.v_lo + P.v_span * mt_double_at(S, cur, 8 * lane + 6);
-                        const double Gamma = P.two_pi_r * v_edge;
-                        g = clockwise ? Gamma : -Gamma;
-                        valid = !(x - P.core_r < 0.0 || x + P.core_r > P.width) &&
-                                !(y - P.core_r < 0.0 || y + P.core_r > P.width) /* sic: width (:349) */ &&
-                                !(norm2d(x - sx, y - sy) < P.core_r + P.clear_r) &&
-                                !(norm2d(x - gx, y - gy) < P.core_r + P.clear_r);
-                        for (int i = 0; i < nc && valid; ++i) valid = cores_compatible(P, W.cx[i], W.cy[i], W.cg[i], x, y, g);
-                    }
-                    int used = nb;
-                    for (;;) {
-                        const unsigned long long m = __ballot(valid);
-                        if (!m) break;
-                        const int j = first_lane(m);  // earliest still-valid candidate is accepted
-                        const double xj = bcast(x, j), yj = bcast(y, j), gj = bcast(g, j);
-                        if (lane == j) { W.cx[nc] = x; W.cy[nc] = y; W.cg[nc] = g; valid = false; }
-                        else if (valid && lane > j) valid = cores_compatible(P, xj, yj, gj, x, y, g);
-                        ++nc;
-                        if (nc == want_c) { used = j + 1; break; }
-                    }
-                    __syncthreads();
-                    tried += used;
-                    mt_advance(cur, 8 * used);
-                    if (nc == want_c || tried >= 500) break;
-                }
-            }
-
-            // ---- obstacles (marinenav_env.py:158-169, check_obstacle :385-420) ------------------
-            if (want_o > 0) {
-                int tried = 0;
-                for (;;) {
-                    int nb = mt_ensure(S, cur, 6, lane);
-                    nb = nb < 500 - tried ? nb : 500 - tried;
-                    const bool mine = lane < nb;
-                    double x = 0, y = 0, r = 0;
-                    bool valid = false;
-                    if (mine) {
-                        x = P.o_lo + P.o_span_x * mt_double_at(S, cur, 6 * lane);
-                        y = P.o_lo + P.o_span_y * mt_double_at(S, cur, 6 * lane + 2);
-                        r = P.or_lo + P.or_span * mt_double_at(S, cur, 6 * lane + 4);
-                        valid = !(x - r < 0.0 || x + r > P.width) && !(y - r < 0.0 || y + r > P.height) &&
-                                !(norm2d(x - sx, y - sy) < r + P.clear_r) && !(norm2d(x - gx, y - gy) < r + P.clear_r);
-                        for (int i = 0; i < nc && valid; ++i) {
-                            const double dx = W.cx[i] - x, dy = W.cy[i] - y;
-                            valid = !(sqrt(dx * dx + dy * dy) <= P.core_r + r);
-                        }
-                        for (int i = 0; i < no && valid; ++i) {
-                            const double dx = W.ox[i] - x, dy = W.oy[i] - y;
-                            valid = !(sqrt(dx * dx + dy * dy) <= W.orad[i] + r);
-                        }
-                    }
-                    int used = nb;
-                    for (;;) {
-                        const unsigned long long m = __ballot(valid);
-                        if (!m) break;
-                        const int j = first_lane(m);
-                        const double xj = bcast(x, j), yj = bcast(y, j), rj = bcast(r, j);
-                        if (lane == j) { W.ox[no] = x; W.oy[no] = y; W.orad[no] = r; valid = false; }
-                        else if (valid && lane > j) {
-                            const double dx = xj - x, dy = yj - y;
-                            valid = !(sqrt(dx * dx + dy * dy) <= rj + r);
-                        }
-                        ++no;
-                        if (no == want_o) { used = j + 1; break; }
-                    }
-                    __syncthreads();
-                    tried += used;
-                    mt_advance(cur, 6 * used);
-                    if (no == want_o || tried >= 500) break;
-                }
-            }
-
-            // ---- robot pose (marinenav_env.py:188-197) -------------------------------------------
-            if (P.random_reset_state) {
-                mt_ensure(S, cur, 4, lane);
-                th0 = 0.0 + (P.two_pi - 0.0) * mt_double_at(S, cur, 0);
-                sp0 = 0.0 + (P.max_speed - 0.0) * mt_double_at(S, cur, 2);
-                mt_advance(cur, 4);
-            } else {
-                th0 = P.init_theta; sp0 = P.init_speed;
-            }
-
-            // ---- write the world + RNG back ------------------------------------------------------
-            __syncthreads();
-            for (int j = lane; j < MT_N; j += MN_WAVE) A.mt[(size_t)e * MT_N + j] = S.key[j];
-            if (lane < MN_MAX_CORES) {
-                const bool v = lane < nc;
-                A.cx[lane * np + e] = v ? W.cx[lane] : 0.0;
-                A.cy[lane * np + e] = v ? W.cy[lane] : 0.0;
-                A.cg[lane * np + e] = v ? W.cg[lane] : 0.0;
-            }
-            if (lane < MN_MAX_OBS) {
-                const bool v = lane < no;
-                A.ox[lane * np + e] = v ? W.ox[lane] : 0.0;
-                A.oy[lane * np + e] = v ? W.oy[lane] : 0.0;
-                A.orad[lane * np + e] = v ? W.orad[lane] : 0.0;
-            }
-            if (lane == 0) {
-                A.mt_pos[e] = cur.pos;
-                A.counts[e] = nc | (no << 8);
-                A.start_x[e] = sx; A.start_y[e] = sy; A.goal_x[e] = gx; A.goal_y[e] = gy;
-                A.init_theta[e] = th0; A.init_speed[e] = sp0;
-            }
-        } else {
-            // pose-only reset of a loaded world (reset_with_eval_config, marinenav_env.py:467-555)
-            const int cnt = A.counts[e];
-            nc = cnt & 0xff; no = (cnt >> 8) & 0xff;
-            if (lane < nc) { W.cx[lane] = A.cx[lane * np + e]; W.cy[lane] = A.cy[lane * np + e]; W.cg[lane] = A.cg[lane * np + e]; }
-            if (lane < no) { W.ox[lane] = A.ox[lane * np + e]; W.oy[lane] = A.oy[lane * np + e]; W.orad[lane] = A.orad[lane * np + e]; }
-            sx = A.start_x[e]; sy = A.start_y[e]; gx = A.goal_x[e]; gy = A.goal_y[e];
-            th0 = A.init_theta[e]; sp0 = A.init_speed[e];
-        }
-        __syncthreads();
-
-        // compact tables for the mixed-precision step kernel (see MnArrays)
-        if (lane < MN_MAX_CORES) {
-            const bool v = lane < nc;
-            A.qcx[lane * np + e] = v ? __double2int_rn(W.cx[lane] * MN_FIX_SCALE) : 0;
-            A.qcy[lane * np + e] = v ? __double2int_rn(W.cy[lane] * MN_FIX_SCALE) : 0;
-            A.qcg[lane * np + e] = v ? (float)W.cg[lane] : 0.0f;
-        }
-        if (lane < MN_MAX_OBS) {
-            const bool v = lane < no;
-            A.qox[lane * np + e] = v ? __double2int_rn(W.ox[lane] * MN_FIX_SCALE) : 0;
-            A.qoy[lane * np + e] = v ? __double2int_rn(W.oy[lane] * MN_FIX_SCALE) : 0;
-            A.qor[lane * np + e] = v ? (float)W.orad[lane] : 0.0f;
-        }
-
-        // ---- Robot.reset_state (robot.py:79-87): velocity = steer + current(start) --------------
-        double cvx = 0.0, cvy = 0.0;
-        {
-            const double r2 = P.core_r * P.core_r, i1 = 1.0 / P.two_pi_r_r, i2 = 1.0 / P.two_pi;
-            for (int k = 0; k < nc; ++k)
-                mn_core_velocity<double>(W.cx[k] - sx, W.cy[k] - sy, W.cg[k], r2, i1, i2, cvx, cvy);
-        }
-        double sn, cs;
-        sincos(th0, &sn, &cs);
-        const double velx = sp0 * cs + cvx, vely = sp0 * sn + cvy;
-
-        // ---- first observation: beams across lanes ------------------------------------------------
-        if (lane < MN_NUM_BEAMS) {
-            const double angle = th0 + P.beam_rel[lane];
-            const bool up = fabs(angle - 0.5 * 3.141592653589793) < 1e-03;
-            const bool down = fabs(angle - 3 * 3.141592653589793 / 2) < 1e-03;
-            double bx = P.beam_cos[lane], by = P.beam_sin[lane];
-            if (up || down) {
-                const double sg = up ? 1.0 : -1.0;
-                bx = sg * sn; by = sg * cs;
-            }
-            MnBeam<M> beam;
-            beam.init();
-            for (int k = 0; k < no; ++k) {
-                const double mx = W.ox[k] - sx, my = W.oy[k] - sy;
-                double tc, h2;
-                mn_beam_geom(cs * mx + sn * my, -sn * mx + cs * my, W.orad[k] * W.orad[k], bx, by, tc, h2);
-                beam.update(tc, h2, (M)P.sonar_range);
-            }
-            // mixed precision: discrete choices in float32, accepted range re-derived in float64 (as mn_step does)
-            const double td = PARITY ? (double)beam.dist : beam.dist64();
-            W.beam[lane][0] = beam.hit() ? td * bx : 0.0;
-            W.beam[lane][1] = beam.hit() ? td * by : 0.0;
-        }
-        __syncthreads();
-        if (lane < MN_OBS_DIM) {
-            double v;
-            const double gdx = gx - sx, gdy = gy - sy;
-            if (lane == 0) v = cs * velx + sn * vely;
-            else if (lane == 1) v = -sn * velx + cs * vely;
-            else if (lane == 2) v = cs * gdx + sn * gdy;
-            else if (lane == 3) v = -sn * gdx + cs * gdy;
-            else v = W.beam[(lane - 4) >> 1][(lane - 4) & 1];
-            if (obs_out) obs_out[(size_t)e * MN_OBS_DIM + lane] = (float)v;
-            if (PARITY) A.obs64[(size_t)e * MN_OBS_DIM + lane] = v;
-        }
-        if (lane == 0) {
-            A.x[e] = sx; A.y[e] = sy; A.theta[e] = th0; A.speed[e] = sp0;
-            A.vx[e] = velx; A.vy[e] = vely;
-            A.ep_t[e] = 0;  // marinenav_env.py:106
-        }
-    }
+    for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
+        mn_reset_env<M, PARITY>(A, P, S, W, list ? list[qi] : (int)qi, mode, obs_out);
 }
 
 // init_genrand (numpy legacy seeding): key[0] = seed, key[i] = 1812433253*(key[i-1]^(key[i-1]>>30)) + i

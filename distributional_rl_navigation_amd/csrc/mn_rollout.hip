@@ -1,0 +1,125 @@
+// mn_rollout.hip -- T consecutive vector steps of the random-policy workload in ONE launch (gfx950).
+//
+// BASELINE configs[1] (4 096 envs, random policy, step kernel only) is launch-latency-bound when every vector step is
+// its own launch: 14 us per 4 096-env step launch + the reset launch + the action generator, for ~3 us of arithmetic.
+// Here a wavefront keeps its environments' pose, counters and world tables in registers (MnLane, mn_step_body.h) and
+// runs T steps back to back; the per-step HBM traffic is the outputs only.  Actions are drawn inside the kernel from a
+// counter-based generator keyed by (seed, step index, global env index) -- mn_random_actions produces the same draws
+// for callers that want to replay a rollout with single launches -- or read from a caller-supplied [T][n] tensor.
+// An env that finishes is reset on the spot by its own wavefront (mn_reset_env, mn_reset_body.h: the wave-cooperative
+// world generation of the reset kernel, same code, same bits), so the sequence of T x (mn_step, mn_reset_done) and one
+// mn_rollout are bit-identical in every output, every counter and every RNG stream.
+#include "mn_reset_body.h"
+#include "mn_step_body.h"
+
+namespace {
+
+__device__ __host__ __forceinline__ uint64_t mix64r(uint64_t x) {   // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// action of global env `env` at step `step`: uniform over the 9 actions (agent.py:203 `random.choice(np.arange(9))`)
+__device__ __forceinline__ int draw_action(uint64_t seed, uint64_t step, uint64_t env) {
+    const uint64_t k = mix64r(seed + 0x9E3779B97F4A7C15ull * (step + 1));
+    const uint64_t x = mix64r(k ^ (0xD1B54A32D192ED03ull * (env + 1)));
+    return (int)__umul64hi(x, (uint64_t)MN_NUM_ACTIONS);
+}
+
+__global__ __launch_bounds__(256) void mn_random_actions_kernel(uint64_t seed, uint64_t step, uint64_t env0, int n,
+                                                                int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = draw_action(seed, step, env0 + (uint64_t)i);
+}
+
+struct MnTrace {
+    float *obs;        // [T][n][26] observation returned by each step (terminal observation for a finished env), or NULL
+    float *reward;     // [T][n]
+    uint8_t *done;     // [T][n]
+    uint8_t *info;     // [T][n]
+    int32_t *action;   // [T][n] the action taken
+};
+
+template <typename M, bool PARITY, int L>
+__global__ __launch_bounds__(MN_WAVE) void mn_rollout_kernel(MnArrays A, MnDev P, int n_steps, const int32_t *__restrict__ actions_in,
+                                                             uint64_t seed, uint64_t step0, uint64_t env0,
+                                                             float *__restrict__ obs_out, MnTrace T) {
+    static_assert(MN_STEP_BLOCK == MN_WAVE, "one wavefront per workgroup: the in-kernel reset is wave-cooperative");
+    __shared__ MtLds S;
+    __shared__ WorldLds W;
+    using Lane = MnLane<M, PARITY, L>;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / L, q = tid % L;
+    const size_t n = (size_t)A.n;
+    if (tid == 0) { A.queue_count[0] = 0u; A.queue_count[1] = 0u; }   // nothing is left for a later mn_reset_done
+    const MnRing none = {};
+
+    Lane ln;
+    ln.load(A, e, q);
+    for (int t = 0; t < n_steps; ++t) {
+        int action = 0;
+        if (ln.active) action = actions_in ? actions_in[(size_t)t * n + e] : draw_action(seed, step0 + (uint64_t)t, env0 + (uint64_t)e);
+        // the row goes to the trace; the LAST step's row also to obs_out, which ends up holding what T x (mn_step,
+        // mn_reset_done) would leave there (finished envs: overwritten below with the new episode's first observation)
+        const bool last = t == n_steps - 1;
+        float *trow = T.obs ? T.obs + ((size_t)t * n + e) * MN_OBS_DIM : nullptr;
+        float *orow = obs_out + (size_t)e * MN_OBS_DIM;
+        const MnStepOut o = ln.template step<false>(A, P, action, (last || !trow) ? orow : trow,
+                                                    PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none, nullptr, nullptr,
+                                                    (last && trow) ? trow : nullptr);
+        if (ln.active && q == 0) {
+            const size_t k = (size_t)t * n + e;
+            if (T.reward) T.reward[k] = (float)o.reward;
+            if (T.done) T.done[k] = (uint8_t)o.done;
+            if (T.info) T.info[k] = (uint8_t)o.info;
+            if (T.action) T.action[k] = action;
+        }
+        // in-kernel reset hand-off: the wave resets its finished envs one after the other, all 64 lanes on each
+        unsigned long long m = __ballot(ln.active && o.done && q == 0);
+        if (m) {
+            ln.store(A);                       // pose + counters (total_timesteps drives the curriculum lookup)
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int env = __builtin_amdgcn_readlane(e, src);
+                mn_reset_env<M, PARITY>(A, P, S, W, env, 0, obs_out);
+            }
+            __syncthreads();                   // the reset's global writes are visible to this wave's reload
+            ln.load(A, e, q);
+        }
+    }
+    ln.store(A);
+}
+
+template <typename M, bool PARITY>
+void launch_rollout(int lanes, const MnArrays &A, const MnDev &P, int n_steps, const int32_t *actions_in, uint64_t seed,
+                    uint64_t step0, uint64_t env0, float *obs_out, const MnTrace &T, hipStream_t s) {
+#define MN_LAUNCH(LL)                                                                                                  \
+    hipLaunchKernelGGL((mn_rollout_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / MN_WAVE)), dim3(MN_WAVE), 0, s, \
+                       A, P, n_steps, actions_in, seed, step0, env0, obs_out, T)
+    // Default: a rollout launch is latency-bound per wave (T dependent steps), so small batches want many lanes per env
+    // -- 8 lanes up to 16 K envs (4 096 envs = 512 waves on 1024 SIMDs) -- and large ones the least total work.
+    if (lanes == 0) lanes = A.n <= 16384 ? 8 : (A.n <= 65536 ? 4 : (A.n <= 262144 ? 2 : 1));
+    switch (lanes) {
+        case 1: MN_LAUNCH(1); break;
+        case 2: MN_LAUNCH(2); break;
+        case 4: MN_LAUNCH(4); break;
+        default: MN_LAUNCH(8); break;
+    }
+#undef MN_LAUNCH
+}
+
+}  // namespace
+
+void mn_launch_rollout(const MnArrays &A, const MnDev &P, int precision, int lanes, int n_steps, const int32_t *actions_in,
+                       uint64_t seed, uint64_t step0, uint64_t env0, float *obs_out, float *obs_trace, float *reward_trace,
+                       uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s) {
+    const MnTrace T = {obs_trace, reward_trace, done_trace, info_trace, action_trace};
+    if (precision == MN_PRECISION_F64) launch_rollout<double, true>(lanes, A, P, n_steps, actions_in, seed, step0, env0, obs_out, T, s);
+    else launch_rollout<float, false>(lanes, A, P, n_steps, actions_in, seed, step0, env0, obs_out, T, s);
+}
+
+void mn_launch_random_actions(uint64_t seed, uint64_t step, uint64_t env0, int n, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(mn_random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, step, env0, n, out);
+}

@@ -1,0 +1,446 @@
+// mn_step_body.h -- one environment step as a device object (gfx950), shared by the single-step kernel (mn_step.hip)
+// and the multi-step rollout kernel (mn_rollout.hip).  Compiled with -ffp-contract=off; the fused multiply-adds are written
+// out (see mn_device.h), so every kernel this is inlined into computes bit-identical results.
+//
+// Replaces, for a batch of environments, MarineNavEnv.step (marinenav_env.py:199-262):
+//   N x [ get_velocity (:422-465) -> Robot.update_state (robot.py:102-123) ],
+//   get_observation (:273-326) with Robot.sonar_reflection (robot.py:125-198),
+//   reward + termination ladder (:220-257), counters (:259-260).
+//
+// Mapping: L lanes per environment, 64/L environments per wavefront.
+//   * 65 536 envs are only 1024 wavefronts at one lane per env -- ONE wave per SIMD, nothing to hide the dependent chain
+//     of a step behind.  With L lanes per env the independent parts of a step are spread over the lane group -- the 8
+//     vortex cores (8/L per lane, summed with DPP quad_perm / row_half_mirror adds, no LDS) and the 11 sonar beams
+//     (ceil(11/L) per lane) -- while the short sequential part (float64 pose integration) is replicated in every lane
+//     of the group; all lanes of a group hold bit-identical poses because the DPP adds are commutative pairs.
+//   * Everything a lane needs lives in registers (its cores, all 10 obstacles); world tables are SoA [row][env], so a
+//     wave's load of row k touches 64/L consecutive envs (the L lanes of a group read the same address).
+//   * Heading: ONE float64 sincos per step; the sub-steps advance (cos, sin) by the constant rotation of w*dt.
+//   * Observations leave as float2 stores into a row-major [env][26] tile.
+// MnLane keeps an env's pose, counters and tables in registers between load() and store(), so the rollout kernel can run
+// many steps without touching HBM for anything but its outputs.
+
+// Developer ablation (profiling only): compiled in ONLY with -DMN_ABLATION, into libmarinenav_hip_ablation.so
+// (make ablation).  The shipped library has no switch that removes work from the kernel.
+#pragma once
+#include "mn_device.h"
+
+#ifdef MN_ABLATION
+#define MN_SKIP(bit) ((P.debug_skip & (bit)) != 0)
+#else
+#define MN_SKIP(bit) false
+#endif
+
+#ifndef MN_STEP_BLOCK
+#define MN_STEP_BLOCK 64    // threads per workgroup (npad is a multiple of 256, so 64 / 128 / 256 all tile it); measured: same at 65 536 envs, 64 is 4 % faster at 1 M
+#endif
+
+// sum over the L lanes of a group; every lane ends with the bit-identical total
+template <int L>
+__device__ __forceinline__ float group_sum(float v) {
+    if (L >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    if (L >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    if (L >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    if (L >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    return v;
+}
+
+template <int L, int CTRL>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+template <int L>
+__device__ __forceinline__ double group_sum(double v) {
+    if (L >= 2) v = dpp_add<L, 0xB1>(v);
+    if (L >= 4) v = dpp_add<L, 0x4E>(v);
+    if (L >= 8) v = dpp_add<L, 0x141>(v);
+    if (L >= 16) v = dpp_add<L, 0x140>(v);
+    return v;
+}
+
+// What one step hands back to its caller (all lanes of an env's group hold the same values).
+struct MnStepOut {
+    double reward;
+    int done, info;
+};
+
+template <typename M, bool PARITY, int L>
+struct MnLane {
+    static constexpr int CPL = MN_MAX_CORES / L;            // vortex cores per lane
+    static constexpr int BPL = (MN_NUM_BEAMS + L - 1) / L;  // sonar beams per lane
+    static_assert(MN_MAX_CORES % L == 0, "L must divide 8");
+
+    int e, q;              // environment, lane within the env's group
+    bool active;
+    // pose, counters, episode constants
+    double x, y, theta, speed, gx, gy;
+    M velx, vely;          // velocity of the last sub-step (what the observation reports, App. A K5)
+    int ep_t, nc, no;
+    long long tot_t;
+    // this lane's vortex cores (generation order is irrelevant for a sum) and ALL obstacles (a beam walks the list in
+    // generation order), padded: missing cores are far away with zero circulation, missing obstacles far away with r = 0
+    double ccx[CPL], ccy[CPL];
+    M cgs[CPL];
+    double obx[MN_MAX_OBS], oby[MN_MAX_OBS], obr[MN_MAX_OBS];
+
+    // Every load is UNCONDITIONAL (rows beyond the placed count hold zeros), so all ~40-70 loads of a lane are in flight
+    // together and the kernel pays one memory latency, not a counts -> tables dependent chain.
+    __device__ __forceinline__ void load(const MnArrays &A, int env, int lane_in_group) {
+        e = env; q = lane_in_group;
+        active = e < A.n;
+        const int np = A.npad;
+        x = A.x[e]; y = A.y[e]; theta = A.theta[e]; speed = A.speed[e];
+        velx = (M)A.vx[e]; vely = (M)A.vy[e];
+        gx = A.goal_x[e]; gy = A.goal_y[e];
+        const int cnt = A.counts[e];
+        ep_t = A.ep_t[e];
+        tot_t = A.tot_t[e];
+        double ccg[CPL];
+        if (PARITY) {   // float64 master tables
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int k = q * CPL + j;
+                ccx[j] = A.cx[k * np + e]; ccy[j] = A.cy[k * np + e]; ccg[j] = A.cg[k * np + e];
+            }
+#pragma unroll
+            for (int k = 0; k < MN_MAX_OBS; ++k) {
+                obx[k] = A.ox[k * np + e]; oby[k] = A.oy[k * np + e]; obr[k] = A.orad[k * np + e];
+            }
+        } else {        // compact tables: int32 fixed-point positions (2^-24 m), float32 Gamma / radius
+            int qx[CPL], qy[CPL], px[MN_MAX_OBS], py[MN_MAX_OBS];
+            float qg[CPL], pr[MN_MAX_OBS];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int k = q * CPL + j;
+                qx[j] = A.qcx[k * np + e]; qy[j] = A.qcy[k * np + e]; qg[j] = A.qcg[k * np + e];
+            }
+#pragma unroll
+            for (int k = 0; k < MN_MAX_OBS; ++k) {
+                px[k] = A.qox[k * np + e]; py[k] = A.qoy[k * np + e]; pr[k] = A.qor[k * np + e];
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                ccx[j] = (double)qx[j] * MN_FIX_INV; ccy[j] = (double)qy[j] * MN_FIX_INV; ccg[j] = (double)qg[j];
+            }
+#pragma unroll
+            for (int k = 0; k < MN_MAX_OBS; ++k) {
+                obx[k] = (double)px[k] * MN_FIX_INV; oby[k] = (double)py[k] * MN_FIX_INV; obr[k] = (double)pr[k];
+            }
+        }
+        nc = cnt & 0xff; no = (cnt >> 8) & 0xff;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const bool v = q * CPL + j < nc;
+            ccx[j] = v ? ccx[j] : 1.0e6;   // padding: far away, zero circulation
+            ccy[j] = v ? ccy[j] : 1.0e6;
+            cgs[j] = v ? (M)ccg[j] : M(0);
+        }
+#pragma unroll
+        for (int k = 0; k < MN_MAX_OBS; ++k) {
+            const bool v = k < no;         // padding: far away, r = 0 -> can never be hit, so the beam
+            obx[k] = v ? obx[k] : 1.0e6;   // loop needs no count test
+            oby[k] = v ? oby[k] : 1.0e6;
+            obr[k] = v ? obr[k] : 0.0;
+        }
+    }
+
+    // pose + counters back to the handle's arrays (lane 0 of the group)
+    __device__ __forceinline__ void store(const MnArrays &A) const {
+        if (active && q == 0) {
+            A.x[e] = x; A.y[e] = y; A.theta[e] = theta; A.speed[e] = speed;
+            A.vx[e] = (double)velx; A.vy[e] = (double)vely;
+            A.ep_t[e] = ep_t;
+            A.tot_t[e] = tot_t;
+        }
+    }
+
+    // One MarineNavEnv.step.  Writes the observation row (terminal observation for a finished env) to obs_row
+    // ([26] floats of THIS env; float64 copy to obs_row64 in parity precision) and, with APPEND, the transition to the
+    // replay ring R (prev_head / prev_beam = this lane's share of obs_t, loaded by the caller).
+    // obs_row_b: optional second destination of the same row (the rollout kernel's trace), or nullptr.
+    template <bool APPEND>
+    __device__ __forceinline__ MnStepOut step(const MnArrays &A, const MnDev &P, int action_raw, float *__restrict__ obs_row,
+                                              double *__restrict__ obs_row64, const MnRing &R, const float2 *prev_head,
+                                              const float2 *prev_beam, float *__restrict__ obs_row_b = nullptr) {
+        int action = action_raw < 0 ? 0 : (action_raw > 8 ? 8 : action_raw);
+
+        // marinenav_env.py:205 dis_before
+        const double dbx = gx - x, dby = gy - y;
+        const double dis_before = sqrt(fma(dbx, dbx, dby * dby));
+
+        // robot.py:55-56: actions[i] = (a[i // 3], w[i % 3])
+        const int ai = action / 3, wi = action - 3 * ai;
+        const double acc = ai == 0 ? P.a[0] : (ai == 1 ? P.a[1] : P.a[2]);
+        const double wdt = (wi == 0 ? P.w[0] : (wi == 1 ? P.w[1] : P.w[2])) * P.dt;
+        const double rot_c = wi == 0 ? P.rot_c[0] : (wi == 1 ? P.rot_c[1] : P.rot_c[2]);   // cos(w*dt)
+        const double rot_s = wi == 0 ? P.rot_s[0] : (wi == 1 ? P.rot_s[1] : P.rot_s[2]);   // sin(w*dt)
+        const double dt = P.dt, two_pi = P.two_pi;
+
+        const double inv_two_pi_r2 = 1.0 / P.two_pi_r_r;
+        const double inv_two_pi = 1.0 / P.two_pi;
+
+        // heading: wrap once on entry (state may have been set from outside), one sincos per step
+        while (theta < 0.0) theta += two_pi;
+        while (theta >= two_pi) theta -= two_pi;
+        double sn = 0.0, cs = 1.0;
+        if (!MN_SKIP(4)) sincos(theta, &sn, &cs);
+
+        // ---- N kinematic sub-steps (marinenav_env.py:208-212) -------------------------------------
+        // The current is the superposition over ALL cores.  Every core's contribution is formed as two
+        // rounded products and the eight of them are added in ONE fixed balanced tree -- ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7))
+        // in generation order: the in-lane part over this lane's contiguous block of cores, the rest by the DPP stages --
+        // so the sum, and with it every output of the step, is bit-identical for every lanes-per-env mapping L.
+        const int nsub = MN_SKIP(1) ? 0 : P.N;
+        if constexpr (!PARITY) {
+            // Mixed precision: the core positions RELATIVE to the robot are formed once in float64, then
+            // tracked in float32 (d -= v*dt): the rounding of a relative position is relative to the
+            // DISTANCE to that core, which is what the 1/d field is sensitive to (a far core's 4e-6 m costs
+            // 1e-8 m/s; a core 0.5 m away is tracked to 3e-8 m).  The absolute pose still integrates in
+            // float64 below.  Cores are processed two at a time on float2 (v_pk_mul / v_pk_fma); a lane with a
+            // single core (L = 8) runs the same operations on scalars.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            constexpr int NP = CPL >= 2 ? CPL / 2 : 1;
+            const float dtf = (float)dt, i2p = (float)inv_two_pi, i2pr = (float)inv_two_pi_r2;
+            f2 rdx[NP], rdy[NP], gsv[NP];
+#pragma unroll
+            for (int p_ = 0; p_ < NP; ++p_) {
+                if constexpr (CPL >= 2) {
+                    rdx[p_] = (f2){(float)(ccx[2 * p_] - x), (float)(ccx[2 * p_ + 1] - x)};
+                    rdy[p_] = (f2){(float)(ccy[2 * p_] - y), (float)(ccy[2 * p_ + 1] - y)};
+                    gsv[p_] = (f2){(float)cgs[2 * p_], (float)cgs[2 * p_ + 1]};
+                } else {      // one real core in .x; .y is a zero-circulation dummy far away (contributes exactly +0)
+                    rdx[p_] = (f2){(float)(ccx[0] - x), 1.0e6f};
+                    rdy[p_] = (f2){(float)(ccy[0] - y), 1.0e6f};
+                    gsv[p_] = (f2){(float)cgs[0], 0.f};
+                }
+            }
+            for (int s = 0; s < nsub; ++s) {
+                float hx[NP], hy[NP];      // per pair: u_2p + u_2p+1
+#pragma unroll
+                for (int p_ = 0; p_ < NP; ++p_) {
+                    const f2 d2 = __builtin_elementwise_fma(rdx[p_], rdx[p_], rdy[p_] * rdy[p_]);
+                    f2 f = (f2){__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)} * i2p;
+                    f.x = f.x < i2pr ? f.x : i2pr;
+                    f.y = f.y < i2pr ? f.y : i2pr;
+                    f *= gsv[p_];
+                    const f2 ux = -rdy[p_] * f, uy = rdx[p_] * f;
+                    hx[p_] = CPL >= 2 ? ux.x + ux.y : ux.x;      // (a dummy's +0 would not change the sum; skipped anyway)
+                    hy[p_] = CPL >= 2 ? uy.x + uy.y : uy.x;
+                }
+                float sx_, sy_;
+                if constexpr (NP == 4) { sx_ = (hx[0] + hx[1]) + (hx[2] + hx[3]); sy_ = (hy[0] + hy[1]) + (hy[2] + hy[3]); }
+                else if constexpr (NP == 2) { sx_ = hx[0] + hx[1]; sy_ = hy[0] + hy[1]; }
+                else { sx_ = hx[0]; sy_ = hy[0]; }
+                const float cvx = group_sum<L>(sx_), cvy = group_sum<L>(sy_);
+                velx = (float)(speed * cs) + cvx;
+                vely = (float)(speed * sn) + cvy;
+                x = fma((double)velx, dt, x);
+                y = fma((double)vely, dt, y);
+                const f2 nvx = (f2){-velx, -velx}, nvy = (f2){-vely, -vely}, dt2 = (f2){dtf, dtf};
+#pragma unroll
+                for (int p_ = 0; p_ < NP; ++p_) {
+                    rdx[p_] = __builtin_elementwise_fma(nvx, dt2, rdx[p_]);
+                    rdy[p_] = __builtin_elementwise_fma(nvy, dt2, rdy[p_]);
+                }
+                speed = fma(fma(-P.k_drag, speed, acc), dt, speed);      // robot.py:113
+                speed = fmin(fmax(speed, 0.0), P.max_speed);           // robot.py:114 clip
+                const double c2 = fma(cs, rot_c, -(sn * rot_s));
+                sn = fma(sn, rot_c, cs * rot_s);
+                cs = c2;
+            }
+            // heading (robot.py:117-123): N increments of w*dt, each wrapped into [0, 2pi).  The wrapped sum is
+            // formed once here (it differs from the reference's step-by-step sum by rounding only, ~1e-15 rad)
+            theta = fma((double)nsub, wdt, theta);
+            while (theta < 0.0) theta += two_pi;
+            while (theta >= two_pi) theta -= two_pi;
+        } else {
+            for (int s = 0; s < nsub; ++s) {
+                // current at the pre-move position, float64 throughout
+                double ux[CPL], uy[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    mn_core_velocity<double>(ccx[j] - x, ccy[j] - y, cgs[j], inv_two_pi_r2, inv_two_pi, ux[j], uy[j]);
+                double sx_, sy_;
+                if constexpr (CPL == 8) {
+                    sx_ = ((ux[0] + ux[1]) + (ux[2] + ux[3])) + ((ux[4] + ux[5]) + (ux[6] + ux[7]));
+                    sy_ = ((uy[0] + uy[1]) + (uy[2] + uy[3])) + ((uy[4] + uy[5]) + (uy[6] + uy[7]));
+                } else if constexpr (CPL == 4) { sx_ = (ux[0] + ux[1]) + (ux[2] + ux[3]); sy_ = (uy[0] + uy[1]) + (uy[2] + uy[3]); }
+                else if constexpr (CPL == 2) { sx_ = ux[0] + ux[1]; sy_ = uy[0] + uy[1]; }
+                else { sx_ = ux[0]; sy_ = uy[0]; }
+                const double cvx = group_sum<L>(sx_), cvy = group_sum<L>(sy_);
+                // robot.py:98-107: velocity = speed*(cos,sin) + current ; position += velocity*dt
+                velx = speed * cs + cvx;
+                vely = speed * sn + cvy;
+                x = fma(velx, dt, x);
+                y = fma(vely, dt, y);
+                // marinenav_env.py:211-212: robot.trajectory gets one point per sub-step
+                if (A.traj && q == 0 && active && s < A.traj_n) {
+                    A.traj[((size_t)e * A.traj_n + s) * 2] = x;
+                    A.traj[((size_t)e * A.traj_n + s) * 2 + 1] = y;
+                }
+                // robot.py:113-114: drag + clip
+                speed = fma(fma(-P.k_drag, speed, acc), dt, speed);
+                speed = speed < 0.0 ? 0.0 : (speed > P.max_speed ? P.max_speed : speed);
+                // robot.py:117-123: heading + wrap to [0, 2pi); (cos, sin) advance by the constant rotation
+                theta += wdt;
+                theta = theta < 0.0 ? theta + two_pi : theta;
+                theta = theta >= two_pi ? theta - two_pi : theta;
+                const double c2 = fma(cs, rot_c, -(sn * rot_s));
+                sn = fma(sn, rot_c, cs * rot_s);
+                cs = c2;
+            }
+        }
+
+        // marinenav_env.py:214 dis_after
+        const double dax = gx - x, day = gy - y;
+        const double dis_after = sqrt(fma(dax, dax, day * day));
+
+        // ---- observation (marinenav_env.py:273-326) ------------------------------------------------
+        // Obstacle centres in the robot frame, m_r = R(theta)^T (c - p) (|m_r| = |c - p|), and at the same
+        // time the sonar work-list: only obstacles that can intersect the fan at all -- within range + r of
+        // the robot and inside the +-60 degree wedge widened by r -- are appended, IN GENERATION ORDER, to a
+        // lane-private LDS column.  A dropped obstacle can never produce a candidate, so it can neither be
+        // hit nor trigger the reference's `break`; the scan over the list is therefore equivalent to the
+        // scan over all obstacles (robot.py:147-198).  Typically 0-3 of the 10 obstacles survive, and the
+        // beam loop runs to the longest list in the wavefront instead of 10.
+        __shared__ double lst_x[MN_MAX_OBS][MN_STEP_BLOCK], lst_y[MN_MAX_OBS][MN_STEP_BLOCK];
+        __shared__ M lst_r[MN_MAX_OBS][MN_STEP_BLOCK];     // radius: float32 is exact for the compact tables, float64 in parity mode
+        const int tl = threadIdx.x;
+        int nrel = 0;
+        double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
+        const double reach0 = P.sonar_range + 0.05;
+        if (!MN_SKIP(8))
+#pragma unroll
+        for (int k = 0; k < MN_MAX_OBS; ++k) {
+            const double mx = obx[k] - x, my = oby[k] - y;
+            const double rx_ = fma(cs, mx, sn * my), ry_ = fma(cs, my, -(sn * mx));
+            const double d2 = fma(mx, mx, my * my);
+            const bool in = k < no;
+            const bool nearer = in && (d2 < best);
+            best = nearer ? d2 : best;
+            best_r2 = nearer ? obr[k] * obr[k] : best_r2;
+            const double r = obr[k];
+            const double reach = reach0 + r;
+            const bool rel = in && (d2 <= reach * reach) &&
+                             (!P.fan_filter || (fma(P.fan_sin, rx_, -(P.fan_cos * fabs(ry_))) >= -(r + 0.05)));
+            if (rel) { lst_x[nrel][tl] = rx_; lst_y[nrel][tl] = ry_; lst_r[nrel][tl] = (M)r; }
+            nrel += rel ? 1 : 0;
+        }
+        const M range = (M)P.sonar_range;
+        const double half_pi = 0.5 * 3.141592653589793, three_half_pi = 3 * 3.141592653589793 / 2;
+        M bxo[BPL], byo[BPL];   // this lane's beams, hit point in the robot frame
+        double bdx[BPL], bdy[BPL];
+        MnBeam<M> beam[BPL];
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const int b = q + L * j;
+            const int bb = b < MN_NUM_BEAMS ? b : MN_NUM_BEAMS - 1;
+            const double angle = theta + P.beam_rel[bb];  // robot.py:134, not wrapped
+            const bool up = fabs(angle - half_pi) < 1e-03;
+            const bool down = fabs(angle - three_half_pi) < 1e-03;
+            // beam direction in the robot frame: the constant (cos rel, sin rel); a snapped beam points
+            // along world (0,+-1), i.e. R^T (0,+-1) = +-(sin theta, cos theta)
+            bdx[j] = P.beam_cos[bb]; bdy[j] = P.beam_sin[bb];
+            if (up || down) {
+                const double sg = up ? 1.0 : -1.0;
+                bdx[j] = sg * sn; bdy[j] = sg * cs;
+            }
+            beam[j].init();
+        }
+        if (!MN_SKIP(2))
+        for (int s_ = 0; __any(s_ < nrel); ++s_) {
+            const bool v = s_ < nrel;
+            const double ox_ = lst_x[s_][tl], oy_ = lst_y[s_][tl];
+            const double rr = (double)lst_r[s_][tl];
+            const double r2o = v ? rr * rr : -1.0;    // exhausted list: h^2 < 0 -> NaN -> never a candidate
+#pragma unroll
+            for (int j = 0; j < BPL; ++j) {
+                double tc, h2;
+                mn_beam_geom(ox_, oy_, r2o, bdx[j], bdy[j], tc, h2);
+                beam[j].update(tc, h2, range);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const bool hit = beam[j].hit();
+            // Mixed precision: the float32 scan above made the discrete choices (which obstacle, hit / miss, `break`); the
+            // accepted range itself is re-derived in float64 from that candidate's float64 geometry, so the returned point
+            // is as accurate as the pose it was cast from (north-star: 1e-5 absolute on float32 outputs).
+            const double td = PARITY ? (double)beam[j].dist : beam[j].dist64();
+            bxo[j] = hit ? (M)(td * bdx[j]) : M(0);  // misses are (0,0): marinenav_env.py:315-316
+            byo[j] = hit ? (M)(td * bdy[j]) : M(0);
+        }
+
+        // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
+        double reward = P.timestep_penalty;
+        reward += dis_before - dis_after;
+        const bool collide = no > 0 && sqrt(best) <= sqrt(best_r2) + P.robot_r;   // sqrt(r*r) == r exactly
+        const bool reach = dis_after <= P.goal_dis;  // check_reach_goal (:338-342)
+        const bool out = (x < 0.0 || x > P.width) || (y < 0.0 || y > P.height);
+        int done, info;
+        if (P.set_boundary && out) { done = 1; info = MN_INFO_OUT_OF_BOUNDARY; }
+        else if (ep_t >= P.max_episode_steps) { done = 1; info = MN_INFO_TOO_LONG; }
+        else if (collide) { reward += P.collision_penalty; done = 1; info = MN_INFO_COLLISION; }
+        else if (reach) { reward += P.goal_reward; done = 1; info = MN_INFO_REACH_GOAL; }
+        else { done = 0; info = MN_INFO_NORMAL; }
+        ep_t += 1;       // marinenav_env.py:259-260
+        tot_t += 1;
+
+        // ---- observation row (+ replay transition) ---------------------------------------------------
+        if (active) {
+            // replay slot of this env's transition (FIFO ring; only the newest `cap` rows of a launch survive)
+            long long slot = -1;
+            if constexpr (APPEND) {
+                const long long first = (long long)A.n > R.cap ? (long long)A.n - R.cap : 0;
+                if (e >= first) { slot = R.ptr + (e - first); slot = slot >= R.cap ? slot - R.cap : slot; }
+            }
+            float2 *rs = APPEND && slot >= 0 ? reinterpret_cast<float2 *>(R.states + slot * MN_OBS_DIM) : nullptr;
+            float2 *rn = APPEND && slot >= 0 ? reinterpret_cast<float2 *>(R.next_states + slot * MN_OBS_DIM) : nullptr;
+            if (q == 0) {
+                // R(theta)^T * velocity: lagged velocity, final heading (App. A K5); R(theta)^T (goal - p)
+                const M c = (M)cs, s_ = (M)sn;
+                const M o0 = MnMath<M>::fma_(c, velx, s_ * vely), o1 = MnMath<M>::fma_(c, vely, -(s_ * velx));
+                const M o2 = (M)fma(cs, dax, sn * day), o3 = (M)fma(cs, day, -(sn * dax));
+                *reinterpret_cast<float2 *>(obs_row) = make_float2((float)o0, (float)o1);
+                *reinterpret_cast<float2 *>(obs_row + 2) = make_float2((float)o2, (float)o3);
+                if (obs_row_b) {
+                    *reinterpret_cast<float2 *>(obs_row_b) = make_float2((float)o0, (float)o1);
+                    *reinterpret_cast<float2 *>(obs_row_b + 2) = make_float2((float)o2, (float)o3);
+                }
+                if constexpr (APPEND) {
+                    if (rs) {
+                        rs[0] = prev_head[0]; rs[1] = prev_head[1];
+                        rn[0] = make_float2((float)o0, (float)o1); rn[1] = make_float2((float)o2, (float)o3);
+                        R.actions[slot] = (int64_t)action_raw;       // as chosen (replay_buffer.py:50 stores the agent's action)
+                        R.rewards[slot] = (float)reward;
+                        R.dones[slot] = done ? 1.0f : 0.0f;
+                    }
+                }
+                if (PARITY) {
+                    A.rew64[e] = reward;
+                    obs_row64[0] = (double)o0; obs_row64[1] = (double)o1; obs_row64[2] = (double)o2; obs_row64[3] = (double)o3;
+                }
+            }
+            if (!MN_SKIP(16))
+#pragma unroll
+            for (int j = 0; j < BPL; ++j) {
+                const int b = q + L * j;
+                if (b < MN_NUM_BEAMS) {
+                    *reinterpret_cast<float2 *>(obs_row + 4 + 2 * b) = make_float2((float)bxo[j], (float)byo[j]);
+                    if (obs_row_b) *reinterpret_cast<float2 *>(obs_row_b + 4 + 2 * b) = make_float2((float)bxo[j], (float)byo[j]);
+                    if constexpr (APPEND) {
+                        if (rs) { rs[2 + b] = prev_beam[j]; rn[2 + b] = make_float2((float)bxo[j], (float)byo[j]); }
+                    }
+                    if (PARITY) { obs_row64[4 + 2 * b] = (double)bxo[j]; obs_row64[5 + 2 * b] = (double)byo[j]; }
+                }
+            }
+        }
+        MnStepOut o;
+        o.reward = reward; o.done = done; o.info = info;
+        return o;
+    }
+};

@@ -50,7 +50,7 @@ class VecMarineNavEnv:
     """
 
     def __init__(self, n_envs, seed=0, seeds=None, schedule=None, device="cuda:0", precision="mixed",
-                 timestep_scale=1.0, first_index=0, params=None, step_lanes=0):
+                 timestep_scale=1.0, first_index=0, params=None, step_lanes=0, rollout_lanes=0):
         if not torch.cuda.is_available():
             raise _capi.MarineNavHipError("VecMarineNavEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.L = _capi.lib()
@@ -61,6 +61,7 @@ class VecMarineNavEnv:
         self.params.precision = _capi.PRECISION_F64 if precision in ("f64", "float64", 0) else _capi.PRECISION_MIXED
         self.precision = "f64" if self.params.precision == _capi.PRECISION_F64 else "mixed"
         self.params.step_lanes = int(step_lanes)
+        self.params.rollout_lanes = int(rollout_lanes)
         h = C.c_void_p()
         rc = self.L.mn_create(self.n_envs, C.byref(self.params), C.byref(h))
         if rc:
@@ -196,6 +197,40 @@ class VecMarineNavEnv:
                                           self._stream()))
         replay.advance(self.n_envs)
         return self.obs, self.reward, self.done, self.info
+
+    def rollout(self, n_steps, actions=None, action_seed=0, first_step=0, trace=("obs", "reward", "done")):
+        """`n_steps` vector steps with auto-reset in ONE launch (C-ABI mn_rollout): uniformly random actions drawn inside
+        the kernel (counter-based: seed, step index, global env index = first_index + i), or `actions` [n_steps, n] i32.
+        Bit-identical to n_steps x (step, reset_done).  Returns a dict with the final `obs` [n,26] (what the next act
+        would see) and the requested traces: obs [T,n,26], reward [T,n], done [T,n] u8, info [T,n] u8, action [T,n] i32."""
+        T, n, dev = int(n_steps), self.n_envs, self.device
+        key = (T, tuple(sorted(trace)))
+        bufs = getattr(self, "_rollout_bufs", None)
+        if bufs is None or bufs[0] != key:
+            mk = dict(obs=lambda: torch.empty(T, n, OBS_DIM, dtype=torch.float32, device=dev),
+                      reward=lambda: torch.empty(T, n, dtype=torch.float32, device=dev),
+                      done=lambda: torch.empty(T, n, dtype=torch.uint8, device=dev),
+                      info=lambda: torch.empty(T, n, dtype=torch.uint8, device=dev),
+                      action=lambda: torch.empty(T, n, dtype=torch.int32, device=dev))
+            bufs = self._rollout_bufs = (key, {k: mk[k]() for k in trace})
+        tr = bufs[1]
+        a = None
+        if actions is not None:
+            a = actions.to(device=dev, dtype=torch.int32).contiguous()
+            assert a.shape == (T, n)
+        p = lambda k: _ptr(tr[k]) if k in tr else None
+        self._check(self.L.mn_rollout(self.h, T, _ptr(a) if a is not None else None, int(action_seed), int(first_step),
+                                      int(self.first_index), _ptr(self.obs), p("obs"), p("reward"), p("done"), p("info"), p("action"),
+                                      self._stream()))
+        out = dict(tr)
+        out["final_obs"] = self.obs
+        return out
+
+    def random_actions(self, action_seed, step):
+        """The actions `rollout(action_seed=...)` takes at step index `step` (int32 [n] on the device)."""
+        a = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)
+        self._check(self.L.mn_random_actions(int(action_seed), int(step), int(self.first_index), self.n_envs, _ptr(a), self._stream()))
+        return a
 
     def reset_done(self, keep_terminal_obs=False):
         """The caller-side `if done: state = env.reset()` (agent.py:152-170) for the whole batch.

@@ -87,7 +87,9 @@ typedef struct mn_params {
     int32_t N;                       /* robot.py:29 sub-steps per action */
     int32_t num_beams;               /* robot.py:9, must equal MN_NUM_BEAMS */
     int32_t precision;               /* MN_PRECISION_* */
-    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = auto (2 up to 128 K envs, else 1), or 1, 2, 4, 8 */
+    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = auto (2 up to 128 K envs, else 1), or 1, 2, 4, 8.
+                                        Results do not depend on it (fixed summation tree): a performance knob only */
+    int32_t rollout_lanes;           /* the same for mn_rollout: 0 = auto (8 up to 16 K envs, 4 up to 64 K, 2 up to 256 K, else 1) */
 } mn_params;
 
 typedef struct mn_handle mn_handle;
@@ -150,6 +152,27 @@ int mn_step_append(mn_handle *h, const int32_t *actions_dev, const float *prev_o
                    uint8_t *done_dev, uint8_t *info_dev, float *ring_states, float *ring_next_states,
                    int64_t *ring_actions, float *ring_rewards, float *ring_dones, int64_t ptr, int64_t capacity,
                    void *stream);
+
+/* T = n_steps consecutive vector steps in ONE launch -- the loop `for t: a = policy(); env.step(a); if done: env.reset()`
+ * (agent.py:113-170 without the learner) for every env, for policies that do not look at the observation: the uniform
+ * random policy of BASELINE configs[1] (actions_dev == NULL: env i takes, at step t, the action
+ * mn_random_actions(action_seed, first_step_index + t, first_env_index + i) -- a counter-based draw, uniform over the 9
+ * actions) or a pre-drawn action tensor actions_dev [n_steps][n_envs] i32.  Environment state stays in registers
+ * between steps and an env that finishes is reset at once by its own wavefront (same world generation, same RNG stream
+ * positions as mn_reset_done), so the result is BIT-IDENTICAL to n_steps x (mn_step, mn_reset_done) with the same
+ * actions.  Outputs (device pointers; every trace may be NULL):
+ *   obs_dev          [n][26] f32       : what obs_dev holds after the last (mn_step, mn_reset_done) pair -- the observation
+ *                                        each env continues from (first observation of the new episode where it just finished)
+ *   obs_trace_dev    [n_steps][n][26]  : the observation each step returned (terminal observation for a finished env)
+ *   reward_trace_dev [n_steps][n] f32, done_trace_dev / info_trace_dev [n_steps][n] u8, action_trace_dev [n_steps][n] i32
+ * first_env_index = this handle's offset in a sharded run (rank * n_envs), so shards draw the actions of their slice.
+ * Afterwards nothing is pending for mn_reset_done and mn_last_done_count reports 0. */
+int mn_rollout(mn_handle *h, int32_t n_steps, const int32_t *actions_dev, uint64_t action_seed, uint64_t first_step_index,
+               uint64_t first_env_index, float *obs_dev, float *obs_trace_dev, float *reward_trace_dev,
+               uint8_t *done_trace_dev, uint8_t *info_trace_dev, int32_t *action_trace_dev, void *stream);
+/* The action draws of mn_rollout for one step: actions_dev[i] = action of env (first_env_index + i) at step step_index. */
+int mn_random_actions(uint64_t action_seed, uint64_t step_index, uint64_t first_env_index, int32_t n, int32_t *actions_dev,
+                      void *stream);
 
 /* The caller-side `if done: state = train_env.reset()` (thirdparty/IQN/agent.py:152-170), batched:
  * resets exactly the envs the LAST mn_step flagged done and overwrites their rows of obs_dev

@@ -18,8 +18,12 @@ for t in range(T):
     bf = ((o64[:, 4:] == 0) != (omx[:, 4:] == 0)); flips += bf.sum() // 2
     dflips += int((e64.done != emx.done).sum())
     err = np.abs(o64 - omx); err[:, 4:][bf] = 0
-    tol = 1e-5 + 1e-5 * np.abs(o64)
+    tol = 1e-5
     worst = np.maximum(worst, err.max(0)); cnt_bad += (err > tol).sum(0)
+    if (err > tol).any():
+        i, k = np.unravel_index(np.argmax(err), err.shape)
+        ds = np.abs(emx.get_state()[0][i] - e64.get_state()[0][i])
+        print(f"t={t} env={i} entry={k} err={err[i,k]:.2e} value={o64[i,k]:.4f} pose err x={ds[0]:.1e} y={ds[1]:.1e} th={ds[2]:.1e}")
     sworst = np.maximum(sworst, np.abs(emx.get_state()[0] - e64.get_state()[0]).max(0))
     e64.reset_done(); emx.reset(mask=e64.done)
 np.set_printoptions(precision=2, linewidth=200)

@@ -41,7 +41,7 @@ def test_act_eval_quantiles_match_reference_forward(torch):
         assert torch.equal(quant2, quant) and torch.equal(t2, t)
     agent.load_model(os.path.join(G, "pretrained_IQN_seed3"), dev)
     _, quant, _ = agent.act_eval_batch(obs, 0.0, 1.0, taus=taus)
-    np.testing.assert_allclose(quant.cpu().numpy(), Z["pretrained_quantiles"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(quant.cpu().numpy(), Z["pretrained_quantiles"], rtol=2e-5, atol=3e-4)      # |Z| up to ~110, float32
     # library-drawn taus: returned taus are the ones the kernel used (re-injecting them reproduces the quantiles)
     a, quant, t = agent.act_eval_batch(obs, 0.0, 0.5)
     assert float(t.max()) < 0.5 and float(t.min()) >= 0.0

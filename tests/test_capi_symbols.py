@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_params_struct_layout_and_defaults():
     from distributional_rl_navigation_amd import _capi
     p = _capi.default_params()
-    assert ctypes.sizeof(_capi.MnParams) == 8 * 29 + 4 * 10   # 29 doubles + 10 int32 (include/marinenav_hip.h)
+    assert ctypes.sizeof(_capi.MnParams) == 8 * 29 + 4 * 12   # 29 doubles + 11 int32 + 4 bytes tail padding (include/marinenav_hip.h)
     assert (p.width, p.height, p.core_r, p.num_cores, p.num_obs, p.N, p.num_beams) == (50, 50, 0.5, 8, 5, 10, 11)
     assert p.max_episode_steps == 1000 and p.goal_reward == 100.0 and p.collision_penalty == -50.0
     assert abs(p.w[2] - 3.141592653589793 / 6) < 1e-16 and p.a[0] == -0.4

