@@ -144,7 +144,7 @@ def main():
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
     env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed", step_lanes=args.lanes,
-                          rollout_lanes=args.lanes)
+                          rollout_lanes=args.lanes if args.lanes != 1 else 0)
     env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
     obs = env.reset()
     agent = None

@@ -12,6 +12,10 @@
 #include "mn_reset_body.h"
 #include "mn_step_body.h"
 
+#ifndef MN_ROLLOUT_MIN_WAVES
+#define MN_ROLLOUT_MIN_WAVES 1
+#endif
+
 namespace {
 
 __device__ __host__ __forceinline__ uint64_t mix64r(uint64_t x) {   // splitmix64 finaliser
@@ -42,7 +46,7 @@ struct MnTrace {
 };
 
 template <typename M, bool PARITY, int L>
-__global__ __launch_bounds__(MN_WAVE) void mn_rollout_kernel(MnArrays A, MnDev P, int n_steps, const int32_t *__restrict__ actions_in,
+__global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES) void mn_rollout_kernel(MnArrays A, MnDev P, int n_steps, const int32_t *__restrict__ actions_in,
                                                              uint64_t seed, uint64_t step0, uint64_t env0,
                                                              float *__restrict__ obs_out, MnTrace T) {
     static_assert(MN_STEP_BLOCK == MN_WAVE, "one wavefront per workgroup: the in-kernel reset is wave-cooperative");
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(MN_WAVE) void mn_rollout_kernel(MnArrays A, MnDev P
 
     Lane ln;
     ln.load(A, e, q);
+    bool stepped = false;      // this lane's registers are newer than the handle's arrays
     for (int t = 0; t < n_steps; ++t) {
         int action = 0;
         if (ln.active) action = actions_in ? actions_in[(size_t)t * n + e] : draw_action(seed, step0 + (uint64_t)t, env0 + (uint64_t)e);
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(MN_WAVE) void mn_rollout_kernel(MnArrays A, MnDev P
         const MnStepOut o = ln.template step<false>(A, P, action, (last || !trow) ? orow : trow,
                                                     PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none, nullptr, nullptr,
                                                     (last && trow) ? trow : nullptr);
+        stepped = true;
         if (ln.active && q == 0) {
             const size_t k = (size_t)t * n + e;
             if (T.reward) T.reward[k] = (float)o.reward;
@@ -87,9 +93,12 @@ __global__ __launch_bounds__(MN_WAVE) void mn_rollout_kernel(MnArrays A, MnDev P
             }
             __syncthreads();                   // the reset's global writes are visible to this wave's reload
             ln.load(A, e, q);
+            stepped = false;
         }
     }
-    ln.store(A);
+    // (an env that was reset by the last step keeps the reset's float64 velocity in the arrays, exactly as after
+    // mn_reset_done: storing the register copy would round it through the mixed kernel's float32 velocity)
+    if (stepped) ln.store(A);
 }
 
 template <typename M, bool PARITY>
@@ -99,10 +108,11 @@ void launch_rollout(int lanes, const MnArrays &A, const MnDev &P, int n_steps, c
     hipLaunchKernelGGL((mn_rollout_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / MN_WAVE)), dim3(MN_WAVE), 0, s, \
                        A, P, n_steps, actions_in, seed, step0, env0, obs_out, T)
     // Default: a rollout launch is latency-bound per wave (T dependent steps), so small batches want many lanes per env
-    // -- 8 lanes up to 16 K envs (4 096 envs = 512 waves on 1024 SIMDs) -- and large ones the least total work.
-    if (lanes == 0) lanes = A.n <= 16384 ? 8 : (A.n <= 65536 ? 4 : (A.n <= 262144 ? 2 : 1));
+    // -- 8 lanes up to 16 K envs (4 096 envs = 512 waves on 1024 SIMDs) -- and large ones less total work.  There is no
+    // 1-lane variant: with 64 envs' tables resident per wave next to the reset code it needs more than the 512 registers
+    // a lane can have (the compiler spills to scratch), and batches that large are better served by mn_step launches.
+    if (lanes == 0) lanes = A.n <= 16384 ? 8 : (A.n <= 65536 ? 4 : 2);
     switch (lanes) {
-        case 1: MN_LAUNCH(1); break;
         case 2: MN_LAUNCH(2); break;
         case 4: MN_LAUNCH(4); break;
         default: MN_LAUNCH(8); break;

@@ -162,7 +162,7 @@ def test_shards_equal_slices_at_config3_size(torch):
             for a, b in zip(sh.get_worlds(100, 16), wb):
                 assert np.array_equal(a["cores"], b["cores"]) and np.array_equal(a["obstacles"], b["obstacles"])
         sh.close()
-    assert total_done > 1000      # resets happened inside the compared window
+    assert total_done > 200       # resets happened inside the compared window
 
 
 def test_bench_shared_learner_line(torch):

@@ -45,7 +45,7 @@ def _same_state(a, b):
 
 
 @pytest.mark.parametrize("precision", ["f64", "mixed"])
-@pytest.mark.parametrize("n,T,rl,sl", [(700, 120, 0, 0), (700, 120, 1, 2), (700, 120, 2, 8), (700, 120, 4, 1), (64, 300, 8, 4), (5000, 40, 0, 0)])
+@pytest.mark.parametrize("n,T,rl,sl", [(700, 120, 0, 0), (700, 120, 2, 8), (700, 120, 4, 1), (700, 120, 8, 2), (64, 300, 8, 4), (5000, 40, 0, 0), (20000, 12, 0, 0)])
 def test_rollout_equals_single_launches(torch, precision, n, T, rl, sl):
     a_env = _make(n, precision, rollout_lanes=rl, step_lanes=sl)      # one launch
     b_env = _make(n, precision, rollout_lanes=rl, step_lanes=sl)      # T x (actions, step, reset_done)
@@ -55,7 +55,7 @@ def test_rollout_equals_single_launches(torch, precision, n, T, rl, sl):
     for k in ("obs", "reward", "done", "info", "action"):
         assert torch.equal(out[k], ref[k]), k
     assert torch.equal(out["final_obs"], ref["final_obs"])
-    assert int(ref["done"].sum()) >= n // 4                                   # plenty of in-kernel resets were compared
+    assert int(ref["done"].sum()) >= n // 8                                   # plenty of in-kernel resets were compared
     _same_state(a_env, b_env)
     if precision == "f64":
         assert np.array_equal(a_env.get_obs64(), b_env.get_obs64()) and np.array_equal(a_env.get_reward64(), b_env.get_reward64())
@@ -125,6 +125,6 @@ def test_rollout_argument_checks(torch):
     assert L.mn_rollout(env.h, 4, None, 0, 0, 0, None, None, None, None, None, None, None) == -1       # obs_dev required
     assert L.mn_rollout(None, 4, None, 0, 0, 0, p(o), None, None, None, None, None, None) == -1
     assert L.mn_random_actions(0, 0, 0, 0, p(o), None) == -1 and L.mn_random_actions(0, 0, 0, 4, None, None) == -1
-    env.params.rollout_lanes = 3
+    env.params.rollout_lanes = 1      # no 1-lane rollout variant
     assert L.mn_set_params(env.h, C.byref(env.params)) == -1 and b"rollout_lanes" in L.mn_last_error(env.h)
     env.close()
