@@ -116,6 +116,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     d.two_pi = 2 * M_PI;
     d.two_pi_r = 2 * M_PI * p.core_r;
     d.two_pi_vrel = 2 * M_PI * p.v_rel_max;
+    d.inv_two_pi_vrel = 1.0 / d.two_pi_vrel;
     d.two_pi_r_r = 2 * M_PI * p.core_r * p.core_r;
     d.binom_q = exp(1.0 * log(1.0 - 0.5));
     d.sg_lo_x = 2.0; d.sg_span_x = (p.width - 2.0) - 2.0; d.sg_lo_y = 2.0; d.sg_span_y = (p.height - 2.0) - 2.0;

@@ -61,6 +61,7 @@ struct MnDev {
     double two_pi;          // 2*pi as python computes it
     double two_pi_r;        // (2*pi)*r              -> Gamma = two_pi_r * v_edge
     double two_pi_vrel;     // (2*pi)*v_rel_max      -> check_core same-direction boundary
+    double inv_two_pi_vrel; // its reciprocal: squared-distance pre-test only (the exact rule divides, like the reference)
     double two_pi_r_r;      // ((2*pi)*r)*r          -> compute_speed inside the core
     double binom_q;         // exp(1*log(1-0.5))     -> binomial(1,.5) == (U > binom_q)
     double sg_lo_x, sg_span_x, sg_lo_y, sg_span_y;  // start/goal uniform: 2 + (w-2-2)*U

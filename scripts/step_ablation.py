@@ -31,9 +31,13 @@ for t in range(300):      # steady state: episodes at all ages
     env.step(acts[t % 64]); env.reset_done()
 
 
-def timed(fn, reps=200):
+snap = env.get_state()
+
+
+def timed(fn, reps=60):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for _ in range(20):
+    env.set_state(*snap)          # every measurement starts from the same steady-state snapshot
+    for _ in range(5):
         fn()
     torch.cuda.synchronize()
     ev[0].record()
@@ -50,10 +54,17 @@ for mask, what in ((0, "full"), (1, "no sub-steps"), (2, "no sonar scan"), (8, "
     L.mn_set_debug_skip(env.h, mask)
     print(f"  {what:36s} {timed(lambda: env.step(acts[0])):7.2f}")
 L.mn_set_debug_skip(env.h, 0)
+env.set_state(*snap)
 env.step(acts[1])
 k = env.last_done_count()
 print(f"reset kernel (mn_reset_done of the same {k} finished envs back to back, us per launch):")
 for mask, what in ((0, "full"), (32, "no start/goal loop"), (64, "no core loop"), (128, "no obstacle loop"), (256, "no first-observation sonar"),
                    (512, "no RNG write-back"), (32 | 64 | 128 | 256 | 512, "RNG load + table / pose stores only")):
     L.mn_set_debug_skip(env.h, mask)
-    print(f"  {what:36s} {timed(lambda: env.reset_done()):7.2f}")
+    L.mn_set_debug_skip(env.h, mask)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize(); ev[0].record()
+    for _ in range(100):
+        env.reset_done()
+    ev[1].record(); torch.cuda.synchronize()
+    print(f"  {what:36s} {ev[0].elapsed_time(ev[1]) / 100 * 1e3:7.2f}")

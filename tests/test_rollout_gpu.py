@@ -55,7 +55,7 @@ def test_rollout_equals_single_launches(torch, precision, n, T, rl, sl):
     for k in ("obs", "reward", "done", "info", "action"):
         assert torch.equal(out[k], ref[k]), k
     assert torch.equal(out["final_obs"], ref["final_obs"])
-    assert int(ref["done"].sum()) >= n // 8                                   # plenty of in-kernel resets were compared
+    assert int(ref["done"].sum()) >= min(n // 8, 200)                                   # plenty of in-kernel resets were compared
     _same_state(a_env, b_env)
     if precision == "f64":
         assert np.array_equal(a_env.get_obs64(), b_env.get_obs64()) and np.array_equal(a_env.get_reward64(), b_env.get_reward64())
