@@ -35,7 +35,12 @@ ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at
 # 65 536 envs, 8 cores / 10 obstacles: profiles/r01_full_loop_kernel_stats.txt.  Not measured live.
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "act": 24.8e6}   # 2 * FETCH_SIZE + WRITE_SIZE, calibrated: profiles/r01_pmc_calibration.txt
+# 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
+# fused step + replay append kernel of the training loop, rollout = mn_rollout at 4 096 envs x 100 steps per launch
+# (profiles/r02_full_loop_kernel_stats.txt, profiles/r02_configs1_rollout.txt)
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 52.8e6, "act": 24.8e6, "rollout_4096x100": 61.8e6}
+# mn_step_append also moves the transition into the replay ring: + 104 B (obs_t row read) + 2 x 104 + 8 + 4 + 4 B written
+APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
 
 def cpu_baseline(n_steps, world):
@@ -257,7 +262,10 @@ def main():
 
     if rank == 0:
         env_steps = n * world * args.steps
-        bytes_per = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
+        bytes_step = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
+        fused_append = agent is not None and not args.separate_append and device.type == "cuda"
+        # the training loop's env kernel is mn_step_append: the step's 406 B + the transition it writes to the ring
+        bytes_per = bytes_step + (APPEND_BYTES_PER_ENV_STEP if fused_append else 0)
         # one launch processes n env-steps (single step) or n * T env-steps (mn_rollout)
         per_launch = n * max(1, roll)
         achieved = bytes_per * per_launch / (step_kernel_ms * 1e-3) / 1e9 if step_kernel_ms > 0 else 0.0
@@ -295,16 +303,19 @@ def main():
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             "roofline_env_step": {
-                "kernel": "mn_rollout_kernel<float,false,L>" if roll else "mn_step_kernel<float,false,L>",
+                "kernel": "mn_rollout_kernel<float,false,L>" if roll else ("mn_step_kernel<float,false,L,APPEND=true> (step + replay append)" if fused_append else "mn_step_kernel<float,false,L>"),
                 "env_steps_per_launch": per_launch,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC_BYTES["step"] if (n, args.cores, args.obstacles) == (65536, 8, 10) else None,
-                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (bytes per launch, not live)",
+                "traffic": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
+                           (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n, args.cores, args.obstacles) == (65536, 8, 10) else None),
+                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch), profiles/r02_full_loop_kernel_stats.txt / r02_configs1_rollout.txt; not live",
                 "algorithmic_bytes_per_env_step": bytes_per,
+                "algorithmic_bytes_step_only": bytes_step,
+                "frac_step_bytes_only": (bytes_step * per_launch / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_kernel_ms > 0 else None,
                 "launch_ms": step_kernel_ms,
                 "launches_timed": launches,
                 "kernel_only_env_steps_per_sec": per_launch / (step_kernel_ms * 1e-3) if step_kernel_ms > 0 else None,
@@ -316,7 +327,7 @@ def main():
                 "kernel": "iqn_qvals_kernel", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
                 "traffic": PMC_TRAFFIC_BYTES["act"] if n == 65536 else None,
-                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch, not live)",
+                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch, same kernel; not live)",
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "launch_ms": act_ms, "launches_timed": act_launches,
             }
         else:

@@ -3,6 +3,10 @@
 // kernels around the RNG streams (seeding, mask -> queue, peek).
 #include "mn_reset_body.h"
 
+#ifndef MN_RESET_MAX_BLOCKS
+#define MN_RESET_MAX_BLOCKS 8192u   // waves launched for a queue-driven reset (each loops over queue entries)
+#endif
+
 namespace {
 
 template <typename M, bool PARITY>
@@ -68,7 +72,7 @@ void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uin
                      const int32_t *list_dev, int mode, float *obs, hipStream_t s) {
     // enough waves to fill the chip several times over; each wave loops over queue entries
     uint32_t cap = count_dev ? (uint32_t)A.n : count_host;
-    uint32_t blocks = cap < 8192u ? cap : 8192u;
+    uint32_t blocks = cap < MN_RESET_MAX_BLOCKS ? cap : MN_RESET_MAX_BLOCKS;
     if (blocks == 0) return;
     if (precision == MN_PRECISION_F64)
         hipLaunchKernelGGL((mn_reset_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs);
