@@ -60,6 +60,12 @@ class ActContext:
     def invalidate(self):
         _capi.lib().mn_iqn_weights_changed(self.h)
 
+    def set_variant(self, variant):
+        """0 = the 32x32x2 MFMA kernel (default), 1 = the 16x16x4 kernel (A / B measurements, tests)."""
+        rc = _capi.lib().mn_iqn_set_variant(self.h, int(variant))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")
+
     def profile_begin(self, max_launches):
         rc = _capi.lib().mn_iqn_profile_begin(self.h, int(max_launches))
         if rc:

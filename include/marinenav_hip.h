@@ -239,6 +239,10 @@ typedef struct mn_iqn_ctx mn_iqn_ctx;
 int mn_iqn_create(mn_iqn_ctx **out);
 int mn_iqn_destroy(mn_iqn_ctx *c);
 int mn_iqn_weights_changed(mn_iqn_ctx *c);
+/* Tuning / A-B knob: which acting kernel serves calls that do not ask for quantiles.  0 (default): the
+ * v_mfma_f32_32x32x2_f32 kernel; 1: the v_mfma_f32_16x16x4_f32 kernel (also the one that writes quantiles).  Same
+ * network, same exact-f32 arithmetic; the two differ only in float32 summation order. */
+int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
 
 /* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
  * K = 32 quantile samples + mean over them (model.py:141-191), then argmax and the epsilon-greedy choice.
@@ -255,7 +259,7 @@ int mn_iqn_weights_changed(mn_iqn_ctx *c);
  *   actions_dev [n] i32   : chosen actions (may be NULL if only Q-values are wanted)
  *   quantiles_dev [n][32][9] f32 : IQNAgent.act_eval's `quantiles` (agent.py:217-236; model.py:185 before the mean), or
  *                           NULL.  When given, the output layer runs per tau and Q is the mean of these values.
- * Exact float32 (v_mfma_f32_16x16x4_f32).  num_taus must be 32. */
+ * Exact float32 MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).  num_taus must be 32. */
 int mn_iqn_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
                const float *explore_u_dev, float eps, int32_t *actions_dev, float *quantiles_dev, int32_t n,
                int32_t num_taus, void *stream);
