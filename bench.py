@@ -109,7 +109,7 @@ def main():
                     help="with --no-learner: T vector steps per launch through mn_rollout (in-kernel random actions and resets); "
                          "--steps must be a multiple of T.  0 = one mn_step + mn_reset_done launch pair per vector step")
     ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
-    ap.add_argument("--act-variant", type=int, default=0, help="acting kernel: 0 = v_mfma_f32_32x32x2_f32 (default), 1 = v_mfma_f32_16x16x4_f32")
+    ap.add_argument("--act-variant", type=int, default=0, help="acting kernel: 0 = v_mfma_f32_16x16x4_f32 (default), 1 = the v_mfma_f32_32x32x2_f32 re-layout")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
 
@@ -326,7 +326,7 @@ def main():
         if fused and act_ms > 0:
             tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
-                "kernel": "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 0 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                "kernel": "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
                 "traffic": PMC_TRAFFIC_BYTES["act"] if n == 65536 else None,
                 "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch, same kernel; not live)",

@@ -412,10 +412,13 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 
 
 // =====================================================================================================================
-// Second generation of the act kernel: the same network, the same register-chained transposed layers, on the
-// v_mfma_f32_32x32x2_f32 shape.  A pure stream of 32x32x2 sustains 4-6 % more than 16x16x4 on this chip (higher
-// effective clock under matrix load, half the instructions, fewer register-file reads per FLOP:
-// profiles/r01_mfma_rate.txt), and all 32 taus of an environment are ONE column tile.
+// The same network, the same register-chained transposed layers, on the v_mfma_f32_32x32x2_f32 shape -- an EXPERIMENT kept
+// selectable (mn_iqn_set_variant(ctx, 1)), not the default.  A pure stream of 32x32x2 sustains 4-6 % more than 16x16x4 on
+// this chip (profiles/r01_mfma_rate.txt) and all 32 taus of an environment are ONE column tile, so round 1 listed this
+// re-layout as the remaining lever.  Measured in round 2 (profiles/r02_act_kernel_variants.txt): 1024 us per 65 536 envs
+// against 998 us for the 16x16x4 kernel -- identical MFMA busy cycles (2.013 G), 2.5 % more elapsed cycles, the same
+// clock: inside this kernel the matrix pipe is shared by two waves that also run VALU epilogues, and the 64-cycle
+// instructions interleave with them less finely than 32-cycle ones; the micro-benchmark's advantage does not carry over.
 //
 // C / D layout of 32x32x2: lane l = (g = l >> 5, c = l & 31) holds column c (= tau c) and rows 8 j + 4 g + r in register
 // 4 j + r (j, r = 0..3).  A operand: A[row = l & 31][k = l >> 5]; B operand: B[k = l >> 5][col = l & 31].  As before the
@@ -555,9 +558,9 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
         const f32x4 *fbv = reinterpret_cast<const f32x4 *>(lds + OFF_FB + wave * F);   // feature float4 index (32 t + 8 j + 4 g) / 4
 
         f32x16 acc2[2] = {zero16(), zero16()};
-
         // ---- layers 1 + 2 fused over the six 32-row feature tiles, software-pipelined (layer-1 MFMAs of tile t + 1 are
         // issued before the bias / ReLU / Hadamard epilogue of tile t)
+        f32x4 left[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // layer-1 leftover tile (features 192..207), 16x16 layout
         f32x16 acc1 = zero16();
 #pragma unroll
         for (int s4 = 0; s4 < 8; ++s4) {
@@ -565,7 +568,6 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc1 = mfma32(a[i], cb[4 * s4 + i], acc1);
         }
-        f32x4 left[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // layer-1 leftover tile (features 192..207), 16x16 layout
 #pragma unroll
         for (int t = 0; t < NT32; ++t) {
             f32x16 nxt = zero16();
@@ -586,8 +588,7 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
                     for (int i = 0; i < 4; ++i) {
                         const int m = 4 * m4 + i;
                         const float own = hbit ? cb[2 * m + 1] : cb[2 * m];            // cos(pi tau_own (4 m + 2 h + g))
-                        const float give = hbit ? cb[2 * m] : cb[2 * m + 1];           // what the partner needs: its k has the OTHER h
-                        const float got = __shfl_xor(give, 16);
+                        const float got = __shfl_xor(hbit ? cb[2 * m] : cb[2 * m + 1], 16);   // the partner's k has the OTHER h
                         left[0] = mfma(a[i], hbit ? got : own, left[0]);               // tile 0: taus 0..15
                         left[1] = mfma(a[i], hbit ? own : got, left[1]);               // tile 1: taus 16..31
                     }
@@ -624,12 +625,16 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v0 = left[0][r] + bias[r], v1 = left[1][r] + bias[r];
-                const unsigned x0 = __builtin_bit_cast(unsigned, (v0 > 0.f ? v0 : 0.f) * fv[r]);
-                const unsigned x1 = __builtin_bit_cast(unsigned, (v1 > 0.f ? v1 : 0.f) * fv[r]);
-                const auto z = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);     // lane bit 4 <-> tile index
-                const auto w_ = __builtin_amdgcn_permlane32_swap(z[0], z[1], false, false); // lane bit 5 <-> pair index
-                y[0][r] = __builtin_bit_cast(float, w_[0]);
-                y[1][r] = __builtin_bit_cast(float, w_[1]);
+                float x0 = (v0 > 0.f ? v0 : 0.f) * fv[r], x1 = (v1 > 0.f ? v1 : 0.f) * fv[r];
+                // v_permlane16_swap: lane bit 4 <-> tile index; v_permlane32_swap: lane bit 5 <-> pair index.  Written as
+                // inline assembly on purpose: with the two builtins chained, hipcc (ROCm 7.2) loses track of the second
+                // result of the second swap (it copies the FIRST result into the register it then uses as the second:
+                // seen in the ISA, and as wrong Q-values for features 200..207).  Both instructions write both operands;
+                // the s_nops are the VALU -> DPP-class and VALU -> MFMA-operand wait states hipcc cannot see inside asm.
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 7"
+                             : "+v"(x0), "+v"(x1));
+                y[0][r] = x0;
+                y[1][r] = x1;
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -640,6 +645,7 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
                     for (int r = 0; r < 4; ++r) acc2[mt] = mfma32(a[r], y[a_][r], acc2[mt]);
                 }
         }
+
         // ---- layer 2 epilogue, layer 3 ---------------------------------------------------------------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -664,8 +670,12 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
         // ---- layer 3 epilogue + mean over the 32 taus before the linear output layer (model.py:185,190), as before:
         // after half_sum32 every lane of half g holds sum_tau h3[32 mt + 8 j + 4 g + r]; lane (g, c < 9) forms the part of
         // action c that comes from its 32 features and the two halves are added with one cross-half shuffle
+        // (row_sum16 leaves the sum over the 16 taus of this lane's ROW in every lane of the row; the output layer is linear,
+        // so each row forms its own partial dot product with W4[action = lane & 15] and the four rows -- two per half, two
+        // halves -- are added with two cross-row shuffles at the end)
         float part = 0.f;
-        const int arow = c < A_OUT ? c : A_OUT - 1;
+        const int c16 = lane & 15;
+        const int arow = c16 < A_OUT ? c16 : A_OUT - 1;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -675,11 +685,12 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc3[mt][4 * j + r] + bias[r];
-                    part = fmaf(w4[r], half_sum32(v > 0.f ? v : 0.f), part);
+                    part = fmaf(w4[r], row_sum16(v > 0.f ? v : 0.f), part);
                 }
             }
+        part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        const float qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + (c < 16 ? c : 0)];     // Q(s, action = c), valid for c < 9
+        const float qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + c16];     // Q(s, action = lane), valid for lane < 9
         if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {
@@ -735,7 +746,7 @@ struct mn_iqn_ctx {
     float *packed = nullptr;       // weight image of the 16x16x4 kernel (act_eval's quantile variant, variant 1)
     float *packed32 = nullptr;     // weight image of the 32x32x2 kernel (default acting path)
     bool dirty = true, dirty32 = true;
-    int variant = 0;               // mn_iqn_set_variant: 0 = 32x32x2 kernel, 1 = 16x16x4 kernel
+    int variant = 0;               // mn_iqn_set_variant: 0 = 16x16x4 kernel (default, the faster one), 1 = 32x32x2 kernel
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
@@ -839,8 +850,8 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     hipStream_t s = (hipStream_t)stream;
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
-    // quantile capture (act_eval) runs on the 16x16x4 kernel; plain acting on the 32x32x2 kernel unless variant 1 is set
-    const bool use32 = !quantiles_dev && c->variant == 0;
+    // the 32x32x2 kernel is opt-in (mn_iqn_set_variant(ctx, 1)); quantile capture (act_eval) always runs on the 16x16x4 kernel
+    const bool use32 = !quantiles_dev && c->variant == 1;
     bool &dirty = use32 ? c->dirty32 : c->dirty;
     float *packed = use32 ? c->packed32 : c->packed;
     const int pack_blocks = dirty ? (use32 ? v32::PACK_BLOCKS : PACK_BLOCKS) : 0;

@@ -61,7 +61,7 @@ class ActContext:
         _capi.lib().mn_iqn_weights_changed(self.h)
 
     def set_variant(self, variant):
-        """0 = the 32x32x2 MFMA kernel (default), 1 = the 16x16x4 kernel (A / B measurements, tests)."""
+        """0 = the 16x16x4 MFMA kernel (default), 1 = the 32x32x2 re-layout (A / B measurements, tests)."""
         rc = _capi.lib().mn_iqn_set_variant(self.h, int(variant))
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")

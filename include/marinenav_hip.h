@@ -239,9 +239,9 @@ typedef struct mn_iqn_ctx mn_iqn_ctx;
 int mn_iqn_create(mn_iqn_ctx **out);
 int mn_iqn_destroy(mn_iqn_ctx *c);
 int mn_iqn_weights_changed(mn_iqn_ctx *c);
-/* Tuning / A-B knob: which acting kernel serves calls that do not ask for quantiles.  0 (default): the
- * v_mfma_f32_32x32x2_f32 kernel; 1: the v_mfma_f32_16x16x4_f32 kernel (also the one that writes quantiles).  Same
- * network, same exact-f32 arithmetic; the two differ only in float32 summation order. */
+/* A-B knob: which acting kernel serves calls that do not ask for quantiles.  0 (default): the v_mfma_f32_16x16x4_f32
+ * kernel (also the one that writes quantiles); 1: the v_mfma_f32_32x32x2_f32 re-layout (measured 2.6 % slower on MI355X,
+ * kept for comparison).  Same network, same exact-f32 arithmetic; the two differ only in float32 summation order. */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
 
 /* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
