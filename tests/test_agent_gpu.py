@@ -328,3 +328,50 @@ def test_experiment_capture_schema(torch):
     # the G14 world with the reference's cvar = 0.5 policy ended out of area after 76 steps; with fresh taus the
     # batched run must at least reach the same kind of outcome record
     assert isinstance(res["IQN_0.5"]["out_of_area"][0], bool)
+
+
+def test_headline_configuration_loop_at_full_size(torch):
+    """BASELINE configs[2] exactly as bench.py composes it -- 65 536 envs, replay 100 000, batch 256, one gradient step
+    every 4 vector steps, fused act / step+append / reset / gradient-step kernels -- run for 24 vector steps with the
+    bookkeeping and the data it leaves behind asserted at full size (size-independent properties)."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    n, cap, B, T = 65536, 100_000, 256, 24
+    dev = "cuda:0"
+    env = VecMarineNavEnv(n, seed=0, device=dev, precision="mixed")
+    env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+    agent = IQNAgent(26, 9, BATCH_SIZE=B, BUFFER_SIZE=cap, device=dev, seed=100, learning_starts=0, UPDATE_EVERY=4)
+    assert agent.use_fused_act and agent.use_fused_train
+    before = torch.cat([p.detach().reshape(-1).clone() for p in agent.qnetwork_local.parameters()])
+    obs = env.reset()
+    losses, dones = [], 0
+    for t in range(T):
+        prev = obs.clone()
+        obs, reward, done, info, loss = agent.vec_step(env, obs, eps=0.5, per_iter=n)
+        assert torch.isfinite(obs).all() and torch.isfinite(reward).all() and ((info != 0) == done.bool()).all()
+        dones += int(done.sum())
+        if loss is not None:
+            losses.append(float(loss))
+        # the transition block this step wrote: ring rows [ptr - n, ptr) hold (obs_t, a, r, ., done) of envs 0..n-1
+        m = agent.memory
+        lo = (m.ptr - n) % cap
+        idx = (lo + torch.arange(n, device=dev)) % cap
+        assert torch.equal(m.states[idx], prev) and torch.equal(m.rewards[idx, 0], reward) and torch.equal(m.dones[idx, 0], done.float())
+        live = ~done.bool()
+        assert torch.equal(m.next_states[idx][live], obs[live])           # finished envs: ring keeps the terminal observation,
+        assert not torch.equal(m.next_states[idx][~live], obs[~live]) or int((~live).sum()) == 0   # `obs` already the new episode's first
+        assert int(m.actions[idx].min()) >= 0 and int(m.actions[idx].max()) <= 8
+    assert agent.current_timestep == T * n and agent.learning_timestep == T and agent.grad_steps == T // 4 == len(losses)
+    assert len(agent.memory) == cap and agent.memory.ptr == (T * n) % cap
+    assert all(np.isfinite(losses)) and dones > 0
+    after = torch.cat([p.detach().reshape(-1) for p in agent.qnetwork_local.parameters()])
+    assert bool(torch.isfinite(after).all()) and float((after - before).abs().max()) > 1e-5        # the learner moved the weights
+    assert int(agent._fused.step_dev) == T // 4
+    s, ep, tot = env.get_state()
+    assert (tot == T).all() and (ep <= T).all()
+    # exploration at eps = 0.5: about half of the actions differ from the greedy ones of the same observations
+    a_greedy = agent.act_batch(obs, 0.0)
+    a_mixed = agent.act_batch(obs, 0.5)
+    frac = float((a_greedy == a_mixed).float().mean())
+    assert 0.50 < frac < 0.62        # 0.5 + 0.5 / 9
+    env.close()
