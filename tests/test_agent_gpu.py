@@ -369,9 +369,15 @@ def test_headline_configuration_loop_at_full_size(torch):
     assert int(agent._fused.step_dev) == T // 4
     s, ep, tot = env.get_state()
     assert (tot == T).all() and (ep <= T).all()
-    # exploration at eps = 0.5: about half of the actions differ from the greedy ones of the same observations
-    a_greedy = agent.act_batch(obs, 0.0)
+    # exploration at eps = 0.5 with the library-drawn random numbers of that very call: greedy wherever u > eps, and the
+    # greedy action is the argmax of the Q-values under the call's own taus
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
     a_mixed = agent.act_batch(obs, 0.5)
-    frac = float((a_greedy == a_mixed).float().mean())
-    assert 0.50 < frac < 0.62        # 0.5 + 0.5 / 9
+    d = agent._act_rng.draws(n, 32).clone()
+    taus, u = d[:n * 32].view(n, 32), d[n * 32:]
+    a_greedy = fused_act(agent.qnetwork_local, obs.contiguous(), 0.0, 1.0, taus=taus)
+    keep = u > 0.5
+    assert torch.equal(a_mixed[keep], a_greedy[keep]) and 0.48 < float(keep.float().mean()) < 0.52
+    hist = torch.bincount(a_mixed[~keep].long(), minlength=9).float()
+    assert float((hist / hist.sum() - 1 / 9).abs().max()) < 0.01          # explored actions uniform over the 9
     env.close()
