@@ -18,11 +18,10 @@
 //                     gathers its transitions from the ring, runs the target forward on four waves and the local
 //                     forward on the other four at the same time, then the loss gradient and the whole backward
 //                     out of LDS on all eight, and writes its partial parameter gradient [35 785] to HBM;
-//   iqn_grad_reduce   sums the partials in a fixed order (deterministic, no float atomics) -> flat gradient, loss, and the
-//                     per-block sums of squares of that gradient (the norm partials);
-//   iqn_sumsq         the norm partials again, only when the caller changed the gradient (all-reduced it over RCCL);
-//   iqn_adam          global norm, clip coefficient, Adam update (torch.optim.Adam arithmetic), one flat pass; advances the
-//                     device-side step counter.
+//   iqn_grad_reduce   sums the partials in a fixed order (deterministic, no float atomics) -> flat gradient, loss;
+//   iqn_sumsq         per-block sums of squares of the (possibly all-reduced) gradient, advances the step counter;
+//   iqn_adam          global norm, clip coefficient, Adam update (torch.optim.Adam arithmetic), one flat pass.
+// Between the last two the caller may all-reduce the flat gradient (shared learner over RCCL).
 //
 // MFMA mapping: exact-f32 v_mfma_f32_16x16x4_f32 throughout (the reference trains in float32).  Every product is a
 // 16x16 output tile accumulated over K in blocks of 16: lane l = (i = l & 15, g = l >> 4) feeds A[i][k] and B[k][i]
@@ -371,8 +370,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
 // grad[p] = sum over workgroups of partial[wg][p]: four quarter sums (one per thread row, partials in index order,
 // 8 loads in flight) combined in a fixed order -> deterministic.  Block 0 also sums the loss.
 __global__ __launch_bounds__(1024) void iqn_grad_reduce(const float *__restrict__ partial, const float *__restrict__ loss_partial,
-                                                        int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
-                                                        float *__restrict__ blocksq) {
+                                                        int n_part, float *__restrict__ grad, float *__restrict__ loss_out) {
     __shared__ float red[4][256];
     const int px = threadIdx.x & 255, seg = threadIdx.x >> 8;
     const int p = blockIdx.x * 256 + px;
@@ -384,21 +382,7 @@ __global__ __launch_bounds__(1024) void iqn_grad_reduce(const float *__restrict_
     }
     red[seg][px] = v;
     __syncthreads();
-    // this block's 256 gradient entries and -- same tree as iqn_sumsq -- their sum of squares (the norm partial of
-    // clip_grad_norm_): the norm pass costs no launch of its own unless the caller changes the gradient in between
-    float gq = 0.f;
-    if (seg == 0) {
-        gq = ((red[0][px] + red[1][px]) + red[2][px]) + red[3][px];
-        if (p < P_TOTAL) grad[p] = gq; else gq = 0.f;
-    }
-    __syncthreads();
-    if (seg == 0) red[0][px] = gq * gq;
-    __syncthreads();
-    for (int s_ = 128; s_ > 0; s_ >>= 1) {
-        if (seg == 0 && px < s_) red[0][px] += red[0][px + s_];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) blocksq[blockIdx.x] = red[0][0];
+    if (seg == 0 && p < P_TOTAL) grad[p] = ((red[0][px] + red[1][px]) + red[2][px]) + red[3][px];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float l = 0.f;
         for (int w = 0; w < n_part; ++w) l += loss_partial[w];
@@ -408,8 +392,8 @@ __global__ __launch_bounds__(1024) void iqn_grad_reduce(const float *__restrict_
 
 constexpr int N_SQ = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
 
-// Per-block sum of squares of a gradient the caller changed after mn_iqn_train_grad (the all-reduced one of a shared learner).
-__global__ __launch_bounds__(256) void iqn_sumsq(const float *__restrict__ grad, float *__restrict__ blocksq) {
+// Per-block sum of squares of the (possibly all-reduced) gradient; block 0 advances the optimizer step counter.
+__global__ __launch_bounds__(256) void iqn_sumsq(const float *__restrict__ grad, float *__restrict__ blocksq, int32_t *__restrict__ step) {
     __shared__ float red[256];
     const int p = blockIdx.x * 256 + threadIdx.x;
     const float gq = p < P_TOTAL ? grad[p] : 0.f;
@@ -419,17 +403,18 @@ __global__ __launch_bounds__(256) void iqn_sumsq(const float *__restrict__ grad,
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) blocksq[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) {
+        blocksq[blockIdx.x] = red[0];
+        if (blockIdx.x == 0) *step += 1;
+    }
 }
 
 // clip_grad_norm_(max_norm) (torch/nn/utils/clip_grad.py: coef = min(1, max_norm / (norm + 1e-6))) followed by
 // torch.optim.Adam's update: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
-// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The step count lives on the device: step[0] = optimizer
-// steps taken so far, step[1] = arrival ticket of this launch -- every block reads step[0] BEFORE it takes a ticket, and
-// the block that takes the last one publishes t = step[0] + 1 and clears the ticket, so no block can see the new count.
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  `step` lives on the device (hipGraph-capturable).
 __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
                                                 float *__restrict__ v, const float *__restrict__ blocksq,
-                                                int32_t *__restrict__ step, double lr, double b1, double b2,
+                                                const int32_t *__restrict__ step, double lr, double b1, double b2,
                                                 double eps_d, double max_norm_d) {
     __shared__ float red[256];
     red[threadIdx.x] = threadIdx.x < N_SQ ? blocksq[threadIdx.x] : 0.f;
@@ -440,12 +425,7 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     }
     const float norm = sqrtf(red[0]);
     const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
-    const int t = step[0] + 1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&step[1], 1) == (int)gridDim.x - 1) { step[1] = 0; __threadfence(); step[0] = t; }
-    }
+    const int t = *step;   // already advanced by iqn_sumsq
     // python-float (double) scalars of torch's Adam, rounded to float32 where the tensor kernels consume them
     const float step_size = (float)(lr / (1.0 - pow(b1, (double)t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
@@ -562,21 +542,18 @@ extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_nex
     hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_part), dim3(THREADS), LDS_BYTES, s, ring_states, ring_next_states, ring_actions,
                        ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev, params_local, params_target, partial,
                        loss_partial, batch, gamma);
-    float *blocksq = workspace + (size_t)n_part * (P_TOTAL + 1);
     hipLaunchKernelGGL(iqn_grad_reduce, dim3(N_SQ), dim3(1024), 0, s, partial, loss_partial, n_part, grad_out,
-                       loss_out, blocksq);
+                       loss_out);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 
 extern "C" int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev,
                                  float *workspace, int32_t batch, double lr, double beta1, double beta2, double eps,
-                                 double max_norm, int32_t grad_changed, void *stream) {
+                                 double max_norm, void *stream) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !workspace || batch <= 0 || batch % BE) return MN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     float *blocksq = workspace + (size_t)(batch / BE) * (P_TOTAL + 1);
-    // the norm partials of mn_iqn_train_grad's own gradient are already in the workspace; recompute them only for a
-    // gradient the caller modified in between (averaged over ranks)
-    if (grad_changed) hipLaunchKernelGGL(iqn_sumsq, dim3(N_SQ), dim3(256), 0, s, grad, blocksq);
+    hipLaunchKernelGGL(iqn_sumsq, dim3(N_SQ), dim3(256), 0, s, grad, blocksq, step_dev);
     hipLaunchKernelGGL(iqn_adam, dim3(N_SQ), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, blocksq, step_dev, lr, beta1,
                        beta2, eps, max_norm);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;

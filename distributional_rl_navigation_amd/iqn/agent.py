@@ -51,7 +51,6 @@ class IQNAgent:
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
         # Adam) instead of ~150 PyTorch autograd / Adam kernels; False = the PyTorch path (always used on the CPU)
         self.use_fused_train = torch.device(device).type == "cuda"
-        self.use_presample = True                    # HIP gradient step: next batch's index / tau draw on a side stream
         self._fused = None
 
         self.qnetwork_local = ObsEncoder(state_size, action_size, seed, device)
@@ -276,20 +275,15 @@ class IQNAgent:
                 self._fused.sync_from_optimizer(self.optimizer)
         self._train_path = path
 
-    def train_from_memory(self, presample_next=None):
+    def train_from_memory(self):
         """`self.train(self.memory.sample())` (agent.py:131-133).  With `use_fused_train` the HIP step gathers its batch
-        straight from the device ring (no sampled copies).  `presample_next`: draw the next step's indices / taus right
-        away on a side stream (default: when the ring is full, i.e. the next call will sample from the same range)."""
+        straight from the device ring (no sampled copies)."""
         if self.use_fused_train and self.device.type == "cuda":
             m = self.memory
             ft = self._fused_trainer()
             self._enter_train_path("hip")
             idx, taus = ft.sample(m.size, self.BATCH_SIZE)                   # replay_buffer.py:47 + model.py:149
             loss = ft.step((m.states, m.actions, m.rewards, m.next_states, m.dones), idx, taus[0], taus[1])
-            if presample_next is None:
-                presample_next = m.size == m.capacity
-            if presample_next and self.use_presample:
-                ft.presample(m.size, self.BATCH_SIZE)
             self.grad_steps += 1
             return loss
         return self.train(self.memory.sample())
@@ -522,10 +516,8 @@ class IQNAgent:
         loss = None
         if self.current_timestep >= self.learning_starts:
             if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
-                G = self.grad_steps_per_update                      # 1 = the reference's cadence (agent.py:129-133)
-                full = self.memory.size == self.memory.capacity
-                for i in range(G):      # pre-draw the next batch while this one trains, whenever the ring size will not change
-                    loss = self.train_from_memory(presample_next=(i + 1 < G) or full)
+                for _ in range(self.grad_steps_per_update):      # 1 = the reference's cadence (agent.py:129-133)
+                    loss = self.train_from_memory()
             if self.target_sync_grad_steps is None:
                 if self.learning_timestep % self.target_update_interval == 0:
                     self.soft_update(self.qnetwork_local, self.qnetwork_target)

@@ -1,5 +1,5 @@
 """Host side of the fused HIP gradient step (csrc/iqn_train.hip): IQNAgent.train (thirdparty/IQN/agent.py:269-304)
-as three kernels behind `mn_iqn_train_grad` / `mn_iqn_train_adam` (+ the sampler, pre-drawn on a side stream).
+as three kernels behind `mn_iqn_train_grad` / `mn_iqn_train_adam`.
 
 The kernels work on FLAT parameter vectors (35 785 floats, `named_parameters()` order).  `FusedTrainer` allocates one
 flat buffer per network and re-points every `nn.Parameter` at a view of it, so the PyTorch modules (checkpoints,
@@ -52,8 +52,7 @@ class FusedTrainer:
         self.target = flatten_network(agent.qnetwork_target)
         z = lambda: torch.zeros(P_TOTAL, dtype=torch.float32, device=self.device)
         self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
-        self._step2 = torch.zeros(2, dtype=torch.int32, device=self.device)     # {optimizer steps taken, the Adam kernel's arrival ticket}
-        self.step_dev = self._step2[:1]
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws, self._ws_batch = None, 0
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
@@ -62,10 +61,6 @@ class FusedTrainer:
         self.rng_state[0] += 0x9E3779B1 * int(getattr(agent, "rank", 0))     # decorrelate the ranks of a shared learner
         self._idx, self._taus = {}, {}
         self._arange = {}
-        # pre-sampling: the index / tau draw of the NEXT gradient step runs on a side stream while this step's reduction
-        # and Adam kernels run (the sampler is one workgroup, 11 us of latency; nothing else needs that stream)
-        self._side = None
-        self._pre_key, self._pre_event, self._grad_event = None, None, None
         off = 0
         for p in agent.qnetwork_local.parameters():      # p.grad = the (clipped) gradient of the last step, as torch
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
@@ -119,42 +114,17 @@ class FusedTrainer:
             self._ws_batch = batch
         return self._ws
 
-    def _launch_sample(self, ring_size, batch, stream):
+    def sample(self, ring_size, batch):
+        """ReplayBuffer.sample's index draw + the step's tau draws in ONE kernel -> (idx [B] i64, taus [2, B, 8])."""
         if batch not in self._idx:
             self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
             self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)
         idx, taus = self._idx[batch], self._taus[batch]
-        rc = _capi.lib().mn_iqn_sample(int(ring_size), batch, _p(self.rng_state), _p(idx), _p(taus), taus.numel(),
-                                       C.c_void_p(stream.cuda_stream))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_iqn_sample(int(ring_size), batch, _p(self.rng_state), _p(idx), _p(taus), taus.numel(), stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_sample failed ({rc}): need batch <= 1024 and ring_size >= batch")
         return idx, taus
-
-    def sample(self, ring_size, batch):
-        """ReplayBuffer.sample's index draw + the step's tau draws in ONE kernel -> (idx [B] i64, taus [2, B, 8]).
-        If `presample` drew exactly this (ring size, batch) ahead of time, its result is used."""
-        cur = torch.cuda.current_stream(self.device)
-        if self._pre_event is not None:
-            cur.wait_event(self._pre_event)          # also orders the two streams' use of rng_state and the buffers
-            hit = self._pre_key == (int(ring_size), int(batch))
-            self._pre_key, self._pre_event = None, None
-            if hit:
-                return self._idx[batch], self._taus[batch]
-        return self._launch_sample(ring_size, batch, cur)
-
-    def presample(self, ring_size, batch):
-        """Draw the NEXT step's indices and taus now, on the side stream, behind the forward / backward kernel of the
-        step just launched (which is the last reader of the buffers): it overlaps that step's reduction + Adam kernels
-        or whatever the main stream does next.  The draw sequence is the same as without pre-sampling."""
-        if self._grad_event is None:
-            return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self._side.wait_event(self._grad_event)
-        self._launch_sample(ring_size, batch, self._side)
-        self._pre_event = torch.cuda.Event()
-        self._pre_event.record(self._side)
-        self._pre_key = (int(ring_size), int(batch))
 
     def step(self, ring, idx=None, taus_target=None, taus_local=None):
         """One optimizer step.  `ring` = (states [c,26] f32, actions [c,1] i64, rewards [c,1] f32, next_states [c,26] f32,
@@ -186,9 +156,6 @@ class FusedTrainer:
                                  B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_grad failed ({rc})")
-        if self._grad_event is None:
-            self._grad_event = torch.cuda.Event()
-        self._grad_event.record(torch.cuda.current_stream(self.device))      # idx / taus / ring rows have been consumed
         if ag.distributed:
             import torch.distributed as dist
             if dist.get_backend() == "gloo":
@@ -199,9 +166,8 @@ class FusedTrainer:
             else:
                 dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)        # one 143 KB bucket over RCCL/xGMI
             self.grad.div_(dist.get_world_size())
-        rc = L.mn_iqn_train_adam(_p(self.local), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self._step2),
+        rc = L.mn_iqn_train_adam(_p(self.local), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev),
                                  _p(self._workspace(B)), B, C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5),
-                                 1 if ag.distributed else 0,      # an all-reduced gradient needs its norm partials recomputed
                                  stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_adam failed ({rc})")

@@ -296,12 +296,10 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  *   workspace                 : mn_iqn_train_workspace_floats(batch) floats of scratch (per-workgroup partial gradients,
  *                               norm partials); pass the same buffer and batch to both calls
  *   grad_out [35 785]         : d loss / d params_local (un-clipped); loss_out [1]: the loss
- * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics) and leaves the gradient's
- * norm partials in the workspace; the caller may average grad_out over ranks (RCCL all-reduce) before mn_iqn_train_adam
- * -- then with grad_changed = 1, which recomputes the partials -- which applies clip_grad_norm_(max_norm)
- * (agent.py:299) and one torch.optim.Adam update (agent.py:300; exp_avg / exp_avg_sq [35 785]; step_dev: i32[2] on the
- * device, ZERO-initialised by the caller: [0] = optimizer steps taken, advanced by the call, [1] = scratch; grad is
- * overwritten with the clipped gradient).
+ * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics); the caller may average
+ * grad_out over ranks (RCCL all-reduce) before mn_iqn_train_adam, which applies clip_grad_norm_(max_norm)
+ * (agent.py:299) and one torch.optim.Adam update (agent.py:300; exp_avg / exp_avg_sq [35 785], step_dev: i32 step
+ * counter on the device, incremented by the call; grad is overwritten with the clipped gradient).
  * batch must be even, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
 /* ReplayBuffer.sample (replay_buffer.py:42-47): `batch` DISTINCT uniform row indices in [0, ring_size) -> idx_out
@@ -316,8 +314,7 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
                       const float *params_target, float *workspace, float *grad_out, float *loss_out, int32_t batch,
                       int32_t num_taus, float gamma, void *stream);
 int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
-                      int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, int32_t grad_changed,
-                      void *stream);
+                      int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
 
 /* Benchmark hook: HIP events on the launch stream around the next act launches of this context (weight / random-number
  * preparation launch included). */

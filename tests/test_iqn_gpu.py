@@ -275,7 +275,6 @@ def test_fused_train_is_deterministic_and_seeded(torch):
         ag.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
         losses = [float(ag.train_from_memory()) for _ in range(6)]
         ft = ag._fused
-        torch.cuda.synchronize()      # (the next batch is pre-drawn on a side stream)
         runs.append((losses, ft.local.clone(), ft._idx[256].clone(), ft._taus[256].clone()))
     (l0, p0, i0, t0), (l1, p1, i1, t1), (l2, p2, i2, t2) = runs
     assert l0 == l1 and torch.equal(p0, p1) and torch.equal(i0, i1) and torch.equal(t0, t1)
@@ -308,7 +307,7 @@ def test_iqn_c_abi_argument_checks(torch):
                          p(f), p(taus), B, K, C.c_float(0.99), None)
     assert L.mn_iqn_train_grad(*args(3, 8)) == INVALID      # odd batch
     assert L.mn_iqn_train_grad(*args(2, 32)) == INVALID     # training uses 8 taus
-    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, 0, None) == INVALID
+    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, None) == INVALID
     assert L.mn_iqn_act(None, p(ring[0]), p(taus), None, None, None, C.c_float(0.0), p(idx), None, 4, 32, None) == INVALID
 
 
@@ -390,32 +389,3 @@ def test_hip_and_torch_gradient_steps_share_one_adam_state(torch):
     assert int(mixed._fused.step_dev) == 7
     st = mixed.optimizer.state[p0]
     assert st["exp_avg"].data_ptr() == mixed._fused.exp_avg.data_ptr()           # same memory, not a copy
-
-
-def test_presampling_on_a_side_stream_changes_nothing(torch):
-    """The next batch's index / tau draw runs on a side stream behind the current forward / backward kernel
-    (FusedTrainer.presample).  Same draw sequence, same batches: losses, gradients and weights are BITWISE those of the
-    run that samples on the main stream -- with the ring full (every step pre-draws), while it is still filling (the
-    ring size changes between training events: a pre-draw for a stale size is discarded), and when calls for other batch
-    geometries (an evaluation-time `train(experiences)`) come in between."""
-    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
-    dev = "cuda:0"
-    out = []
-    for pre in (False, True):
-        g = torch.Generator(device=dev); g.manual_seed(5)
-        ag = IQNAgent(26, 9, BATCH_SIZE=128, seed=21, BUFFER_SIZE=3000, device=dev)
-        ag.use_presample = pre
-        losses = []
-        for rnd in range(8):                                  # ring: 500, 1000, ... 3000 (full from round 6 on)
-            s_, ac, r, ns, d = _random_batch(torch, 500, g)
-            ag.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
-            full = ag.memory.size == ag.memory.capacity
-            for i in range(5):                                # vec_step's pattern: G steps per event
-                losses.append(float(ag.train_from_memory(presample_next=(i < 4) or full)))
-            if rnd == 3:                                      # a step on explicit experiences in between
-                exp = _random_batch(torch, 64, g)
-                losses.append(float(ag.train(exp)))
-        torch.cuda.synchronize()
-        out.append((losses, ag._fused.local.clone(), ag._fused.grad.clone(), int(ag._fused.step_dev)))
-    (l0, p0, g0, t0), (l1, p1, g1, t1) = out
-    assert l0 == l1 and torch.equal(p0, p1) and torch.equal(g0, g1) and t0 == t1 == 41
