@@ -195,7 +195,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    roll = args.rollout if (agent is None and args.rollout > 0) else 0
+    if args.rollout > 0 and agent is not None:
+        raise SystemExit("--rollout is the random-policy workload (BASELINE configs[1]): use it with --no-learner")
+    roll = args.rollout if args.rollout > 0 else 0
     if roll and (args.steps % roll or args.warmup % roll):
         raise SystemExit(f"--rollout {roll}: --steps and --warmup must be multiples of it")
     trace = tuple(k for k in args.rollout_trace.split(",") if k)

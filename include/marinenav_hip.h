@@ -166,7 +166,8 @@ int mn_step_append(mn_handle *h, const int32_t *actions_dev, const float *prev_o
  *   obs_trace_dev    [n_steps][n][26]  : the observation each step returned (terminal observation for a finished env)
  *   reward_trace_dev [n_steps][n] f32, done_trace_dev / info_trace_dev [n_steps][n] u8, action_trace_dev [n_steps][n] i32
  * first_env_index = this handle's offset in a sharded run (rank * n_envs), so shards draw the actions of their slice.
- * Afterwards nothing is pending for mn_reset_done and mn_last_done_count reports 0. */
+ * Afterwards nothing is pending for mn_reset_done and mn_last_done_count reports 0.  (Envs a preceding mn_step flagged
+ * done are NOT reset by this call: finish the mn_step / mn_reset_done pair before switching to mn_rollout.) */
 int mn_rollout(mn_handle *h, int32_t n_steps, const int32_t *actions_dev, uint64_t action_seed, uint64_t first_step_index,
                uint64_t first_env_index, float *obs_dev, float *obs_trace_dev, float *reward_trace_dev,
                uint8_t *done_trace_dev, uint8_t *info_trace_dev, int32_t *action_trace_dev, void *stream);
