@@ -109,6 +109,8 @@ def main():
                     help="with --no-learner: T vector steps per launch through mn_rollout (in-kernel random actions and resets); "
                          "--steps must be a multiple of T.  0 = one mn_step + mn_reset_done launch pair per vector step")
     ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "f64"],
+                    help="env kernels: mixed (default; float32 field / sonar decisions, 1e-5 on float32 outputs) or f64 (everything float64, 1e-9)")
     ap.add_argument("--act-variant", type=int, default=0, help="acting kernel: 0 = v_mfma_f32_16x16x4_f32 (default), 1 = the v_mfma_f32_32x32x2_f32 re-layout")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
@@ -149,7 +151,7 @@ def main():
 
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
-    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision="mixed", step_lanes=args.lanes,
+    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision=args.precision, step_lanes=args.lanes,
                           rollout_lanes=args.lanes if args.lanes != 1 else 0)
     env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
     obs = env.reset()
@@ -285,7 +287,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_detail": "IQN act / train: f32 (exact-f32 MFMA); env kernels: f64 pose integration + f64 sonar geometry, f32 field",
+            "dtype_detail": "IQN act / train: f32 (exact-f32 MFMA); env kernels: " + ("f64 pose integration + f64 sonar geometry, f32 field and sonar decisions"
+                                                                                      if args.precision == "mixed" else "f64 throughout"),
             "data": "synthetic (seeded random worlds, random-init IQN)",
             "config": {
                 "workload": ((f"step kernel only, random policy, {roll} vector steps per launch (mn_rollout: in-kernel actions + resets, traces: {','.join(trace) or 'none'})"
@@ -307,6 +310,7 @@ def main():
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             "roofline_env_step": {
+                "precision": args.precision,
                 "kernel": "mn_rollout_kernel<float,false,L>" if roll else ("mn_step_kernel<float,false,L,APPEND=true> (step + replay append)" if fused_append else "mn_step_kernel<float,false,L>"),
                 "env_steps_per_launch": per_launch,
                 "bound": "hbm",
