@@ -35,6 +35,8 @@
 
 #include "marinenav_hip.h"
 
+#define MN_IQN_VARIANT_DEFAULT 0
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -732,6 +734,8 @@ __global__ __launch_bounds__(256) void iqn_prep32_kernel(IqnWeights w, float *__
 
 }  // namespace v32
 
+#include "iqn_act_split.h"
+
 }  // namespace
 
 // C-ABI ----------------------------------------------------------------------------------------------
@@ -745,8 +749,10 @@ struct mn_iqn_ctx {
     int n_cu = 0;
     float *packed = nullptr;       // weight image of the 16x16x4 kernel (act_eval's quantile variant, variant 1)
     float *packed32 = nullptr;     // weight image of the 32x32x2 kernel (default acting path)
-    bool dirty = true, dirty32 = true;
-    int variant = 0;               // mn_iqn_set_variant: 0 = 16x16x4 kernel (default, the faster one), 1 = 32x32x2 kernel
+    uint32_t *packed_sp = nullptr; // weight image of the split-f16 kernel (iqn_act_split.h)
+    float *consts_sp = nullptr;    // its scale / bound constants
+    bool dirty = true, dirty32 = true, dirty_sp = true;
+    int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
@@ -763,14 +769,20 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(v32::iqn_qvals32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+                            v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
         return MN_ERR_HIP;
     mn_iqn_ctx *c = new mn_iqn_ctx();
     c->device = dev;
     c->n_cu = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void **>(&c->packed), OFF_FB * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->packed32), v32::OFF_FB * sizeof(float)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&c->packed32), v32::OFF_FB * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST * sizeof(float)) != hipSuccess) {
         (void)hipFree(c->packed);
+        (void)hipFree(c->packed32);
+        (void)hipFree(c->packed_sp);
         delete c;
         return MN_ERR_ALLOC;
     }
@@ -786,6 +798,8 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->packed);
     (void)hipFree(c->packed32);
+    (void)hipFree(c->packed_sp);
+    (void)hipFree(c->consts_sp);
     if (moved) (void)hipSetDevice(cur);
     delete c;
     return MN_OK;
@@ -795,11 +809,12 @@ extern "C" int mn_iqn_weights_changed(mn_iqn_ctx *c) {
     if (!c) return MN_ERR_INVALID;
     c->dirty = true;
     c->dirty32 = true;
+    c->dirty_sp = true;
     return MN_OK;
 }
 
 extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
-    if (!c || (variant != 0 && variant != 1)) return MN_ERR_INVALID;
+    if (!c || variant < 0 || variant > 2) return MN_ERR_INVALID;
     c->variant = variant;
     return MN_OK;
 }
@@ -850,8 +865,30 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     hipStream_t s = (hipStream_t)stream;
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
-    // the 32x32x2 kernel is opt-in (mn_iqn_set_variant(ctx, 1)); quantile capture (act_eval) always runs on the 16x16x4 kernel
+    // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 1 = exact-f32 32x32x2 kernel, 2 = split-f16 kernel
+    // (iqn_act_split.h); quantile capture (act_eval) always runs on the exact 16x16x4 kernel
+    const bool use_sp = !quantiles_dev && c->variant == 2;
     const bool use32 = !quantiles_dev && c->variant == 1;
+    if (use_sp) {
+        const int pack_blocks = c->dirty_sp ? sp::PACK_BLOCKS : 0;
+        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(256), 0, s, w, c->consts_sp);
+        if (rng_state_dev) {
+            long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
+            int rng_blocks = (int)((groups + 255) / 256);
+            if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
+            hipLaunchKernelGGL(sp::iqn_split_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                               c->packed_sp, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
+            taus_dev = draws_dev;
+            explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
+        } else if (pack_blocks) {
+            hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
+        }
+        c->dirty_sp = false;
+        hipLaunchKernelGGL(sp::iqn_qvals_split_kernel, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                           (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+        if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
+        return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+    }
     bool &dirty = use32 ? c->dirty32 : c->dirty;
     float *packed = use32 ? c->packed32 : c->packed;
     const int pack_blocks = dirty ? (use32 ? v32::PACK_BLOCKS : PACK_BLOCKS) : 0;

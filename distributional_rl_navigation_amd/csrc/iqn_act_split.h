@@ -1,0 +1,502 @@
+// iqn_act_split.h -- the IQN action-value network of iqn_act.hip on the f16 matrix pipe at float32 accuracy.
+// Included by iqn_act.hip inside its anonymous namespace (uses IqnWeights, row_sum16, draw_block, the layer constants).
+//
+// Why: the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate, 1/16 of the f16 rate, and the act kernel
+// built on it sits at 84 % of that peak -- the only way to go substantially faster is to leave that
+// pipe.  Here every f32 operand x is split into two f16 pieces, hi = RNE16(x), lo = RNE16(x - hi) (the subtraction is exact,
+// so x = hi + lo + e with |e| <= 2^-24 |x| as long as lo stays above the f16 subnormal floor), and a product of two
+// operands is accumulated as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16: f16 x f16 products are exact in the f32
+// accumulator, the dropped lo.lo term and the two e terms are each <= 2^-24 relative.  That is the error class of one f32
+// rounding per product; measured against a float64 reference the three-product scheme is as close as the exact-f32 MFMA
+// on these layer shapes (profiles/r02_f16_split_probe.txt: rms error 1.7e-7 vs 1.95e-7 relative, K = 224), f16 subnormal
+// inputs are not flushed by the matrix pipe, and three f16 MFMAs cost 3/16 of the f32 instruction they replace
+// (2057 vs 145.5 TFLOP/s sustained in the same probe).
+//
+// Range.  f16 tops out at 65504, so operands are scaled by powers of two (exact) before the split and the accumulators
+// are unscaled in the layer epilogues (one v_fma that replaces the bias add, so no extra instruction):
+//   * weights of layer l: 2^k_l with max |W_l| 2^k_l in [2^14, 2^15)                    (static, part of the weight image);
+//   * cos embedding: in [-1, 1], not scaled (an f16 pair keeps an absolute error of 2^-25 for ANY |x| <= 1, i.e. 2^-25 of
+//     the largest element, which is what a dot product's error is measured against);
+//   * hidden activations: ONE power of two S per environment, carried through all layers (ReLU is positively
+//     homogeneous: relu(W (S h) + S b) = S relu(W h + b)); S is chosen from a guaranteed bound, not from the data:
+//         |h1_j| <= B1_j |f_j|,  B1_j = sum_k |W1_jk| + |b1_j|     (|cos| <= 1),      m1 = max_j B1_j |f_j|   (per env)
+//         |h2_i| <= R2 m1 + beta2,  R2 = max_i sum_j |W2_ij|,  beta2 = max |b2|;   |h3| <= R3 (R2 m1 + beta2) + beta3
+//     and S = 2^(14 - floor(log2 M)) for M = the largest of the three bounds, so S |h| < 2^15 always: no overflow for
+//     any weights and any observation.  The bound is conservative (row-sum norms), typically by 2^6..2^10; that costs
+//     nothing as long as the largest activation stays above 2^-1 after scaling (17 binades of slack), see the probe's
+//     "scale 2^-10 lower" rows.
+// The observation encoders, the tau-mean and the 9 x 64 output layer stay f32 VALU work as in the exact kernel.
+//
+// Layout.  Same transposed, register-chained scheme as the exact kernel: weights are the A operand (16 output features x
+// 32 k, lane (g, row) holds k slots 8 g + i), activations the B operand (32 k x 16 taus), C tile [16 features x 16 taus]
+// with lane (g, col) holding features 4 g + r.  K block b of the NEXT layer consumes C tiles 2b and 2b + 1: k slot
+// (g, i) := feature 16 (2b + (i >> 2)) + 4 g + (i & 3), i.e. exactly registers 0..3 of the two tiles in lane group g --
+// a layer's accumulators, split in place, ARE the next layer's B operands.  Layer 2's K = 208 is 6.5 blocks: the 7th
+// block's upper half is zero (weights and activations).
+//
+// act_eval's per-tau quantile output keeps using the exact kernel (iqn_qvals_kernel<true>).
+
+namespace sp {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KB2 = 7;                                  // layer-2 K blocks (208 -> 224)
+// weight image, in 16-byte units (8 halves = one lane's A operand): [.. tile ..][piece: hi, lo][64 lanes]
+constexpr int W1_U4 = 0;                                // [13 mt][2 kb]
+constexpr int W2_U4 = W1_U4 + T1 * 2 * 2 * 64;          // [4 mt][7 kb]
+constexpr int W3_U4 = W2_U4 + 4 * KB2 * 2 * 64;         // [4 mt][2 kb]
+constexpr int END_U4 = W3_U4 + 4 * 2 * 2 * 64;
+// float part (indices in floats from the start of the image)
+constexpr int OFF_W4 = END_U4 * 4;                      // [4 t2][64 l][4 r] f32 output layer, as in the exact kernel
+constexpr int OFF_B1 = OFF_W4 + 4 * 64 * 4;             // [208]
+constexpr int OFF_B2 = OFF_B1 + F;                      // [64]
+constexpr int OFF_B3 = OFF_B2 + H;                      // [64]
+constexpr int OFF_B4 = OFF_B3 + H;                      // [16]
+constexpr int OFF_BND = OFF_B4 + 16;                    // [208] B1_j
+constexpr int OFF_CST = OFF_BND + F;                    // [16] c1 c2 c3 (accumulator unscale), a2 d2 a3 d3 (activation bounds)
+constexpr int OFF_WS = OFF_CST + 16;                    // [6 i4][176 sf][4] sensor encoder, inputs 4 + 4 i4 + c
+constexpr int OFF_WVG = OFF_WS + 6 * 176 * 4;           // [32 f][2] velocity / goal encoders
+constexpr int OFF_BE = OFF_WVG + 64;                    // [208] encoder biases
+constexpr int OFF_FB = OFF_BE + F;                      // [8 waves][208] per-wave scaled features
+constexpr int LDS_FLOATS = OFF_FB + 8 * F;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS image of the split-f16 act kernel must fit the CU's 160 KB");
+static_assert(OFF_WS % 4 == 0 && OFF_WVG % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0 && OFF_CST % 4 == 0, "16-byte aligned blocks");
+constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;       // one thread per 32-bit word of the image
+constexpr int N_CONST = 16;
+
+// power of two p with amax * p in [2^14, 2^15)  (amax > 0 finite); 1 for degenerate input
+__device__ __forceinline__ float pow2_to_2p15(float amax) {
+    if (!(amax > 1e-30f) || !(amax < 1e30f)) return 1.0f;
+    const int e = (int)(__builtin_bit_cast(uint32_t, amax) >> 23);       // amax in [2^(e-127), 2^(e-126))
+    return __builtin_bit_cast(float, (uint32_t)(268 - e) << 23);         // 2^(141 - e)
+}
+
+__device__ __forceinline__ float block_max_256(float v, float *red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3
+// (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 256 threads.
+__global__ __launch_bounds__(256) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    for (int i = tid; i < F * N_COS; i += 256) m1 = fmaxf(m1, fabsf(w.W1[i]));
+    for (int i = tid; i < H * F; i += 256) m2 = fmaxf(m2, fabsf(w.W2[i]));
+    for (int i = tid; i < H * H; i += 256) m3 = fmaxf(m3, fabsf(w.W3[i]));
+    m1 = block_max_256(m1, red); m2 = block_max_256(m2, red); m3 = block_max_256(m3, red);
+    float r2 = 0.f, r3 = 0.f, be2 = 0.f, be3 = 0.f;
+    if (tid < H) {
+        for (int j = 0; j < F; ++j) r2 += fabsf(w.W2[tid * F + j]);
+        for (int j = 0; j < H; ++j) r3 += fabsf(w.W3[tid * H + j]);
+        be2 = fabsf(w.b2[tid]); be3 = fabsf(w.b3[tid]);
+    }
+    r2 = block_max_256(r2, red); r3 = block_max_256(r3, red); be2 = block_max_256(be2, red); be3 = block_max_256(be3, red);
+    if (tid == 0) {
+        const float s1 = pow2_to_2p15(m1), s2 = pow2_to_2p15(m2), s3 = pow2_to_2p15(m3), infl = 1.0009765625f;
+        consts[0] = s1; consts[1] = s2; consts[2] = s3;
+        consts[3] = 1.0f / s1; consts[4] = 1.0f / s2; consts[5] = 1.0f / s3;      // exact: powers of two
+        consts[6] = r2 * infl; consts[7] = be2 * infl;
+        consts[8] = r3 * r2 * infl * infl; consts[9] = (r3 * be2 * infl + be3) * infl;
+        for (int i = 10; i < N_CONST; ++i) consts[i] = 0.f;
+    }
+}
+
+// the f32 weight behind A-operand k slot (g, i8) of [layer][mt][kb], row `row`
+__device__ __forceinline__ float split_weight(const IqnWeights &w, int layer, int mt, int kb, int g, int row, int i8) {
+    if (layer == 1) return w.W1[(16 * mt + row) * N_COS + 32 * kb + 8 * g + i8];
+    const int feat = 16 * (2 * kb + (i8 >> 2)) + 4 * g + (i8 & 3);
+    if (layer == 2) return feat < F ? w.W2[(16 * mt + row) * F + feat] : 0.f;
+    return w.W3[(16 * mt + row) * H + feat];
+}
+
+__device__ __forceinline__ uint32_t half_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(uint16_t, h); }
+
+// 32-bit word i of the image
+__device__ __forceinline__ uint32_t pack_word(const IqnWeights &w, const float *__restrict__ consts, int i) {
+    if (i < OFF_W4) {
+        const int u4 = i >> 2, pair = i & 3, lane = u4 & 63, piece = (u4 >> 6) & 1, g = lane >> 4, row = lane & 15;
+        int q = u4 >> 7, layer, mt, kb;
+        if (q < T1 * 2) { layer = 1; mt = q >> 1; kb = q & 1; }
+        else if (q < T1 * 2 + 4 * KB2) { q -= T1 * 2; layer = 2; mt = q / KB2; kb = q % KB2; }
+        else { q -= T1 * 2 + 4 * KB2; layer = 3; mt = q >> 1; kb = q & 1; }
+        const float sc = consts[layer - 1];
+        uint32_t out = 0;
+        for (int j = 0; j < 2; ++j) {
+            const float x = split_weight(w, layer, mt, kb, g, row, 2 * pair + j) * sc;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 v = piece == 0 ? hi : (_Float16)(x - (float)hi);
+            out |= half_bits(v) << (16 * j);
+        }
+        return out;
+    }
+    float v;
+    if (i < OFF_B1) {                // W4p[t2][l][r] = W4[l & 15][16 t2 + 4 (l >> 4) + r] (rows >= 9 are zero)
+        const int k = i - OFF_W4, r = k & 3, l = (k >> 2) & 63, t2 = k >> 8;
+        v = (l & 15) < A_OUT ? w.W4[(l & 15) * H + 16 * t2 + 4 * (l >> 4) + r] : 0.f;
+    } else if (i < OFF_B2) v = w.b1[i - OFF_B1];
+    else if (i < OFF_B3) v = w.b2[i - OFF_B2];
+    else if (i < OFF_B4) v = w.b3[i - OFF_B3];
+    else if (i < OFF_BND) v = (i - OFF_B4) < A_OUT ? w.b4[i - OFF_B4] : 0.f;
+    else if (i < OFF_CST) {          // B1_j = sum_k |W1_jk| + |b1_j|, inflated against the rounding of the sum
+        const int j = i - OFF_BND;
+        float s = fabsf(w.b1[j]);
+        for (int k = 0; k < N_COS; ++k) s += fabsf(w.W1[j * N_COS + k]);
+        v = s * 1.0009765625f;
+    } else if (i < OFF_WS) {         // CST[j] = consts[3 + j]: c1 c2 c3 a2 d2 a3 d3
+        const int j = i - OFF_CST;
+        v = 3 + j < N_CONST ? consts[3 + j] : 0.f;
+    }
+    else if (i < OFF_WVG) {          // WS[i4][sf][c] = se_w[sf][4 i4 + c] (22 inputs, zero padded to 24)
+        const int k = i - OFF_WS, c = k & 3, sf = (k >> 2) % 176, i4 = (k >> 2) / 176, inp = 4 * i4 + c;
+        v = inp < 22 ? w.se_w[sf * 22 + inp] : 0.f;
+    } else if (i < OFF_BE) {         // WVG[f][c]
+        const int k = i - OFF_WVG, c = k & 1, f = k >> 1;
+        v = f < 16 ? w.ve_w[f * 2 + c] : w.ge_w[(f - 16) * 2 + c];
+    } else {
+        const int f = i - OFF_BE;
+        v = f < 16 ? w.ve_b[f] : (f < 32 ? w.ge_b[f - 16] : w.se_b[f - 32]);
+    }
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(256) void iqn_split_pack_kernel(IqnWeights w, const float *__restrict__ consts, uint32_t *__restrict__ packed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < OFF_FB) packed[i] = pack_word(w, consts, i);
+}
+
+// weight image (when stale; consts from iqn_split_consts_kernel earlier in the stream) + the call's random numbers
+__global__ __launch_bounds__(256) void iqn_split_prep_kernel(IqnWeights w, const float *__restrict__ consts, uint32_t *__restrict__ packed,
+                                                             const uint64_t *__restrict__ rng_state, float *__restrict__ draws, int n,
+                                                             const float *__restrict__ cvar_row, float cvar, int pack_blocks) {
+    if ((int)blockIdx.x < pack_blocks) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < OFF_FB) packed[i] = pack_word(w, consts, i);
+        return;
+    }
+    draw_block(rng_state, draws, n, cvar_row, cvar, pack_blocks);
+}
+
+__device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// (x, y) -> hi pair, lo pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (x - hi, exact), v_cvt_pk_f16_f32
+__device__ __forceinline__ void split2(float x, float y, f16x2 &h, f16x2 &l) {
+    const f32x2 v = {x, y};
+    h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = {fmaf((float)h[0], -1.0f, x), fmaf((float)h[1], -1.0f, y)};
+    l = __builtin_convertvector(r, f16x2);
+}
+
+__device__ __forceinline__ f16x8 cat4(f16x2 a, f16x2 b, f16x2 c, f16x2 d) {
+    const f16x4 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+    return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// two C tiles (registers of one lane) -> the hi / lo B operands of the K block they form
+__device__ __forceinline__ void split_tiles(f32x4 t0, f32x4 t1, f16x8 &bh, f16x8 &bl) {
+    f16x2 h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(t0[0], t0[1], h0, l0); split2(t0[2], t0[3], h1, l1);
+    split2(t1[0], t1[1], h2, l2); split2(t1[2], t1[3], h3, l3);
+    bh = cat4(h0, h1, h2, h3); bl = cat4(l0, l1, l2, l3);
+}
+__device__ __forceinline__ void split_tile_lower(f32x4 t0, f16x8 &bh, f16x8 &bl) {     // upper half of the K block is padding
+    f16x2 h0, h1, l0, l1;
+    const f16x2 z = {(_Float16)0.f, (_Float16)0.f};
+    split2(t0[0], t0[1], h0, l0); split2(t0[2], t0[3], h1, l1);
+    bh = cat4(h0, h1, z, z); bl = cat4(l0, l1, z, z);
+}
+
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float c, f32x4 b) {
+    f32x4 r;
+    r.x = fmaf(a.x, c, b.x); r.y = fmaf(a.y, c, b.y); r.z = fmaf(a.z, c, b.z); r.w = fmaf(a.w, c, b.w);
+    return r;
+}
+
+// max over the wave of a non-negative value (uniform result)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    const int iv = __builtin_bit_cast(int, v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+constexpr int NT = 2;   // one environment = 32 tau rows = 2 column tiles per wave iteration
+
+// layer-1 MFMAs of layer-2 K block b (feature tiles 2b, 2b + 1; only 2b for the last block): 3 products x 2 cos K blocks
+template <int B>
+__device__ __forceinline__ void layer1_pair(const u32x4 *__restrict__ lds4, int lane, const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT],
+                                            f32x4 (&acc)[2][NT]) {
+    constexpr int NTI = (2 * B + 1 < T1) ? 2 : 1;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f16x8 ah[NTI], al[NTI];
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti) {
+            const int base = W1_U4 + (((2 * B + ti) * 2 + kb) * 2) * 64 + lane;
+            ah[ti] = __builtin_bit_cast(f16x8, lds4[base]);
+            al[ti] = __builtin_bit_cast(f16x8, lds4[base + 64]);
+        }
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(al[ti], cbh[kb][nt], acc[ti][nt]);
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(ah[ti], cbl[kb][nt], acc[ti][nt]);
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(ah[ti], cbh[kb][nt], acc[ti][nt]);
+    }
+}
+
+// epilogue of layer-1 pair B (bias, ReLU, Hadamard with the scaled features, split) + its layer-2 MFMAs
+template <int B>
+__device__ __forceinline__ void layer2_block(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const f32x4 *__restrict__ fbv,
+                                             int lane, int g, float c1, const f32x4 (&acc1)[2][NT], f32x4 (&acc2)[4][NT]) {
+    constexpr int NTI = (2 * B + 1 < T1) ? 2 : 1;
+    f32x4 h1[2][NT];
+#pragma unroll
+    for (int ti = 0; ti < NTI; ++ti) {
+        const f32x4 fv = fbv[4 * (2 * B + ti)];                            // S * features[16t + 4g + r]
+        const f32x4 bias = ldsv[(OFF_B1 >> 2) + 4 * (2 * B + ti) + g];     // b1[16t + 4g + r]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h1[ti][nt] = relu4(fma4(acc1[ti][nt], c1, bias)) * fv;
+    }
+    f16x8 bh[NT], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (NTI == 2) split_tiles(h1[0][nt], h1[1][nt], bh[nt], bl[nt]);
+        else split_tile_lower(h1[0][nt], bh[nt], bl[nt]);
+    }
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int base = W2_U4 + ((mt * KB2 + B) * 2) * 64 + lane;
+        ah[mt] = __builtin_bit_cast(f16x8, lds4[base]);
+        al[mt] = __builtin_bit_cast(f16x8, lds4[base + 64]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(al[mt], bh[nt], acc2[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(ah[mt], bl[nt], acc2[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(ah[mt], bh[nt], acc2[mt][nt]);
+}
+
+__global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
+                                                                 const uint32_t *__restrict__ packed, float *__restrict__ qvals,
+                                                                 const float *__restrict__ explore_u, float eps,
+                                                                 int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by the prep kernel
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(packed);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
+        for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, g = lane >> 4, col = lane & 15;
+    const int wave = tid >> 6, waves_per_block = blockDim.x >> 6;
+    const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
+    const u32x4 *lds4 = reinterpret_cast<const u32x4 *>(lds);
+    const float c1 = lds[OFF_CST + 0], c2 = lds[OFF_CST + 1], c3 = lds[OFF_CST + 2];
+    const float a2 = lds[OFF_CST + 3], d2 = lds[OFF_CST + 4], a3 = lds[OFF_CST + 5], d3 = lds[OFF_CST + 6];
+
+    // cos(tau * pi * k), k = 32 kb + 8 g + i, as cos(2 pi * frac(tau * k / 2)) like the exact kernel
+    float hk[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hk[kb][i] = 0.5f * (float)(32 * kb + 8 * g + i);
+
+    for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
+        float tau[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e * K_TAUS + 16 * nt + col];
+        // layer-1 B operands: the cos embedding (model.py:155), unscaled, split
+        f16x8 cbh[2][NT], cbl[2][NT];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f16x2 h[4], l[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    split2(__builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[kb][2 * p])),
+                           __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[kb][2 * p + 1])), h[p], l[p]);
+                cbh[kb][nt] = cat4(h[0], h[1], h[2], h[3]);
+                cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
+            }
+
+        // ---- observation encoders (model.py:170-173).  Lane l computes sensor features l, l + 64, l + 128 (22 inputs each)
+        // and, for l < 32, velocity / goal feature l (2 inputs); then the per-environment activation bound and scale S,
+        // and S * feature goes to this wave's LDS buffer for the Hadamard product
+        float S, invS;
+        {
+            const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
+            float ov[28];
+#pragma unroll
+            for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
+            float fval[4], bnd = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sf = lane + 64 * j;
+                fval[j] = 0.f;
+                if (sf < 176) {
+                    float a = lds[OFF_BE + 32 + sf];
+#pragma unroll
+                    for (int i4 = 0; i4 < 6; ++i4) {
+                        const f32x4 wv = ldsv[(OFF_WS >> 2) + i4 * 176 + sf];
+                        a += wv[0] * ov[4 + 4 * i4] + wv[1] * ov[5 + 4 * i4] + wv[2] * ov[6 + 4 * i4] + wv[3] * ov[7 + 4 * i4];
+                    }
+                    fval[j] = a;
+                    bnd = fmaxf(bnd, fabsf(a) * lds[OFF_BND + 32 + sf]);
+                }
+            }
+            fval[3] = 0.f;
+            if (lane < 32) {
+                const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + OFF_WVG)[lane];
+                const float i0 = lane < 16 ? ov[0] : ov[2], i1 = lane < 16 ? ov[1] : ov[3];
+                fval[3] = lds[OFF_BE + lane] + wv[0] * i0 + wv[1] * i1;
+                bnd = fmaxf(bnd, fabsf(fval[3]) * lds[OFF_BND + lane]);
+            }
+            const float m1 = wave_max_nonneg(bnd);
+            float M = fmaxf(fmaxf(m1, fmaf(a2, m1, d2)), fmaf(a3, m1, d3));
+            M = fminf(fmaxf(M, 1e-30f), 1e30f);
+            const int eM = (int)(__builtin_bit_cast(uint32_t, M) >> 23);          // M in [2^(eM-127), 2^(eM-126))
+            S = __builtin_bit_cast(float, (uint32_t)(268 - eM) << 23);           // 2^(141 - eM): S M < 2^15
+            invS = __builtin_bit_cast(float, (uint32_t)(eM - 14) << 23);         // 2^(eM - 141)
+            float *fb = lds + OFF_FB + wave * F;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sf = lane + 64 * j;
+                if (sf < 176) fb[32 + sf] = fval[j] * S;
+            }
+            if (lane < 32) fb[lane] = fval[3] * S;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const f32x4 *fbv = reinterpret_cast<const f32x4 *>(lds + OFF_FB + wave * F) + g;   // + 4*t per tile
+
+        // ---- layers 1 + 2 fused over the 7 K blocks of layer 2, software-pipelined as in the exact kernel: the layer-1
+        // MFMAs of block b + 1 are issued before the VALU epilogue of block b
+        f32x4 acc2[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 accA[2][NT], accB[2][NT];
+        layer1_pair<0>(lds4, lane, cbh, cbl, accA);
+        layer1_pair<1>(lds4, lane, cbh, cbl, accB); layer2_block<0>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
+        layer1_pair<2>(lds4, lane, cbh, cbl, accA); layer2_block<1>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
+        layer1_pair<3>(lds4, lane, cbh, cbl, accB); layer2_block<2>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
+        layer1_pair<4>(lds4, lane, cbh, cbl, accA); layer2_block<3>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
+        layer1_pair<5>(lds4, lane, cbh, cbl, accB); layer2_block<4>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
+        layer1_pair<6>(lds4, lane, cbh, cbl, accA); layer2_block<5>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
+        layer2_block<6>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
+
+        // ---- layer 2 epilogue (S h2 = relu(acc2 2^-k2 + S b2)), split, layer 3 ------------------------------------------
+        f16x8 b3h[2][NT], b3l[2][NT];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 sb[2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) sb[ti] = ldsv[(OFF_B2 >> 2) + 4 * (2 * kb + ti) + g] * S;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                split_tiles(relu4(fma4(acc2[2 * kb][nt], c2, sb[0])), relu4(fma4(acc2[2 * kb + 1][nt], c2, sb[1])), b3h[kb][nt], b3l[kb][nt]);
+        }
+        f32x4 acc3[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f16x8 ah[4], al[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int base = W3_U4 + ((mt * 2 + kb) * 2) * 64 + lane;
+                ah[mt] = __builtin_bit_cast(f16x8, lds4[base]);
+                al[mt] = __builtin_bit_cast(f16x8, lds4[base + 64]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(al[mt], b3h[kb][nt], acc3[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(ah[mt], b3l[kb][nt], acc3[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(ah[mt], b3h[kb][nt], acc3[mt][nt]);
+        }
+        // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
+        float part = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 sb = ldsv[(OFF_B3 >> 2) + 4 * mt + g] * S;
+            const f32x4 h0 = relu4(fma4(acc3[mt][0], c3, sb)), h1 = relu4(fma4(acc3[mt][1], c3, sb));
+            const f32x4 a = ldsv[(OFF_W4 >> 2) + mt * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float qv = part * (invS * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
+        if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
+        // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
+        if (actions) {
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int a = 0; a < A_OUT; ++a) {
+                const float v = __shfl(qv, a);
+                if (v > best) { best = v; arg = a; }
+            }
+            if (lane == 0) {
+                int act = arg;
+                if (explore_u && eps > 0.f) {
+                    const float u = explore_u[e];            // greedy iff u > eps (agent.py:200)
+                    if (!(u > eps)) { act = (int)(u / eps * (float)A_OUT); act = act > A_OUT - 1 ? A_OUT - 1 : act; }
+                }
+                actions[e] = act;
+            }
+        }
+    }
+}
+
+}  // namespace sp
