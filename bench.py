@@ -33,6 +33,8 @@ HBM_PEAK_GBS = 8000.0
 # the kernel takes the tau-mean before the linear output layer, so it executes 960 MFMAs = 1.966 MFLOP + a 9x64 mat-vec)
 ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md (micro-benchmark ceiling 2382; profiles/r02_f16_split_probe.txt: 2057 sustained by one instruction stream)
+ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_mfma_f32_16x16x32_f16 per environment (3 per f32 product, layer-2 K padded 208 -> 224)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at
 # 65 536 envs, 8 cores / 10 obstacles: profiles/r01_full_loop_kernel_stats.txt.  Not measured live.
 # 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
@@ -111,7 +113,7 @@ def main():
     ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "f64"],
                     help="env kernels: mixed (default; float32 field / sonar decisions, 1e-5 on float32 outputs) or f64 (everything float64, 1e-9)")
-    ap.add_argument("--act-variant", type=int, default=0, help="acting kernel: 0 = v_mfma_f32_16x16x4_f32 (default), 1 = the v_mfma_f32_32x32x2_f32 re-layout")
+    ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
 
@@ -287,9 +289,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_detail": "IQN act / train: f32 (exact-f32 MFMA); env kernels: " + ("f64 pose integration + f64 sonar geometry, f32 field and sonar decisions"
+            "dtype_detail": ("IQN act: f32 results from split-f16 MFMA (hi/lo f16 pieces, 3 products per f32 product; error vs float64 equal to the "
+                             "exact-f32 kernel's, tests/test_act_split_gpu.py), IQN train: f32 (exact-f32 MFMA); env kernels: " if args.act_variant == 2 else
+                             "IQN act / train: f32 (exact-f32 MFMA); env kernels: ") + ("f64 pose integration + f64 sonar geometry, f32 field and sonar decisions"
                                                                                       if args.precision == "mixed" else "f64 throughout"),
             "data": "synthetic (seeded random worlds, random-init IQN)",
+            "act_kernel_variant": args.act_variant,
             "config": {
                 "workload": ((f"step kernel only, random policy, {roll} vector steps per launch (mn_rollout: in-kernel actions + resets, traces: {','.join(trace) or 'none'})"
                               if roll else "step kernel only, random policy, one mn_step + mn_reset_done launch pair per vector step") if agent is None else
@@ -330,13 +335,25 @@ def main():
             },
         }
         if fused and act_ms > 0:
-            tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
+            alg_tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
+            if args.act_variant == 2:
+                # split-f16 kernel: the matrix pipe executes three f16 MFMAs per float32 product; `achieved` counts the FLOPs it
+                # ISSUES (incl. the 3x and the K padding) against the f16 dense peak, i.e. the fraction of the pipe that is busy
+                tf = ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
+                kern, peak = "iqn_qvals_split_kernel (3 x v_mfma_f32_16x16x32_f16 per f32 product, f32-class accuracy)", F16_MFMA_PEAK_TFLOPS
+            else:
+                tf = alg_tf
+                kern = "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)"
+                peak = F32_MFMA_PEAK_TFLOPS
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
-                "kernel": "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
+                "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak,
+                "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": PMC_TRAFFIC_BYTES["act"] if n == 65536 else None,
-                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch, same kernel; not live)",
-                "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "launch_ms": act_ms, "launches_timed": act_launches,
+                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch: observations + taus in, actions out -- the same for every kernel variant; not live)",
+                "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else ACT_FLOP_PER_ENV_STEP,
+                "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
+                "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,
+                "launch_ms": act_ms, "launches_timed": act_launches,
             }
         else:
             out["roofline"] = out["roofline_env_step"]

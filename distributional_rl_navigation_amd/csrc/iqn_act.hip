@@ -35,7 +35,7 @@
 
 #include "marinenav_hip.h"
 
-#define MN_IQN_VARIANT_DEFAULT 0
+#define MN_IQN_VARIANT_DEFAULT 2
 
 namespace {
 

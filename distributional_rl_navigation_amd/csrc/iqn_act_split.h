@@ -61,8 +61,9 @@ constexpr int OFF_CST = OFF_BND + F;                    // [16] c1 c2 c3 (accumu
 constexpr int OFF_WS = OFF_CST + 16;                    // [6 i4][176 sf][4] sensor encoder, inputs 4 + 4 i4 + c
 constexpr int OFF_WVG = OFF_WS + 6 * 176 * 4;           // [32 f][2] velocity / goal encoders
 constexpr int OFF_BE = OFF_WVG + 64;                    // [208] encoder biases
-constexpr int OFF_FB = OFF_BE + F;                      // [8 waves][208] per-wave scaled features
-constexpr int LDS_FLOATS = OFF_FB + 8 * F;
+constexpr int OFF_FB = OFF_BE + F;                      // [waves][208] per-wave scaled features
+constexpr int WAVES = 8;                                // one 512-thread workgroup per CU, two waves per SIMD
+constexpr int LDS_FLOATS = OFF_FB + WAVES * F;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS image of the split-f16 act kernel must fit the CU's 160 KB");
 static_assert(OFF_WS % 4 == 0 && OFF_WVG % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0 && OFF_CST % 4 == 0, "16-byte aligned blocks");
 constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;       // one thread per 32-bit word of the image
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint32_t pack_word(const IqnWeights &w, const float *
     if (i < OFF_B1) {                // W4p[t2][l][r] = W4[l & 15][16 t2 + 4 (l >> 4) + r] (rows >= 9 are zero)
         const int k = i - OFF_W4, r = k & 3, l = (k >> 2) & 63, t2 = k >> 8;
         v = (l & 15) < A_OUT ? w.W4[(l & 15) * H + 16 * t2 + 4 * (l >> 4) + r] : 0.f;
-    } else if (i < OFF_B2) v = w.b1[i - OFF_B1];
+    } else if (i < OFF_B2) v = w.b1[i - OFF_B1] * consts[0];    // pre-scaled like W1: it is the layer-1 accumulator's initial value
     else if (i < OFF_B3) v = w.b2[i - OFF_B2];
     else if (i < OFF_B4) v = w.b3[i - OFF_B3];
     else if (i < OFF_BND) v = (i - OFF_B4) < A_OUT ? w.b4[i - OFF_B4] : 0.f;
@@ -192,11 +193,15 @@ __global__ __launch_bounds__(256) void iqn_split_prep_kernel(IqnWeights w, const
 
 __device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// (x, y) -> hi pair, lo pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (x - hi, exact), v_cvt_pk_f16_f32
+// (x, y) -> hi pair, lo pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (x - hi, exact; written as asm because the SLP vectoriser
+// otherwise turns the pair into 2 x v_cvt_f32_f16 + v_pk_fma_f32), v_cvt_pk_f16_f32
 __device__ __forceinline__ void split2(float x, float y, f16x2 &h, f16x2 &l) {
     const f32x2 v = {x, y};
     h = __builtin_convertvector(v, f16x2);
-    const f32x2 r = {fmaf((float)h[0], -1.0f, x), fmaf((float)h[1], -1.0f, y)};
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    f32x2 r;
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel_hi:[0,0,1]" : "=v"(r[0]) : "v"(x), "v"(hb));
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[1]) : "v"(y), "v"(hb));
     l = __builtin_convertvector(r, f16x2);
 }
 
@@ -219,6 +224,17 @@ __device__ __forceinline__ void split_tile_lower(f32x4 t0, f16x8 &bh, f16x8 &bl)
     bh = cat4(h0, h1, z, z); bl = cat4(l0, l1, z, z);
 }
 
+// max(x, 0) as ONE instruction.  Written as a float compare / select (or fmaxf, or med3), a ReLU whose input is a raw MFMA
+// result gets a second v_max_f32 x, x, x in front of it (sNaN canonicalisation of an operand the compiler cannot prove
+// canonical).  On the bit patterns it is an integer max: negative floats are negative ints, non-negative floats order
+// like ints.  (Not inline asm: the MFMA -> VALU read hazard is software-managed and the compiler only counts wait states
+// for instructions it knows.)
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ f32x4 relu4s(f32x4 v) { return (f32x4){relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)}; }
+
 __device__ __forceinline__ f32x4 fma4(f32x4 a, float c, f32x4 b) {
     f32x4 r;
     r.x = fmaf(a.x, c, b.x); r.y = fmaf(a.y, c, b.y); r.z = fmaf(a.z, c, b.z); r.w = fmaf(a.w, c, b.w);
@@ -239,23 +255,42 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 
 constexpr int NT = 2;   // one environment = 32 tau rows = 2 column tiles per wave iteration
 
+// LDS addressing.  The image is 154 KB and a ds_read carries a 16-bit byte offset, so every read is written as
+// (opaque base register) + (compile-time constant < 64 KB): four bases cover the image.  Left to itself the compiler
+// materialises one address VGPR per read outside the environment loop (~70 registers), which caps the occupancy.
+struct LdsBase {
+    int w_lo;     // lane                       : 16-byte units [0, 4096)
+    int w_hi;     // lane + 4096                : 16-byte units [4096, 8192)  (rest of W2, W3, W4)
+    int fl;       // (OFF_B1 >> 2) + g          : biases, bounds (16-byte units, indexed by lane group)
+    int fb;       // this wave's feature buffer + g (16-byte units)
+};
+__device__ __forceinline__ u32x4 ld_w(const u32x4 *__restrict__ lds4, const LdsBase &lb, int c) {     // c: unit index without the lane
+    return c < 4096 - 64 ? lds4[lb.w_lo + c] : lds4[lb.w_hi + (c - 4096)];
+}
+
 // layer-1 MFMAs of layer-2 K block b (feature tiles 2b, 2b + 1; only 2b for the last block): 3 products x 2 cos K blocks
+// ---- the fused layer 1 + layer 2 pipeline, in three pieces per layer-2 K block B (feature tiles 2B, 2B + 1; the last block has one)
+constexpr int ntiles_of(int B) { return (2 * B + 1 < T1) ? 2 : 1; }
+
+// layer-1 MFMAs: 3 products x 2 cos K blocks; the accumulators start from the (pre-scaled) bias 2^k1 b1[16t + 4g + r]
 template <int B>
-__device__ __forceinline__ void layer1_pair(const u32x4 *__restrict__ lds4, int lane, const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT],
-                                            f32x4 (&acc)[2][NT]) {
-    constexpr int NTI = (2 * B + 1 < T1) ? 2 : 1;
+__device__ __forceinline__ void l1_mfma(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
+                                        const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], f32x4 (&acc)[2][NT]) {
+    constexpr int NTI = ntiles_of(B);
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < NTI; ++ti) {
+        const f32x4 bias = ldsv[lb.fl + 4 * (2 * B + ti)];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = bias;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         f16x8 ah[NTI], al[NTI];
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti) {
-            const int base = W1_U4 + (((2 * B + ti) * 2 + kb) * 2) * 64 + lane;
-            ah[ti] = __builtin_bit_cast(f16x8, lds4[base]);
-            al[ti] = __builtin_bit_cast(f16x8, lds4[base + 64]);
+            const int c = W1_U4 + (((2 * B + ti) * 2 + kb) * 2) * 64;
+            ah[ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+            al[ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
         }
 #pragma unroll
         for (int ti = 0; ti < NTI; ++ti)
@@ -272,47 +307,135 @@ __device__ __forceinline__ void layer1_pair(const u32x4 *__restrict__ lds4, int 
     }
 }
 
-// epilogue of layer-1 pair B (bias, ReLU, Hadamard with the scaled features, split) + its layer-2 MFMAs
+// layer-1 epilogue (VALU only): ReLU, Hadamard with the scaled features, split into the layer-2 B operands of block B
 template <int B>
-__device__ __forceinline__ void layer2_block(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const f32x4 *__restrict__ fbv,
-                                             int lane, int g, float c1, const f32x4 (&acc1)[2][NT], f32x4 (&acc2)[4][NT]) {
-    constexpr int NTI = (2 * B + 1 < T1) ? 2 : 1;
+__device__ __forceinline__ void l1_epilogue(const f32x4 *__restrict__ ldsv, const LdsBase &lb, const f32x4 (&acc1)[2][NT],
+                                            f16x8 (&bh)[NT], f16x8 (&bl)[NT]) {
+    constexpr int NTI = ntiles_of(B);
     f32x4 h1[2][NT];
 #pragma unroll
     for (int ti = 0; ti < NTI; ++ti) {
-        const f32x4 fv = fbv[4 * (2 * B + ti)];                            // S * features[16t + 4g + r]
-        const f32x4 bias = ldsv[(OFF_B1 >> 2) + 4 * (2 * B + ti) + g];     // b1[16t + 4g + r]
+        const f32x4 fv = ldsv[lb.fb + 4 * (2 * B + ti)];                   // S 2^-k1 features[16t + 4g + r]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) h1[ti][nt] = relu4(fma4(acc1[ti][nt], c1, bias)) * fv;
+        for (int nt = 0; nt < NT; ++nt) h1[ti][nt] = relu4s(acc1[ti][nt]) * fv;
     }
-    f16x8 bh[NT], bl[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if constexpr (NTI == 2) split_tiles(h1[0][nt], h1[1][nt], bh[nt], bl[nt]);
         else split_tile_lower(h1[0][nt], bh[nt], bl[nt]);
     }
-    f16x8 ah[4], al[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int base = W2_U4 + ((mt * KB2 + B) * 2) * 64 + lane;
-        ah[mt] = __builtin_bit_cast(f16x8, lds4[base]);
-        al[mt] = __builtin_bit_cast(f16x8, lds4[base + 64]);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(al[mt], bh[nt], acc2[mt][nt]);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(ah[mt], bl[nt], acc2[mt][nt]);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mf(ah[mt], bh[nt], acc2[mt][nt]);
 }
 
-__global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
+// The split of one register pair in three schedulable pieces (see stage()).
+__device__ __forceinline__ f16x2 cvt_pair(float x, float y) {
+    const f32x2 v = {x, y};
+    return __builtin_convertvector(v, f16x2);
+}
+__device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &rx, float &ry) {   // x - hi, exact
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel_hi:[0,0,1]" : "=v"(rx) : "v"(x), "v"(hb));
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "v"(hb));
+}
+
+// One pipeline stage of the fused layers 1 + 2.  Stage B issues, as ONE hand-interleaved instruction stream,
+//   * the 24 layer-2 MFMAs of K block B            (inputs: bh / bl, the split activations of block B),
+//   * the layer-1 MFMAs of block B + 2             (into accW),
+//   * the VALU epilogue of block B + 1             (accR -> bhN / blN: ReLU, Hadamard, split),
+// which are mutually independent.  The epilogue is cut into sub-steps of ~3 VALU instructions and one sub-step follows
+// every second MFMA, pinned with sched_barrier(0): a wave's own VALU / LDS work has to sit BETWEEN its MFMAs -- the matrix
+// pipe hides ~2.5 other instructions per 16-cycle MFMA when they are interleaved at that grain and almost none of a VALU
+// burst that follows an MFMA burst (profiles/r02_mfma_valu_overlap_probe.txt; sched_group_barrier did not move hipcc's
+// clustered schedule for this kernel).
+template <int B>
+__device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
+                                      const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT],
+                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT]) {
+    constexpr int NTI_W = (B + 2 < KB2) ? ntiles_of(B + 2) : 0;      // layer-1 tiles written (block B + 2)
+    constexpr int NTI_R = (B + 1 < KB2) ? ntiles_of(B + 1) : 0;      // layer-1 tiles read by the epilogue (block B + 1)
+    constexpr int N_L2 = 3 * 4 * NT, PER_KB = 3 * NTI_W * NT, NM = N_L2 + 2 * PER_KB;
+    constexpr int N_UNIT = NTI_R * NT * 2, N_SUB = 3 * N_UNIT;
+
+    f16x8 a2h[4], a2l[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int c = W2_U4 + ((mt * KB2 + B) * 2) * 64;
+        a2h[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+        a2l[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+    }
+    f32x4 fv[2];
+#pragma unroll
+    for (int ti = 0; ti < NTI_R; ++ti) fv[ti] = ldsv[lb.fb + 4 * (2 * (B + 1) + ti)];          // S 2^-k1 features[16t + 4g + r]
+#pragma unroll
+    for (int ti = 0; ti < NTI_W; ++ti) {
+        const f32x4 bias = ldsv[lb.fl + 4 * (2 * (B + 2) + ti)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accW[ti][nt] = bias;
+    }
+    f16x8 a1h[2][2], a1l[2][2];
+    f16x2 hP[NT][4], lP[NT][4];
+    const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hP[nt][q] = zero2; lP[nt][q] = zero2; }
+    float x0 = 0.f, x1 = 0.f, r0 = 0.f, r1 = 0.f;
+    f16x2 hcur = zero2;
+    __builtin_amdgcn_sched_barrier(0);
+
+    int sub = 0;      // next epilogue sub-step (compile-time after unrolling)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        // ---- LDS reads of the layer-1 weights, issued ~12 MFMAs ahead of their first use
+        if (NTI_W > 0) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                if (m == N_L2 + kb * PER_KB - 12) {
+#pragma unroll
+                    for (int ti = 0; ti < NTI_W; ++ti) {
+                        const int c = W1_U4 + (((2 * (B + 2) + ti) * 2 + kb) * 2) * 64;
+                        a1h[kb][ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+                        a1l[kb][ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+                    }
+                }
+        }
+        // ---- the MFMA of this slot
+        if (m < N_L2) {
+            const int p = m / (4 * NT), mt = (m % (4 * NT)) / NT, nt = m % NT;
+            acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
+        } else if (NTI_W > 0) {
+            const int q = m - N_L2, kb = q / PER_KB, r = q % PER_KB, p = r / (NTI_W * NT), ti = (r % (NTI_W * NT)) / NT, nt = r % NT;
+            accW[ti][nt] = mf(p == 0 ? a1l[kb][ti] : a1h[kb][ti], p == 1 ? cbl[kb][nt] : cbh[kb][nt], accW[ti][nt]);
+        }
+        // ---- epilogue sub-steps due by now: sub-step s goes after MFMA (s + 1) NM / (N_SUB + 1)
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            if (sub < N_SUB && (sub + 1) * NM / (N_SUB + 1) <= m) {
+                const int u = sub / 3, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2;
+                if (sub % 3 == 0) {                    // ReLU + Hadamard: 2 v_max_i32, v_pk_mul_f32
+                    x0 = relu1(accR[ti][nt][2 * pr]) * fv[ti][2 * pr];
+                    x1 = relu1(accR[ti][nt][2 * pr + 1]) * fv[ti][2 * pr + 1];
+                } else if (sub % 3 == 1) {             // hi pair, residuals: v_cvt_pk_f16_f32, 2 v_fma_mix_f32
+                    hcur = cvt_pair(x0, x1);
+                    residual_pair(x0, x1, hcur, r0, r1);
+                    hP[nt][2 * ti + pr] = hcur;
+                } else {                               // lo pair: v_cvt_pk_f16_f32
+                    lP[nt][2 * ti + pr] = cvt_pair(r0, r1);
+                }
+                ++sub;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (N_UNIT > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bhN[nt] = cat4(hP[nt][0], hP[nt][1], hP[nt][2], hP[nt][3]);
+            blN[nt] = cat4(lP[nt][0], lP[nt][1], lP[nt][2], lP[nt][3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                                  const uint32_t *__restrict__ packed, float *__restrict__ qvals,
                                                                  const float *__restrict__ explore_u, float eps,
                                                                  int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state) {
@@ -330,15 +453,17 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
     const int wave = tid >> 6, waves_per_block = blockDim.x >> 6;
     const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
     const u32x4 *lds4 = reinterpret_cast<const u32x4 *>(lds);
+    LdsBase lb;
+    lb.w_lo = lane; lb.w_hi = lane + 4096; lb.fl = (OFF_B1 >> 2) + g; lb.fb = ((OFF_FB + wave * F) >> 2) + g;
+    int enc_w = (OFF_WS >> 2) + lane;       // sensor encoder weights (16-byte units)
+    int enc_f = OFF_BND + lane;             // bounds / encoder biases (floats)
+    int fb_f = OFF_FB + wave * F + lane;    // this wave's feature buffer (floats)
+    asm volatile("" : "+v"(lb.w_lo), "+v"(lb.w_hi), "+v"(lb.fl), "+v"(lb.fb), "+v"(enc_w), "+v"(enc_f), "+v"(fb_f));
     const float c1 = lds[OFF_CST + 0], c2 = lds[OFF_CST + 1], c3 = lds[OFF_CST + 2];
     const float a2 = lds[OFF_CST + 3], d2 = lds[OFF_CST + 4], a3 = lds[OFF_CST + 5], d3 = lds[OFF_CST + 6];
 
-    // cos(tau * pi * k), k = 32 kb + 8 g + i, as cos(2 pi * frac(tau * k / 2)) like the exact kernel
-    float hk[2][8];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) hk[kb][i] = 0.5f * (float)(32 * kb + 8 * g + i);
+    // cos(tau * pi * k), k = 32 kb + 8 g + i: v_cos_f32 takes its argument in revolutions (tau * k / 2 <= 32) and reduces it itself
+    const float hk0 = 4.0f * (float)g;     // k / 2 = hk0 + (16 kb + i / 2)
 
     for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
         float tau[NT];
@@ -353,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
                 f16x2 h[4], l[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    split2(__builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[kb][2 * p])),
-                           __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau[nt] * hk[kb][2 * p + 1])), h[p], l[p]);
+                    split2(__builtin_amdgcn_cosf(tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p)))),
+                           __builtin_amdgcn_cosf(tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p + 1)))), h[p], l[p]);
                 cbh[kb][nt] = cat4(h[0], h[1], h[2], h[3]);
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
@@ -374,22 +499,24 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
                 const int sf = lane + 64 * j;
                 fval[j] = 0.f;
                 if (sf < 176) {
-                    float a = lds[OFF_BE + 32 + sf];
+                    f32x2 a2 = {lds[enc_f + (OFF_BE - OFF_BND) + 32 + 64 * j], 0.f};
 #pragma unroll
-                    for (int i4 = 0; i4 < 6; ++i4) {
-                        const f32x4 wv = ldsv[(OFF_WS >> 2) + i4 * 176 + sf];
-                        a += wv[0] * ov[4 + 4 * i4] + wv[1] * ov[5 + 4 * i4] + wv[2] * ov[6 + 4 * i4] + wv[3] * ov[7 + 4 * i4];
+                    for (int i4 = 0; i4 < 6; ++i4) {       // two v_pk_fma_f32 per 4 inputs
+                        const f32x4 wv = ldsv[enc_w + i4 * 176 + 64 * j];
+                        a2 += (f32x2){wv[0], wv[1]} * (f32x2){ov[4 + 4 * i4], ov[5 + 4 * i4]};
+                        a2 += (f32x2){wv[2], wv[3]} * (f32x2){ov[6 + 4 * i4], ov[7 + 4 * i4]};
                     }
+                    const float a = a2[0] + a2[1];
                     fval[j] = a;
-                    bnd = fmaxf(bnd, fabsf(a) * lds[OFF_BND + 32 + sf]);
+                    bnd = fmaxf(bnd, fabsf(a) * lds[enc_f + 32 + 64 * j]);
                 }
             }
             fval[3] = 0.f;
             if (lane < 32) {
                 const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + OFF_WVG)[lane];
                 const float i0 = lane < 16 ? ov[0] : ov[2], i1 = lane < 16 ? ov[1] : ov[3];
-                fval[3] = lds[OFF_BE + lane] + wv[0] * i0 + wv[1] * i1;
-                bnd = fmaxf(bnd, fabsf(fval[3]) * lds[OFF_BND + lane]);
+                fval[3] = lds[enc_f + (OFF_BE - OFF_BND)] + wv[0] * i0 + wv[1] * i1;
+                bnd = fmaxf(bnd, fabsf(fval[3]) * lds[enc_f]);
             }
             const float m1 = wave_max_nonneg(bnd);
             float M = fmaxf(fmaxf(m1, fmaf(a2, m1, d2)), fmaf(a3, m1, d3));
@@ -397,17 +524,16 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
             const int eM = (int)(__builtin_bit_cast(uint32_t, M) >> 23);          // M in [2^(eM-127), 2^(eM-126))
             S = __builtin_bit_cast(float, (uint32_t)(268 - eM) << 23);           // 2^(141 - eM): S M < 2^15
             invS = __builtin_bit_cast(float, (uint32_t)(eM - 14) << 23);         // 2^(eM - 141)
-            float *fb = lds + OFF_FB + wave * F;
+            const float Sc = S * c1;                                              // layer-1 accumulators carry 2^k1
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int sf = lane + 64 * j;
-                if (sf < 176) fb[32 + sf] = fval[j] * S;
+                if (sf < 176) lds[fb_f + 32 + 64 * j] = fval[j] * Sc;
             }
-            if (lane < 32) fb[lane] = fval[3] * S;
+            if (lane < 32) lds[fb_f] = fval[3] * Sc;
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        const f32x4 *fbv = reinterpret_cast<const f32x4 *>(lds + OFF_FB + wave * F) + g;   // + 4*t per tile
 
         // ---- layers 1 + 2 fused over the 7 K blocks of layer 2, software-pipelined as in the exact kernel: the layer-1
         // MFMAs of block b + 1 are issued before the VALU epilogue of block b
@@ -416,15 +542,19 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Stage b = layer-2 MFMAs of block b + layer-1 MFMAs of block b + 2 + VALU epilogue of block b + 1, see stage()
         f32x4 accA[2][NT], accB[2][NT];
-        layer1_pair<0>(lds4, lane, cbh, cbl, accA);
-        layer1_pair<1>(lds4, lane, cbh, cbl, accB); layer2_block<0>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
-        layer1_pair<2>(lds4, lane, cbh, cbl, accA); layer2_block<1>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
-        layer1_pair<3>(lds4, lane, cbh, cbl, accB); layer2_block<2>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
-        layer1_pair<4>(lds4, lane, cbh, cbl, accA); layer2_block<3>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
-        layer1_pair<5>(lds4, lane, cbh, cbl, accB); layer2_block<4>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
-        layer1_pair<6>(lds4, lane, cbh, cbl, accA); layer2_block<5>(lds4, ldsv, fbv, lane, g, c1, accB, acc2);
-        layer2_block<6>(lds4, ldsv, fbv, lane, g, c1, accA, acc2);
+        f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
+        l1_mfma<0>(lds4, ldsv, lb, cbh, cbl, accA);
+        l1_mfma<1>(lds4, ldsv, lb, cbh, cbl, accB);
+        l1_epilogue<0>(ldsv, lb, accA, bhA, blA);
+        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<6>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accB, accA, bhB, blB);
 
         // ---- layer 2 epilogue (S h2 = relu(acc2 2^-k2 + S b2)), split, layer 3 ------------------------------------------
         f16x8 b3h[2][NT], b3l[2][NT];
@@ -432,10 +562,10 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
         for (int kb = 0; kb < 2; ++kb) {
             f32x4 sb[2];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) sb[ti] = ldsv[(OFF_B2 >> 2) + 4 * (2 * kb + ti) + g] * S;
+            for (int ti = 0; ti < 2; ++ti) sb[ti] = ldsv[lb.fl + ((OFF_B2 - OFF_B1) >> 2) + 4 * (2 * kb + ti)] * S;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                split_tiles(relu4(fma4(acc2[2 * kb][nt], c2, sb[0])), relu4(fma4(acc2[2 * kb + 1][nt], c2, sb[1])), b3h[kb][nt], b3l[kb][nt]);
+                split_tiles(relu4s(fma4(acc2[2 * kb][nt], c2, sb[0])), relu4s(fma4(acc2[2 * kb + 1][nt], c2, sb[1])), b3h[kb][nt], b3l[kb][nt]);
         }
         f32x4 acc3[4][NT];
 #pragma unroll
@@ -447,9 +577,9 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
             f16x8 ah[4], al[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int base = W3_U4 + ((mt * 2 + kb) * 2) * 64 + lane;
-                ah[mt] = __builtin_bit_cast(f16x8, lds4[base]);
-                al[mt] = __builtin_bit_cast(f16x8, lds4[base + 64]);
+                const int c = W3_U4 + ((mt * 2 + kb) * 2) * 64;
+                ah[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+                al[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
             }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -468,9 +598,9 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_split_kernel(const float *__
         float part = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 sb = ldsv[(OFF_B3 >> 2) + 4 * mt + g] * S;
-            const f32x4 h0 = relu4(fma4(acc3[mt][0], c3, sb)), h1 = relu4(fma4(acc3[mt][1], c3, sb));
-            const f32x4 a = ldsv[(OFF_W4 >> 2) + mt * 64 + lane];
+            const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * S;
+            const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3, sb)), h1 = relu4s(fma4(acc3[mt][1], c3, sb));
+            const f32x4 a = ldsv[lb.w_hi + ((OFF_W4 >> 2) - 4096) + mt * 64];
 #pragma unroll
             for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
         }

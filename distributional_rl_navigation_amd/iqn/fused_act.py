@@ -60,8 +60,11 @@ class ActContext:
     def invalidate(self):
         _capi.lib().mn_iqn_weights_changed(self.h)
 
+    DEFAULT_VARIANT = 2
+
     def set_variant(self, variant):
-        """0 = the 16x16x4 MFMA kernel (default), 1 = the 32x32x2 re-layout (A / B measurements, tests)."""
+        """2 = the split-f16 kernel (default: three f16 MFMA products per float32 product, float32-class accuracy, ~3x faster),
+        0 = the exact-f32 16x16x4 MFMA kernel, 1 = its 32x32x2 re-layout (A / B measurements, tests)."""
         rc = _capi.lib().mn_iqn_set_variant(self.h, int(variant))
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")

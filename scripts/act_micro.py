@@ -3,8 +3,9 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from distributional_rl_navigation_amd.iqn.model import ObsEncoder
-from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
 net = ObsEncoder(26, 9, seed=1, device="cuda:0")
+act_context(net).set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 for n in (2048, 4096, 8192, 16384, 65536, 131072):
     obs = torch.randn(n, 26, device="cuda:0"); taus = torch.rand(n, 32, device="cuda:0")
     for _ in range(5): fused_act(net, obs, 0.0, 1.0, taus=taus)
