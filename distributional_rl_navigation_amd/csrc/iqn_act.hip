@@ -32,6 +32,7 @@
 // so the live state is 32 accumulator + 32 cos registers per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 #include "marinenav_hip.h"
 

@@ -36,6 +36,10 @@
 //
 // act_eval's per-tau quantile output keeps using the exact kernel (iqn_qvals_kernel<true>).
 
+#ifndef SP_ABL
+#define SP_ABL 0      // measurement builds only (scripts/act_split_ablation.sh): 1 no operand split, 2 no weight LDS reads, 4 no ReLU / Hadamard, 8 no cos, 16 half the MFMAs
+#endif
+
 namespace sp {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void iqn_split_prep_kernel(IqnWeights w, const
 }
 
 __device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mf_lo(f16x8 a, f16x8 b, f32x4 c) { return (SP_ABL & 16) ? c : mf(a, b, c); }   // the lo.hi / hi.lo products
 
 // (x, y) -> hi pair, lo pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (x - hi, exact; written as asm because the SLP vectoriser
 // otherwise turns the pair into 2 x v_cvt_f32_f16 + v_pk_fma_f32), v_cvt_pk_f16_f32
@@ -255,6 +260,14 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 
 constexpr int NT = 2;   // one environment = 32 tau rows = 2 column tiles per wave iteration
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>) -- the pipeline slots below are unrolled by
+// construction (a 48- or 72-slot `#pragma unroll` body exceeds the unroller's size limit and falls back to a real loop with
+// dynamically indexed -- scratch -- register arrays)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // LDS addressing.  The image is 154 KB and a ds_read carries a 16-bit byte offset, so every read is written as
 // (opaque base register) + (compile-time constant < 64 KB): four bases cover the image.  Left to itself the compiler
 // materialises one address VGPR per read outside the environment loop (~70 registers), which caps the occupancy.
@@ -265,6 +278,7 @@ struct LdsBase {
     int fb;       // this wave's feature buffer + g (16-byte units)
 };
 __device__ __forceinline__ u32x4 ld_w(const u32x4 *__restrict__ lds4, const LdsBase &lb, int c) {     // c: unit index without the lane
+    if (SP_ABL & 2) return (u32x4){(uint32_t)lb.w_lo, (uint32_t)lb.w_hi, (uint32_t)lb.fl, (uint32_t)lb.fb};
     return c < 4096 - 64 ? lds4[lb.w_lo + c] : lds4[lb.w_hi + (c - 4096)];
 }
 
@@ -328,11 +342,13 @@ __device__ __forceinline__ void l1_epilogue(const f32x4 *__restrict__ ldsv, cons
 
 // The split of one register pair in three schedulable pieces (see stage()).
 __device__ __forceinline__ f16x2 cvt_pair(float x, float y) {
+    if (SP_ABL & 1) return __builtin_bit_cast(f16x2, x);
     const f32x2 v = {x, y};
     return __builtin_convertvector(v, f16x2);
 }
 __device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &rx, float &ry) {   // x - hi, exact
     const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    if (SP_ABL & 1) { rx = y; ry = x; return; }
     asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel_hi:[0,0,1]" : "=v"(rx) : "v"(x), "v"(hb));
     asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "v"(hb));
 }
@@ -341,36 +357,40 @@ __device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &
 //   * the 24 layer-2 MFMAs of K block B            (inputs: bh / bl, the split activations of block B),
 //   * the layer-1 MFMAs of block B + 2             (into accW),
 //   * the VALU epilogue of block B + 1             (accR -> bhN / blN: ReLU, Hadamard, split),
-// which are mutually independent.  The epilogue is cut into sub-steps of ~3 VALU instructions and one sub-step follows
-// every second MFMA, pinned with sched_barrier(0): a wave's own VALU / LDS work has to sit BETWEEN its MFMAs -- the matrix
-// pipe hides ~2.5 other instructions per 16-cycle MFMA when they are interleaved at that grain and almost none of a VALU
-// burst that follows an MFMA burst (profiles/r02_mfma_valu_overlap_probe.txt; sched_group_barrier did not move hipcc's
-// clustered schedule for this kernel).
-template <int B>
+// which are mutually independent.  The epilogue is cut
+// into sub-steps of ~3 VALU instructions and one sub-step follows every second MFMA, pinned with sched_barrier(0): a wave's
+// own VALU / LDS work has to sit BETWEEN its MFMAs -- the matrix pipe hides ~2.5 other instructions per 16-cycle MFMA when
+// they are interleaved at that grain and almost none of a VALU burst that follows an MFMA burst
+// (profiles/r02_mfma_valu_overlap_probe.txt; sched_group_barrier did not move hipcc's clustered schedule for this kernel).
+// Stages -2 and -1 fill the pipeline (no layer-2 work yet).
+template <int B, class Extra>
 __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
                                       const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT],
-                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT]) {
-    constexpr int NTI_W = (B + 2 < KB2) ? ntiles_of(B + 2) : 0;      // layer-1 tiles written (block B + 2)
-    constexpr int NTI_R = (B + 1 < KB2) ? ntiles_of(B + 1) : 0;      // layer-1 tiles read by the epilogue (block B + 1)
-    constexpr int N_L2 = 3 * 4 * NT, PER_KB = 3 * NTI_W * NT, NM = N_L2 + 2 * PER_KB;
+                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT],
+                                      Extra &&extra) {
+    constexpr int NTI_W = (B + 2 < KB2) ? ntiles_of(B + 2) : 0;                  // layer-1 tiles written (block B + 2)
+    constexpr int NTI_R = (B + 1 >= 0 && B + 1 < KB2) ? ntiles_of(B + 1) : 0;    // layer-1 tiles read by the epilogue (block B + 1)
+    constexpr bool HAS_L2 = B >= 0;
+    constexpr int N_L2 = HAS_L2 ? 3 * 4 * NT : 0, PER_KB = 3 * NTI_W * NT, NM = N_L2 + 2 * PER_KB;
     constexpr int N_UNIT = NTI_R * NT * 2, N_SUB = 3 * N_UNIT;
 
+    // Operands are loaded by the stage itself (layer-2 weights, features, bias up front; layer-1 weights 12 slots ahead of
+    // their use).  Having the predecessor stage prefetch them (measured) changes nothing: the LDS latency is already covered
+    // by the partner wave, and the extra live registers (+40) are better spent elsewhere.
     f16x8 a2h[4], a2l[4];
+    if (HAS_L2) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int c = W2_U4 + ((mt * KB2 + B) * 2) * 64;
-        a2h[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
-        a2l[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+        for (int mt = 0; mt < 4; ++mt) {
+            const int c = W2_U4 + ((mt * KB2 + (HAS_L2 ? B : 0)) * 2) * 64;
+            a2h[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+            a2l[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+        }
     }
-    f32x4 fv[2];
+    f32x4 fv[2], bias[2];
 #pragma unroll
     for (int ti = 0; ti < NTI_R; ++ti) fv[ti] = ldsv[lb.fb + 4 * (2 * (B + 1) + ti)];          // S 2^-k1 features[16t + 4g + r]
 #pragma unroll
-    for (int ti = 0; ti < NTI_W; ++ti) {
-        const f32x4 bias = ldsv[lb.fl + 4 * (2 * (B + 2) + ti)];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accW[ti][nt] = bias;
-    }
+    for (int ti = 0; ti < NTI_W; ++ti) bias[ti] = ldsv[lb.fl + 4 * (2 * (B + 2) + ti)];        // 2^k1 b1: the accumulators' initial value
     f16x8 a1h[2][2], a1l[2][2];
     f16x2 hP[NT][4], lP[NT][4];
     const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
@@ -382,14 +402,13 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
     f16x2 hcur = zero2;
     __builtin_amdgcn_sched_barrier(0);
 
-    int sub = 0;      // next epilogue sub-step (compile-time after unrolling)
-#pragma unroll
-    for (int m = 0; m < NM; ++m) {
+    static_for<NM>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
         // ---- LDS reads of the layer-1 weights, issued ~12 MFMAs ahead of their first use
         if (NTI_W > 0) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
-                if (m == N_L2 + kb * PER_KB - 12) {
+                if (m == (N_L2 + kb * PER_KB - 12 > 0 ? N_L2 + kb * PER_KB - 12 : 0)) {
 #pragma unroll
                     for (int ti = 0; ti < NTI_W; ++ti) {
                         const int c = W1_U4 + (((2 * (B + 2) + ti) * 2 + kb) * 2) * 64;
@@ -401,19 +420,24 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
         // ---- the MFMA of this slot
         if (m < N_L2) {
             const int p = m / (4 * NT), mt = (m % (4 * NT)) / NT, nt = m % NT;
-            acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
+            if (!((SP_ABL & 16) && p < 2)) acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
         } else if (NTI_W > 0) {
             const int q = m - N_L2, kb = q / PER_KB, r = q % PER_KB, p = r / (NTI_W * NT), ti = (r % (NTI_W * NT)) / NT, nt = r % NT;
-            accW[ti][nt] = mf(p == 0 ? a1l[kb][ti] : a1h[kb][ti], p == 1 ? cbl[kb][nt] : cbh[kb][nt], accW[ti][nt]);
+            if (!((SP_ABL & 16) && p < 2))
+                accW[ti][nt] = mf(p == 0 ? a1l[kb][ti] : a1h[kb][ti], p == 1 ? cbl[kb][nt] : cbh[kb][nt],
+                                  (kb == 0 && p == ((SP_ABL & 16) ? 2 : 0)) ? bias[ti] : accW[ti][nt]);
         }
-        // ---- epilogue sub-steps due by now: sub-step s goes after MFMA (s + 1) NM / (N_SUB + 1)
+        // ---- epilogue sub-steps of this slot: sub-step s goes after MFMA (s + 1) NM / (N_SUB + 1)
 #pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            if (sub < N_SUB && (sub + 1) * NM / (N_SUB + 1) <= m) {
+        for (int sub = 0; sub < N_SUB; ++sub) {
+            if ((sub + 1) * NM / (N_SUB + 1) == m) {
                 const int u = sub / 3, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2;
                 if (sub % 3 == 0) {                    // ReLU + Hadamard: 2 v_max_i32, v_pk_mul_f32
-                    x0 = relu1(accR[ti][nt][2 * pr]) * fv[ti][2 * pr];
-                    x1 = relu1(accR[ti][nt][2 * pr + 1]) * fv[ti][2 * pr + 1];
+                    if (SP_ABL & 4) { x0 = accR[ti][nt][2 * pr]; x1 = accR[ti][nt][2 * pr + 1]; }
+                    else {
+                        x0 = relu1(accR[ti][nt][2 * pr]) * fv[ti][2 * pr];
+                        x1 = relu1(accR[ti][nt][2 * pr + 1]) * fv[ti][2 * pr + 1];
+                    }
                 } else if (sub % 3 == 1) {             // hi pair, residuals: v_cvt_pk_f16_f32, 2 v_fma_mix_f32
                     hcur = cvt_pair(x0, x1);
                     residual_pair(x0, x1, hcur, r0, r1);
@@ -421,11 +445,11 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
                 } else {                               // lo pair: v_cvt_pk_f16_f32
                     lP[nt][2 * ti + pr] = cvt_pair(r0, r1);
                 }
-                ++sub;
             }
         }
+        extra(M_);                                     // optional extra work scheduled into this slot (unused: see the kernel)
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     if (N_UNIT > 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -433,6 +457,140 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
             blN[nt] = cat4(lP[nt][0], lP[nt][1], lP[nt][2], lP[nt][3]);
         }
     }
+}
+
+// ---- observation encoders (model.py:170-173) in schedulable pieces.  Lane l computes sensor features l, l + 64, l + 128 (22
+// inputs each) and velocity / goal feature l (2 inputs; lanes < 32), then its share of the activation bound.  25 sub-steps of
+// 1 LDS read + 2-4 VALU (schedulable through stage()'s `extra` hook; the shipped kernel runs them back to back).
+struct EncState {
+    float fval[4];
+    float bnd;
+    f32x2 a2;
+};
+template <int IDX>
+__device__ __forceinline__ void enc_substep(const float *__restrict__ lds, const f32x4 *__restrict__ ldsv, int enc_w, int enc_f, int lane,
+                                            const float (&ov)[28], EncState &st) {
+    if constexpr (IDX < 24) {
+        constexpr int j = IDX / 8, k = IDX % 8;
+        if constexpr (k == 0) {
+            if (j == 0) st.bnd = 0.f;
+            st.a2 = (f32x2){lds[enc_f + (OFF_BE - OFF_BND) + 32 + 64 * j], 0.f};
+        } else if constexpr (k < 7) {                  // two v_pk_fma_f32 per 4 inputs
+            constexpr int i4 = k - 1;
+            const f32x4 wv = ldsv[enc_w + i4 * 176 + 64 * j];
+            st.a2 += (f32x2){wv[0], wv[1]} * (f32x2){ov[4 + 4 * i4], ov[5 + 4 * i4]};
+            st.a2 += (f32x2){wv[2], wv[3]} * (f32x2){ov[6 + 4 * i4], ov[7 + 4 * i4]};
+        } else {
+            const bool valid = lane + 64 * j < 176;    // lanes past the 176 sensor features computed on in-range garbage
+            const float a = valid ? st.a2[0] + st.a2[1] : 0.f;
+            st.fval[j] = a;
+            st.bnd = fmaxf(st.bnd, fabsf(a) * (valid ? lds[enc_f + 32 + 64 * j] : 0.f));
+        }
+    } else {
+        const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + OFF_WVG)[lane & 31];
+        const float i0 = lane < 16 ? ov[0] : ov[2], i1 = lane < 16 ? ov[1] : ov[3];
+        const float a = lane < 32 ? lds[enc_f + (OFF_BE - OFF_BND)] + wv[0] * i0 + wv[1] * i1 : 0.f;
+        st.fval[3] = a;
+        st.bnd = fmaxf(st.bnd, fabsf(a) * lds[enc_f]);
+    }
+}
+constexpr int N_ENC_SUB = 25;
+
+// the per-environment scale from the lanes' bounds (see the header): S, 1 / S
+__device__ __forceinline__ void env_scale(float bnd, float a2, float d2, float a3, float d3, float &S, float &invS) {
+    const float m1 = wave_max_nonneg(bnd);
+    float M = fmaxf(fmaxf(m1, fmaf(a2, m1, d2)), fmaf(a3, m1, d3));
+    M = fminf(fmaxf(M, 1e-30f), 1e30f);
+    const int eM = (int)(__builtin_bit_cast(uint32_t, M) >> 23);          // M in [2^(eM-127), 2^(eM-126))
+    S = __builtin_bit_cast(float, (uint32_t)(268 - eM) << 23);           // 2^(141 - eM): S M < 2^15
+    invS = __builtin_bit_cast(float, (uint32_t)(eM - 14) << 23);         // 2^(eM - 141)
+}
+// S 2^-k1 feature -> this wave's LDS buffer (the Hadamard multiplier of the layer-1 epilogue)
+__device__ __forceinline__ void store_features(float *__restrict__ lds, int fb_f, int lane, const EncState &st, float Sc) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (lane + 64 * j < 176) lds[fb_f + 32 + 64 * j] = st.fval[j] * Sc;
+    if (lane < 32) lds[fb_f] = st.fval[3] * Sc;
+}
+
+// The end of an environment's pipeline as one hand-interleaved stream of 72 MFMAs:
+//   slots  0..11  layer-2 MFMAs of the last K block for output tiles 0, 1
+//   slots 12..23  the same for tiles 2, 3            || layer-2 epilogue of tiles 0, 1 (unscale + bias, ReLU, split)
+//   slots 24..47  layer-3 MFMAs of K block 0         || layer-2 epilogue of tiles 2, 3
+//   slots 48..71  layer-3 MFMAs of K block 1 (output tiles 0, 1 first)
+// S h2 = relu(acc2 2^-k2 + S b2); the layer-3 accumulators are left in acc3.
+__device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float S,
+                                     const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f32x4 (&acc3)[4][NT]) {
+    f16x8 a2h[4], a2l[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int c = W2_U4 + ((mt * KB2 + (KB2 - 1)) * 2) * 64;
+        a2h[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+        a2l[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+    }
+    f32x4 sb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sb[t] = ldsv[lb.fl + ((OFF_B2 - OFF_B1) >> 2) + 4 * t] * S;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 a3h[2][4], a3l[2][4];
+    f16x2 hP[2][NT][4], lP[2][NT][4];
+    f16x8 b3h[2][NT], b3l[2][NT];
+    float t0 = 0.f, t1 = 0.f, r0 = 0.f, r1 = 0.f;
+    f16x2 hcur = {(_Float16)0.f, (_Float16)0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<72>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+            if (m == 12 + 24 * kb) {            // layer-3 weights, 12 slots ahead
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int c = W3_U4 + ((mt * 2 + kb) * 2) * 64;
+                    a3h[kb][mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+                    a3l[kb][mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+                }
+            }
+        if (m < 24) {                           // layer 2, last K block: tiles {0, 1} then {2, 3}
+            const int half = m / 12, q = m % 12, p = q / 4, mt = 2 * half + (q % 4) / 2, nt = q % 2;
+            if (!((SP_ABL & 16) && p < 2)) acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
+        } else if (m < 48) {                    // layer 3, K block 0
+            const int q = m - 24, p = q / 8, mt = (q % 8) / 2, nt = q % 2;
+            if (!((SP_ABL & 16) && p < 2)) acc3[mt][nt] = mf(p == 0 ? a3l[0][mt] : a3h[0][mt], p == 1 ? b3l[0][nt] : b3h[0][nt], acc3[mt][nt]);
+        } else {                                // layer 3, K block 1: tiles {0, 1} then {2, 3}
+            const int q = m - 48, half = q / 12, r = q % 12, p = r / 4, mt = 2 * half + (r % 4) / 2, nt = r % 2;
+            if (!((SP_ABL & 16) && p < 2)) acc3[mt][nt] = mf(p == 0 ? a3l[1][mt] : a3h[1][mt], p == 1 ? b3l[1][nt] : b3h[1][nt], acc3[mt][nt]);
+        }
+        // epilogue sub-steps (48 = 2 halves x 8 register pairs x 3): half 0 two per slot in slots 12..23, half 1 one per slot in 24..47
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int sub = (m >= 12 && m < 24) ? 2 * (m - 12) + rep : ((m >= 24 && m < 48 && rep == 0) ? m : -1);
+            if (sub >= 0) {
+                const int half = sub / 24, u = (sub % 24) / 3, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2, t = 2 * half + ti;
+                if (sub % 3 == 0) {
+                    t0 = relu1(fmaf(acc2[t][nt][2 * pr], c2, sb[t][2 * pr]));
+                    t1 = relu1(fmaf(acc2[t][nt][2 * pr + 1], c2, sb[t][2 * pr + 1]));
+                } else if (sub % 3 == 1) {
+                    hcur = cvt_pair(t0, t1);
+                    residual_pair(t0, t1, hcur, r0, r1);
+                    hP[half][nt][2 * ti + pr] = hcur;
+                } else {
+                    lP[half][nt][2 * ti + pr] = cvt_pair(r0, r1);
+                }
+                if (sub == 23 || sub == 47) {
+                    const int hdone = sub / 24;
+#pragma unroll
+                    for (int n2 = 0; n2 < NT; ++n2) {
+                        b3h[hdone][n2] = cat4(hP[hdone][n2][0], hP[hdone][n2][1], hP[hdone][n2][2], hP[hdone][n2][3]);
+                        b3l[hdone][n2] = cat4(lP[hdone][n2][0], lP[hdone][n2][1], lP[hdone][n2][2], lP[hdone][n2][3]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
@@ -465,6 +623,12 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     // cos(tau * pi * k), k = 32 kb + 8 g + i: v_cos_f32 takes its argument in revolutions (tau * k / 2 <= 32) and reduces it itself
     const float hk0 = 4.0f * (float)g;     // k / 2 = hk0 + (16 kb + i / 2)
 
+    // Software-pipelining the loop ACROSS environments (next environment's taus / observation row loaded and its encoders run in
+    // the pipeline's issue gaps through the `extra` hook of stage()) was built and measured: 359 us against 326 us -- the kernel is
+    // bound by the SIMD's aggregate instruction issue (~1 instruction per 5 cycles over both waves, the same rate as
+    // profiles/r02_mfma_valu_overlap_probe.txt at K = 3), so moving instructions around buys nothing and the extra live
+    // registers cost spills.
+    auto no_extra = [](auto) {};
     for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
         float tau[NT];
 #pragma unroll
@@ -478,59 +642,24 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
                 f16x2 h[4], l[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
+                    if (SP_ABL & 8) { h[p] = __builtin_bit_cast(f16x2, tau[nt]); l[p] = h[p]; }
+                    else
                     split2(__builtin_amdgcn_cosf(tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p)))),
                            __builtin_amdgcn_cosf(tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p + 1)))), h[p], l[p]);
                 cbh[kb][nt] = cat4(h[0], h[1], h[2], h[3]);
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
-
-        // ---- observation encoders (model.py:170-173).  Lane l computes sensor features l, l + 64, l + 128 (22 inputs each)
-        // and, for l < 32, velocity / goal feature l (2 inputs); then the per-environment activation bound and scale S,
-        // and S * feature goes to this wave's LDS buffer for the Hadamard product
+        // observation encoders, per-environment scale S, S 2^-k1 features -> this wave's LDS buffer
         float S, invS;
         {
             const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
             float ov[28];
 #pragma unroll
             for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
-            float fval[4], bnd = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int sf = lane + 64 * j;
-                fval[j] = 0.f;
-                if (sf < 176) {
-                    f32x2 a2 = {lds[enc_f + (OFF_BE - OFF_BND) + 32 + 64 * j], 0.f};
-#pragma unroll
-                    for (int i4 = 0; i4 < 6; ++i4) {       // two v_pk_fma_f32 per 4 inputs
-                        const f32x4 wv = ldsv[enc_w + i4 * 176 + 64 * j];
-                        a2 += (f32x2){wv[0], wv[1]} * (f32x2){ov[4 + 4 * i4], ov[5 + 4 * i4]};
-                        a2 += (f32x2){wv[2], wv[3]} * (f32x2){ov[6 + 4 * i4], ov[7 + 4 * i4]};
-                    }
-                    const float a = a2[0] + a2[1];
-                    fval[j] = a;
-                    bnd = fmaxf(bnd, fabsf(a) * lds[enc_f + 32 + 64 * j]);
-                }
-            }
-            fval[3] = 0.f;
-            if (lane < 32) {
-                const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + OFF_WVG)[lane];
-                const float i0 = lane < 16 ? ov[0] : ov[2], i1 = lane < 16 ? ov[1] : ov[3];
-                fval[3] = lds[enc_f + (OFF_BE - OFF_BND)] + wv[0] * i0 + wv[1] * i1;
-                bnd = fmaxf(bnd, fabsf(fval[3]) * lds[enc_f]);
-            }
-            const float m1 = wave_max_nonneg(bnd);
-            float M = fmaxf(fmaxf(m1, fmaf(a2, m1, d2)), fmaf(a3, m1, d3));
-            M = fminf(fmaxf(M, 1e-30f), 1e30f);
-            const int eM = (int)(__builtin_bit_cast(uint32_t, M) >> 23);          // M in [2^(eM-127), 2^(eM-126))
-            S = __builtin_bit_cast(float, (uint32_t)(268 - eM) << 23);           // 2^(141 - eM): S M < 2^15
-            invS = __builtin_bit_cast(float, (uint32_t)(eM - 14) << 23);         // 2^(eM - 141)
-            const float Sc = S * c1;                                              // layer-1 accumulators carry 2^k1
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int sf = lane + 64 * j;
-                if (sf < 176) lds[fb_f + 32 + 64 * j] = fval[j] * Sc;
-            }
-            if (lane < 32) lds[fb_f] = fval[3] * Sc;
+            EncState st;
+            static_for<N_ENC_SUB>([&](auto I_) { enc_substep<decltype(I_)::value>(lds, ldsv, enc_w, enc_f, lane, ov, st); });
+            env_scale(st.bnd, a2, d2, a3, d3, S, invS);
+            store_features(lds, fb_f, lane, st, S * c1);
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -545,55 +674,16 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         // Stage b = layer-2 MFMAs of block b + layer-1 MFMAs of block b + 2 + VALU epilogue of block b + 1, see stage()
         f32x4 accA[2][NT], accB[2][NT];
         f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
-        l1_mfma<0>(lds4, ldsv, lb, cbh, cbl, accA);
-        l1_mfma<1>(lds4, ldsv, lb, cbh, cbl, accB);
-        l1_epilogue<0>(ldsv, lb, accA, bhA, blA);
-        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
-        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
-        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
-        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
-        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
-        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
-        stage<6>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accB, accA, bhB, blB);
-
-        // ---- layer 2 epilogue (S h2 = relu(acc2 2^-k2 + S b2)), split, layer 3 ------------------------------------------
-        f16x8 b3h[2][NT], b3l[2][NT];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x4 sb[2];
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti) sb[ti] = ldsv[lb.fl + ((OFF_B2 - OFF_B1) >> 2) + 4 * (2 * kb + ti)] * S;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                split_tiles(relu4s(fma4(acc2[2 * kb][nt], c2, sb[0])), relu4s(fma4(acc2[2 * kb + 1][nt], c2, sb[1])), b3h[kb][nt], b3l[kb][nt]);
-        }
+        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB, no_extra);      // layer-1 block 0
+        stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);      // layer-1 block 1, epilogue of block 0
+        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
+        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
+        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
+        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
+        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
+        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
         f32x4 acc3[4][NT];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f16x8 ah[4], al[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int c = W3_U4 + ((mt * 2 + kb) * 2) * 64;
-                ah[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
-                al[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(al[mt], b3h[kb][nt], acc3[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(ah[mt], b3l[kb][nt], acc3[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc3[mt][nt] = mf(ah[mt], b3h[kb][nt], acc3[mt][nt]);
-        }
+        tail(lds4, ldsv, lb, c2, S, bhA, blA, acc2, acc3);
         // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
         float part = 0.f;
 #pragma unroll

@@ -19,6 +19,40 @@ __device__ __forceinline__ void body(f32x4 (&acc)[8], f16x8 a, f16x8 b, float (&
 }
 
 // MODE 0: every wave runs MFMA + K fillers; MODE 1: waves 0-3 MFMA only, waves 4-7 (if present) K*8 VALU only per iteration
+// (d) dependent-accumulator distance: the 8 MFMAs of an iteration cycle over NACC accumulators
+template <int K, int NACC>
+__global__ __launch_bounds__(512) void kern_dist(float *out, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 1e-3f); b[i] = (_Float16)1.0f; }
+    f32x4 acc[8];
+    float v[8];
+    for (int j = 0; j < 8; ++j) { acc[j] = (f32x4){0, 0, 0, 0}; v[j] = threadIdx.x * 0.001f + j; }
+    const float m = 0.999f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j % NACC], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(j + k) & 7]) : "v"(m));
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + v[j];
+    if (s == 12345.f) out[0] = s;
+}
+template <int K, int NACC>
+static float run_dist(int iters, float *dout) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipEventRecord(e0);
+        kern_dist<K, NACC><<<256, 512>>>(dout, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    return ms;
+}
+
 template <int K, int MODE>
 __global__ __launch_bounds__(512) void kern(float *out, int iters, int valu_only_first) {
     f16x8 a, b;
@@ -74,5 +108,9 @@ int main() {
     printf("   VALU-only wave alone, K=2: %.3f  K=3: %.3f  K=4: %.3f ms\n", run<2, 1>(256, iters, 2, dout), run<3, 1>(256, iters, 2, dout), run<4, 1>(256, iters, 2, dout));
     printf("   together (MFMA waves 0-3 older, VALU waves 4-7), K=2: %.3f  K=3: %.3f  K=4: %.3f ms\n", run<2, 1>(512, iters, 0, dout), run<3, 1>(512, iters, 0, dout), run<4, 1>(512, iters, 0, dout));
     printf("   together (VALU waves 0-3 older, MFMA waves 4-7), K=2: %.3f  K=3: %.3f  K=4: %.3f ms\n", run<2, 1>(512, iters, 1, dout), run<3, 1>(512, iters, 1, dout), run<4, 1>(512, iters, 1, dout));
+    printf("(d) TWO waves per SIMD, dependent-accumulator distance (ns per MFMA slot per SIMD):\n");
+    printf("   K=0: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<0, 8>(iters, dout) * per / 2, run_dist<0, 4>(iters, dout) * per / 2, run_dist<0, 2>(iters, dout) * per / 2, run_dist<0, 1>(iters, dout) * per / 2);
+    printf("   K=2: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<2, 8>(iters, dout) * per / 2, run_dist<2, 4>(iters, dout) * per / 2, run_dist<2, 2>(iters, dout) * per / 2, run_dist<2, 1>(iters, dout) * per / 2);
+    printf("   K=3: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<3, 8>(iters, dout) * per / 2, run_dist<3, 4>(iters, dout) * per / 2, run_dist<3, 2>(iters, dout) * per / 2, run_dist<3, 1>(iters, dout) * per / 2);
     return 0;
 }
