@@ -872,7 +872,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     const bool use32 = !quantiles_dev && c->variant == 1;
     if (use_sp) {
         const int pack_blocks = c->dirty_sp ? sp::PACK_BLOCKS : 0;
-        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(256), 0, s, w, c->consts_sp);
+        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
             int rng_blocks = (int)((groups + 255) / 256);

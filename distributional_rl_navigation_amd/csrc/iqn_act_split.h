@@ -13,7 +13,8 @@
 // (2057 vs 145.5 TFLOP/s sustained in the same probe).
 //
 // Range.  f16 tops out at 65504, so operands are scaled by powers of two (exact) before the split and the accumulators
-// are unscaled in the layer epilogues (one v_fma that replaces the bias add, so no extra instruction):
+// are unscaled in the layer epilogues (layers 2, 3: one v_pk_fma that also adds the bias; layer 1: its bias, pre-scaled, is
+// the accumulators' initial value and its 2^-k1 is folded into the Hadamard multiplier, so that epilogue is ReLU + multiply):
 //   * weights of layer l: 2^k_l with max |W_l| 2^k_l in [2^14, 2^15)                    (static, part of the weight image);
 //   * cos embedding: in [-1, 1], not scaled (an f16 pair keeps an absolute error of 2^-25 for ANY |x| <= 1, i.e. 2^-25 of
 //     the largest element, which is what a dot product's error is measured against);
@@ -26,6 +27,13 @@
 //     nothing as long as the largest activation stays above 2^-1 after scaling (17 binades of slack), see the probe's
 //     "scale 2^-10 lower" rows.
 // The observation encoders, the tau-mean and the 9 x 64 output layer stay f32 VALU work as in the exact kernel.
+//
+// Schedule.  With the matrix work cut 4.7 x the kernel is bound by instruction issue: a SIMD issues about one instruction per
+// 5 cycles in total over its two waves once VALU / LDS work is mixed with MFMAs (scripts/probes/mfma_valu_overlap.hip), and a
+// wave's other instructions only hide under its MFMAs when they sit BETWEEN them.  The layers are therefore written as
+// hand-interleaved pipeline stages (stage<B>, tail): every slot is one MFMA plus a few VALU / LDS instructions of an
+// independent piece of work, pinned with sched_barrier(0).  What remains is the instruction count itself (per environment:
+// 372 MFMA + ~960 VALU + ~195 LDS + ~170 scalar), ~0.15 us per instruction per 65 536-env launch.
 //
 // Layout.  Same transposed, register-chained scheme as the exact kernel: weights are the A operand (16 output features x
 // 32 k, lane (g, row) holds k slots 8 g + i), activations the B operand (32 k x 16 taus), C tile [16 features x 16 taus]
@@ -80,42 +88,46 @@ __device__ __forceinline__ float pow2_to_2p15(float amax) {
     return __builtin_bit_cast(float, (uint32_t)(268 - e) << 23);         // 2^(141 - e)
 }
 
-__device__ __forceinline__ float block_max_256(float v, float *red) {
+// consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3
+// (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 1024 threads: coalesced max-reductions
+// over the three weight matrices; the 64 row sums of W2 / W3 by 16 threads per row (a thread per row walking its row serially
+// took 28 us -- 208 dependent L2 round trips -- and this kernel runs after every optimizer step).
+__device__ __forceinline__ float block_max_1024(float v, float *red) {
     const int tid = threadIdx.x;
-    red[tid] = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-        __syncthreads();
-    }
-    const float r = red[0];
+    float r = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
     __syncthreads();
     return r;
 }
-
-// consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3
-// (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 256 threads.
-__global__ __launch_bounds__(256) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
-    __shared__ float red[256];
+__global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
+    __shared__ float red[16];
     const int tid = threadIdx.x;
     float m1 = 0.f, m2 = 0.f, m3 = 0.f;
-    for (int i = tid; i < F * N_COS; i += 256) m1 = fmaxf(m1, fabsf(w.W1[i]));
-    for (int i = tid; i < H * F; i += 256) m2 = fmaxf(m2, fabsf(w.W2[i]));
-    for (int i = tid; i < H * H; i += 256) m3 = fmaxf(m3, fabsf(w.W3[i]));
-    m1 = block_max_256(m1, red); m2 = block_max_256(m2, red); m3 = block_max_256(m3, red);
-    float r2 = 0.f, r3 = 0.f, be2 = 0.f, be3 = 0.f;
-    if (tid < H) {
-        for (int j = 0; j < F; ++j) r2 += fabsf(w.W2[tid * F + j]);
-        for (int j = 0; j < H; ++j) r3 += fabsf(w.W3[tid * H + j]);
-        be2 = fabsf(w.b2[tid]); be3 = fabsf(w.b3[tid]);
-    }
-    r2 = block_max_256(r2, red); r3 = block_max_256(r3, red); be2 = block_max_256(be2, red); be3 = block_max_256(be3, red);
+    for (int i = tid; i < F * N_COS; i += 1024) m1 = fmaxf(m1, fabsf(w.W1[i]));
+    for (int i = tid; i < H * F; i += 1024) m2 = fmaxf(m2, fabsf(w.W2[i]));
+    for (int i = tid; i < H * H; i += 1024) m3 = fmaxf(m3, fabsf(w.W3[i]));
+    // row sums: row = tid / 16, 16 threads per row
+    const int row = tid >> 4, k = tid & 15;
+    float r2 = 0.f, r3 = 0.f;
+    for (int j = k; j < F; j += 16) r2 += fabsf(w.W2[row * F + j]);
+    for (int j = k; j < H; j += 16) r3 += fabsf(w.W3[row * H + j]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { r2 += __shfl_xor(r2, off); r3 += __shfl_xor(r3, off); }
+    const float be2 = tid < H ? fabsf(w.b2[tid]) : 0.f, be3 = tid < H ? fabsf(w.b3[tid]) : 0.f;
+    m1 = block_max_1024(m1, red); m2 = block_max_1024(m2, red); m3 = block_max_1024(m3, red);
+    r2 = block_max_1024(r2, red); r3 = block_max_1024(r3, red);
+    const float b2m = block_max_1024(be2, red), b3m = block_max_1024(be3, red);
     if (tid == 0) {
         const float s1 = pow2_to_2p15(m1), s2 = pow2_to_2p15(m2), s3 = pow2_to_2p15(m3), infl = 1.0009765625f;
         consts[0] = s1; consts[1] = s2; consts[2] = s3;
         consts[3] = 1.0f / s1; consts[4] = 1.0f / s2; consts[5] = 1.0f / s3;      // exact: powers of two
-        consts[6] = r2 * infl; consts[7] = be2 * infl;
-        consts[8] = r3 * r2 * infl * infl; consts[9] = (r3 * be2 * infl + be3) * infl;
+        consts[6] = r2 * infl; consts[7] = b2m * infl;
+        consts[8] = r3 * r2 * infl * infl; consts[9] = (r3 * b2m * infl + b3m) * infl;
         for (int i = 10; i < N_CONST; ++i) consts[i] = 0.f;
     }
 }
