@@ -40,7 +40,7 @@ ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_m
 # 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
 # fused step + replay append kernel of the training loop, rollout = mn_rollout at 4 096 envs x 100 steps per launch
 # (profiles/r02_full_loop_kernel_stats.txt, profiles/r02_configs1_rollout.txt)
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 52.8e6, "act": 24.8e6, "rollout_4096x100": 61.8e6}
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 61.8e6}
 # mn_step_append also moves the transition into the replay ring: + 104 B (obs_t row read) + 2 x 104 + 8 + 4 + 4 B written
 APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
@@ -325,7 +325,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
                            (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n, args.cores, args.obstacles) == (65536, 8, 10) else None),
-                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch), profiles/r02_full_loop_kernel_stats.txt / r02_configs1_rollout.txt; not live",
+                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch), profiles/r02_full_loop_kernel_stats_split_act.txt / r02_configs1_rollout.txt; not live",
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "algorithmic_bytes_step_only": bytes_step,
                 "frac_step_bytes_only": (bytes_step * per_launch / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_kernel_ms > 0 else None,
@@ -348,8 +348,9 @@ def main():
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
                 "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak,
                 "unit": "TFLOP/s", "frac": tf / peak,
-                "traffic": PMC_TRAFFIC_BYTES["act"] if n == 65536 else None,
-                "traffic_source": "rocprofv3 PMC, profiles/r01_full_loop_kernel_stats.txt (HBM bytes per launch: observations + taus in, actions out -- the same for every kernel variant; not live)",
+                "traffic": PMC_TRAFFIC_BYTES["act_split" if args.act_variant == 2 else "act"] if n == 65536 else None,
+                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch: observations + taus in, actions out), "
+                                  + ("profiles/r02_full_loop_kernel_stats_split_act.txt" if args.act_variant == 2 else "profiles/r01_full_loop_kernel_stats.txt") + "; not live",
                 "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else ACT_FLOP_PER_ENV_STEP,
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
                 "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,
@@ -373,12 +374,37 @@ def main():
                     "value": v, "unit": "env steps/s", "cores": nth, "kind": "port",
                     "sample": f"{nth} host threads x {each} steps, one oracle env each, {dt:.1f} s",
                 }
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     env.close()
+    return result_line
+
+
+def _main_with_clean_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio when a process group is created
+    (it lands after the JSON line when stdout is a file), so everything the run itself writes to file descriptor 1 -- Python
+    or C level -- is sent to stderr, and the result line is written to the real stdout at the very end."""
+    import ctypes
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = main()
+    finally:
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    _main_with_clean_stdout()
