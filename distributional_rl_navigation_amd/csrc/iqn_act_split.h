@@ -208,7 +208,6 @@ __global__ __launch_bounds__(256) void iqn_split_prep_kernel(IqnWeights w, const
 }
 
 __device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mf_lo(f16x8 a, f16x8 b, f32x4 c) { return (SP_ABL & 16) ? c : mf(a, b, c); }   // the lo.hi / hi.lo products
 
 // (x, y) -> hi pair, lo pair: v_cvt_pk_f16_f32, 2 x v_fma_mix_f32 (x - hi, exact; written as asm because the SLP vectoriser
 // otherwise turns the pair into 2 x v_cvt_f32_f16 + v_pk_fma_f32), v_cvt_pk_f16_f32
@@ -225,20 +224,6 @@ __device__ __forceinline__ void split2(float x, float y, f16x2 &h, f16x2 &l) {
 __device__ __forceinline__ f16x8 cat4(f16x2 a, f16x2 b, f16x2 c, f16x2 d) {
     const f16x4 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
     return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-// two C tiles (registers of one lane) -> the hi / lo B operands of the K block they form
-__device__ __forceinline__ void split_tiles(f32x4 t0, f32x4 t1, f16x8 &bh, f16x8 &bl) {
-    f16x2 h0, h1, h2, h3, l0, l1, l2, l3;
-    split2(t0[0], t0[1], h0, l0); split2(t0[2], t0[3], h1, l1);
-    split2(t1[0], t1[1], h2, l2); split2(t1[2], t1[3], h3, l3);
-    bh = cat4(h0, h1, h2, h3); bl = cat4(l0, l1, l2, l3);
-}
-__device__ __forceinline__ void split_tile_lower(f32x4 t0, f16x8 &bh, f16x8 &bl) {     // upper half of the K block is padding
-    f16x2 h0, h1, l0, l1;
-    const f16x2 z = {(_Float16)0.f, (_Float16)0.f};
-    split2(t0[0], t0[1], h0, l0); split2(t0[2], t0[3], h1, l1);
-    bh = cat4(h0, h1, z, z); bl = cat4(l0, l1, z, z);
 }
 
 // max(x, 0) as ONE instruction.  Written as a float compare / select (or fmaxf, or med3), a ReLU whose input is a raw MFMA
@@ -295,62 +280,8 @@ __device__ __forceinline__ u32x4 ld_w(const u32x4 *__restrict__ lds4, const LdsB
 }
 
 // layer-1 MFMAs of layer-2 K block b (feature tiles 2b, 2b + 1; only 2b for the last block): 3 products x 2 cos K blocks
-// ---- the fused layer 1 + layer 2 pipeline, in three pieces per layer-2 K block B (feature tiles 2B, 2B + 1; the last block has one)
+// ---- the fused layer 1 + layer 2 pipeline; layer-2 K block B = feature tiles 2B, 2B + 1 (the last block has one)
 constexpr int ntiles_of(int B) { return (2 * B + 1 < T1) ? 2 : 1; }
-
-// layer-1 MFMAs: 3 products x 2 cos K blocks; the accumulators start from the (pre-scaled) bias 2^k1 b1[16t + 4g + r]
-template <int B>
-__device__ __forceinline__ void l1_mfma(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
-                                        const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], f32x4 (&acc)[2][NT]) {
-    constexpr int NTI = ntiles_of(B);
-#pragma unroll
-    for (int ti = 0; ti < NTI; ++ti) {
-        const f32x4 bias = ldsv[lb.fl + 4 * (2 * B + ti)];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = bias;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        f16x8 ah[NTI], al[NTI];
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti) {
-            const int c = W1_U4 + (((2 * B + ti) * 2 + kb) * 2) * 64;
-            ah[ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
-            al[ti] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
-        }
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(al[ti], cbh[kb][nt], acc[ti][nt]);
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(ah[ti], cbl[kb][nt], acc[ti][nt]);
-#pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[ti][nt] = mf(ah[ti], cbh[kb][nt], acc[ti][nt]);
-    }
-}
-
-// layer-1 epilogue (VALU only): ReLU, Hadamard with the scaled features, split into the layer-2 B operands of block B
-template <int B>
-__device__ __forceinline__ void l1_epilogue(const f32x4 *__restrict__ ldsv, const LdsBase &lb, const f32x4 (&acc1)[2][NT],
-                                            f16x8 (&bh)[NT], f16x8 (&bl)[NT]) {
-    constexpr int NTI = ntiles_of(B);
-    f32x4 h1[2][NT];
-#pragma unroll
-    for (int ti = 0; ti < NTI; ++ti) {
-        const f32x4 fv = ldsv[lb.fb + 4 * (2 * B + ti)];                   // S 2^-k1 features[16t + 4g + r]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) h1[ti][nt] = relu4s(acc1[ti][nt]) * fv;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if constexpr (NTI == 2) split_tiles(h1[0][nt], h1[1][nt], bh[nt], bl[nt]);
-        else split_tile_lower(h1[0][nt], bh[nt], bl[nt]);
-    }
-}
 
 // The split of one register pair in three schedulable pieces (see stage()).
 __device__ __forceinline__ f16x2 cvt_pair(float x, float y) {
@@ -375,11 +306,10 @@ __device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &
 // they are interleaved at that grain and almost none of a VALU burst that follows an MFMA burst
 // (profiles/r02_mfma_valu_overlap_probe.txt; sched_group_barrier did not move hipcc's clustered schedule for this kernel).
 // Stages -2 and -1 fill the pipeline (no layer-2 work yet).
-template <int B, class Extra>
+template <int B>
 __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
                                       const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT],
-                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT],
-                                      Extra &&extra) {
+                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT]) {
     constexpr int NTI_W = (B + 2 < KB2) ? ntiles_of(B + 2) : 0;                  // layer-1 tiles written (block B + 2)
     constexpr int NTI_R = (B + 1 >= 0 && B + 1 < KB2) ? ntiles_of(B + 1) : 0;    // layer-1 tiles read by the epilogue (block B + 1)
     constexpr bool HAS_L2 = B >= 0;
@@ -459,7 +389,6 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
                 }
             }
         }
-        extra(M_);                                     // optional extra work scheduled into this slot (unused: see the kernel)
         __builtin_amdgcn_sched_barrier(0);
     });
     if (N_UNIT > 0) {
@@ -473,7 +402,7 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
 
 // ---- observation encoders (model.py:170-173) in schedulable pieces.  Lane l computes sensor features l, l + 64, l + 128 (22
 // inputs each) and velocity / goal feature l (2 inputs; lanes < 32), then its share of the activation bound.  25 sub-steps of
-// 1 LDS read + 2-4 VALU (schedulable through stage()'s `extra` hook; the shipped kernel runs them back to back).
+// 1 LDS read + 2-4 VALU.
 struct EncState {
     float fval[4];
     float bnd;
@@ -636,11 +565,10 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     const float hk0 = 4.0f * (float)g;     // k / 2 = hk0 + (16 kb + i / 2)
 
     // Software-pipelining the loop ACROSS environments (next environment's taus / observation row loaded and its encoders run in
-    // the pipeline's issue gaps through the `extra` hook of stage()) was built and measured: 359 us against 326 us -- the kernel is
+    // the pipeline's issue gaps) was built and measured: 359 us against 326 us -- the kernel is
     // bound by the SIMD's aggregate instruction issue (~1 instruction per 5 cycles over both waves, the same rate as
     // profiles/r02_mfma_valu_overlap_probe.txt at K = 3), so moving instructions around buys nothing and the extra live
     // registers cost spills.
-    auto no_extra = [](auto) {};
     for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
         float tau[NT];
 #pragma unroll
@@ -686,14 +614,14 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         // Stage b = layer-2 MFMAs of block b + layer-1 MFMAs of block b + 2 + VALU epilogue of block b + 1, see stage()
         f32x4 accA[2][NT], accB[2][NT];
         f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
-        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB, no_extra);      // layer-1 block 0
-        stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);      // layer-1 block 1, epilogue of block 0
-        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
-        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
-        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
-        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
-        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, no_extra);
-        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, no_extra);
+        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB);      // layer-1 block 0
+        stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);      // layer-1 block 1, epilogue of block 0
+        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
         f32x4 acc3[4][NT];
         tail(lds4, ldsv, lb, c2, S, bhA, blA, acc2, acc3);
         // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
