@@ -91,39 +91,39 @@ __device__ __forceinline__ float pow2_to_2p15(float amax) {
 // consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3
 // (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 1024 threads: coalesced max-reductions
 // over the three weight matrices; the 64 row sums of W2 / W3 by 16 threads per row (a thread per row walking its row serially
-// took 28 us -- 208 dependent L2 round trips -- and this kernel runs after every optimizer step).
-__device__ __forceinline__ float block_max_1024(float v, float *red) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float r = red[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
-    __syncthreads();
-    return r;
-}
+// took 28 us -- 208 dependent L2 round trips -- and this kernel runs after every optimizer step); one combined reduction.
 __global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
-    __shared__ float red[16];
+    __shared__ float red[16][8];
     const int tid = threadIdx.x;
-    float m1 = 0.f, m2 = 0.f, m3 = 0.f;
-    for (int i = tid; i < F * N_COS; i += 1024) m1 = fmaxf(m1, fabsf(w.W1[i]));
-    for (int i = tid; i < H * F; i += 1024) m2 = fmaxf(m2, fabsf(w.W2[i]));
-    for (int i = tid; i < H * H; i += 1024) m3 = fmaxf(m3, fabsf(w.W3[i]));
-    // row sums: row = tid / 16, 16 threads per row
+    // v[0..2] = max |W1|, |W2|, |W3|;  v[3], v[4] = row sums of W2, W3 (row = tid / 16, 16 threads per row);  v[5], v[6] = |b2|, |b3|
+    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < F * N_COS; i += 1024) v[0] = fmaxf(v[0], fabsf(w.W1[i]));
+    for (int i = tid; i < H * F; i += 1024) v[1] = fmaxf(v[1], fabsf(w.W2[i]));
+    for (int i = tid; i < H * H; i += 1024) v[2] = fmaxf(v[2], fabsf(w.W3[i]));
     const int row = tid >> 4, k = tid & 15;
-    float r2 = 0.f, r3 = 0.f;
-    for (int j = k; j < F; j += 16) r2 += fabsf(w.W2[row * F + j]);
-    for (int j = k; j < H; j += 16) r3 += fabsf(w.W3[row * H + j]);
+    for (int j = k; j < F; j += 16) v[3] += fabsf(w.W2[row * F + j]);
+    for (int j = k; j < H; j += 16) v[4] += fabsf(w.W3[row * H + j]);
+    if (tid < H) { v[5] = fabsf(w.b2[tid]); v[6] = fabsf(w.b3[tid]); }
+    // the row sums first (within 16 lanes), then all seven maxima through the same shuffle rounds and ONE pass through LDS
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { r2 += __shfl_xor(r2, off); r3 += __shfl_xor(r3, off); }
-    const float be2 = tid < H ? fabsf(w.b2[tid]) : 0.f, be3 = tid < H ? fabsf(w.b3[tid]) : 0.f;
-    m1 = block_max_1024(m1, red); m2 = block_max_1024(m2, red); m3 = block_max_1024(m3, red);
-    r2 = block_max_1024(r2, red); r3 = block_max_1024(r3, red);
-    const float b2m = block_max_1024(be2, red), b3m = block_max_1024(be3, red);
+    for (int off = 8; off > 0; off >>= 1) { v[3] += __shfl_xor(v[3], off); v[4] += __shfl_xor(v[4], off); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) v[q] = fmaxf(v[q], __shfl_xor(v[q], off));
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[tid >> 6][q] = v[q];
+    __syncthreads();
     if (tid == 0) {
-        const float s1 = pow2_to_2p15(m1), s2 = pow2_to_2p15(m2), s3 = pow2_to_2p15(m3), infl = 1.0009765625f;
+        float r[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            r[q] = red[0][q];
+            for (int i = 1; i < 16; ++i) r[q] = fmaxf(r[q], red[i][q]);
+        }
+        const float s1 = pow2_to_2p15(r[0]), s2 = pow2_to_2p15(r[1]), s3 = pow2_to_2p15(r[2]), infl = 1.0009765625f;
+        const float r2 = r[3], r3 = r[4], b2m = r[5], b3m = r[6];
         consts[0] = s1; consts[1] = s2; consts[2] = s3;
         consts[3] = 1.0f / s1; consts[4] = 1.0f / s2; consts[5] = 1.0f / s3;      // exact: powers of two
         consts[6] = r2 * infl; consts[7] = b2m * infl;
