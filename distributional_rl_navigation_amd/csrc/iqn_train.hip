@@ -121,6 +121,76 @@ __device__ __forceinline__ f32x4 tile_gemm(const float *A, int lda, const float 
     return acc;
 }
 
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser (Steele, Lea, Flood 2014)
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+constexpr int MAX_BATCH = 1024;
+__device__ __forceinline__ uint64_t sample_base(const uint64_t *__restrict__ state) {
+    return mix64(state[0] + 0x9E3779B97F4A7C15ull * (state[1] + 1));
+}
+// tau draw e of the step (e in [0, 2 * batch * 8): target network's first, model.py:149): 24-bit uniform in [0, 1), like torch.rand
+__device__ __forceinline__ float sample_tau(uint64_t base, int e) {
+    const uint64_t x = mix64(base ^ (0xD1B54A32D192ED03ull * (uint64_t)(e + 1)));
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+// The batch's `batch` distinct ring rows into val[] (LDS), by ALL threads of the workgroup (any workgroup size: a slot's draws
+// depend only on the slot and its attempt number, and every round redraws all clashing slots at once).  Every slot draws
+// uniformly from [0, n); a slot whose value is also held by a lower slot redraws, until all are distinct.  A slot only ever
+// rejects values that end up owned by a lower slot, so slot k's value is uniform over what slots < k left: exactly sequential
+// sampling without replacement (replay_buffer.py:42-47, random.sample).
+template <int NTHREADS>
+__device__ __forceinline__ void sample_rows(int *val, int *flag, int64_t n, int batch, uint64_t base) {
+    constexpr int PER = MAX_BATCH / NTHREADS;
+    const int padded = (batch + 3) & ~3;
+    int attempt[PER];
+    for (int k = threadIdx.x, q = 0; k < padded; k += NTHREADS, ++q) {
+        attempt[q] = 0;
+        const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1));
+        val[k] = k < batch ? (int)__umul64hi(x, (uint64_t)n) : -1;
+        flag[k] = 0;
+    }
+    __syncthreads();
+    for (;;) {
+        // does a LOWER slot hold slot k's value?  Two work items per slot, each scanning half of [0, k) four candidates per LDS
+        // read; only the last, partial group needs index masks.  (One item per slot scanning all of [0, k) with masks on every
+        // candidate was 2 us per pass -- VALU-bound -- in every one of the 128 workgroups.)
+        for (int w = threadIdx.x; w < 2 * batch; w += NTHREADS) {
+            const int k = w >> 1, part = w & 1, v = val[k];
+            const int jmax = k & ~3, mid = (jmax >> 1) & ~3;
+            const int lo = part ? mid : 0, hi = part ? jmax : mid;
+            bool c = false;
+            for (int j = lo; j < hi; j += 4) {
+                const int4 q4 = *reinterpret_cast<const int4 *>(&val[j]);
+                c |= (q4.x == v) | (q4.y == v) | (q4.z == v) | (q4.w == v);
+            }
+            if (part) {
+                const int4 q4 = *reinterpret_cast<const int4 *>(&val[jmax]);
+                c |= ((q4.x == v) & (jmax < k)) | ((q4.y == v) & (jmax + 1 < k)) | ((q4.z == v) & (jmax + 2 < k));
+            }
+            if (c) flag[k] = 1;
+        }
+        __syncthreads();
+        int clash = 0;
+        bool redo[PER];
+        for (int k = threadIdx.x, q = 0; k < batch; k += NTHREADS, ++q) {
+            redo[q] = flag[k] != 0;
+            clash |= redo[q];
+        }
+        if (!__syncthreads_or(clash)) break;
+        for (int k = threadIdx.x, q = 0; k < batch; k += NTHREADS, ++q) {
+            if (!redo[q]) continue;
+            ++attempt[q];
+            const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1) + 0x9FB21C651E98DF25ull * (uint64_t)attempt[q]);
+            val[k] = (int)__umul64hi(x, (uint64_t)n);
+            flag[k] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 // model.py:160-186 for the 16 rows of this workgroup, executed by ONE HALF of the workgroup (4 waves; the other half
 // runs the other network at the same time, so every __syncthreads() here is reached by all 512 threads):
 // `obs` [2][28], `tau` [16] in LDS, parameters `P` in HBM/L2.  Leaves cos, (h1,) x, h2, h3, features and q in LDS.
@@ -199,26 +269,45 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
                                                             const float *__restrict__ taus_t, const float *__restrict__ taus_l,
                                                             const float *__restrict__ PL, const float *__restrict__ PT,
                                                             float *__restrict__ partial, float *__restrict__ loss_partial,
-                                                            int batch, float gamma) {
+                                                            int batch, float gamma, const uint64_t *__restrict__ rng_state,
+                                                            int64_t ring_n, int64_t *__restrict__ idx_out, float *__restrict__ taus_out) {
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
+    __shared__ int64_t s_row[BE];
+    __shared__ __align__(16) int s_val[MAX_BATCH];
+    __shared__ int s_flag[MAX_BATCH];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * BE;
     float *out = partial + (size_t)blockIdx.x * P_TOTAL;
 
+    // The batch: either given (idx, taus_t, taus_l), or drawn here from the generator state -- EVERY workgroup runs the whole
+    // (cheap, deterministic) draw of the batch's rows and keeps its own two, which saves the separate sampling launch (8-11 us
+    // of a 57 us gradient step).  The state's call counter is advanced by iqn_grad_reduce, after all workgroups have read it.
+    if (rng_state) {
+        const uint64_t base = sample_base(rng_state);
+        sample_rows<THREADS>(s_val, s_flag, ring_n, batch, base);
+        if (tid < BE) s_row[tid] = s_val[b0 + tid];
+        if (tid < 2 * ROWS) S[S_TAU + tid] = sample_tau(base, (tid < ROWS ? 0 : batch * NQ) + b0 * NQ + (tid & (ROWS - 1)));
+        if (blockIdx.x == 0) {      // the caller's copies (inspection, tests)
+            if (idx_out) for (int k = tid; k < batch; k += THREADS) idx_out[k] = s_val[k];
+            if (taus_out) for (int e = tid; e < 2 * batch * NQ; e += THREADS) taus_out[e] = sample_tau(base, e);
+        }
+    } else {
+        if (tid < BE) s_row[tid] = idx[b0 + tid];
+        if (tid < 2 * ROWS) S[S_TAU + tid] = (tid < ROWS ? taus_t : taus_l)[b0 * NQ + (tid & (ROWS - 1))];
+    }
+    __syncthreads();
     // gather this workgroup's transitions from the replay ring (replay_buffer.py:42-57)
     for (int t = tid; t < 2 * BE * OBS; t += THREADS) {
         const int which = t / (BE * OBS), rem = t - which * (BE * OBS), be = rem / OBS, k = rem - be * OBS;
-        const int64_t row = idx[b0 + be];
-        S[S_OBS + which * (BE * 28) + be * 28 + k] = (which ? ring_ns : ring_s)[row * OBS + k];
+        S[S_OBS + which * (BE * 28) + be * 28 + k] = (which ? ring_ns : ring_s)[s_row[be] * OBS + k];
     }
     if (tid < BE) {
-        const int64_t row = idx[b0 + tid];
+        const int64_t row = s_row[tid];
         s_act[tid] = (int)ring_a[row];
         S[S_MISC + tid] = ring_r[row];
         S[S_MISC + BE + tid] = ring_d[row];
     }
-    if (tid < 2 * ROWS) S[S_TAU + tid] = (tid < ROWS ? taus_t : taus_l)[b0 * NQ + (tid & (ROWS - 1))];
     __syncthreads();
 
     // ---- waves 0-3: local network on states; waves 4-7: target network on next_states (agent.py:279-286).
@@ -370,8 +459,10 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
 // grad[p] = sum over workgroups of partial[wg][p]: four quarter sums (one per thread row, partials in index order,
 // 8 loads in flight) combined in a fixed order -> deterministic.  Block 0 also sums the loss.
 __global__ __launch_bounds__(1024) void iqn_grad_reduce(const float *__restrict__ partial, const float *__restrict__ loss_partial,
-                                                        int n_part, float *__restrict__ grad, float *__restrict__ loss_out) {
+                                                        int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
+                                                        uint64_t *__restrict__ rng_state) {
     __shared__ float red[4][256];
+    if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[1] += 1;   // the batch of this step was drawn by iqn_train_fwdbwd
     const int px = threadIdx.x & 255, seg = threadIdx.x >> 8;
     const int p = blockIdx.x * 256 + px;
     const int per = (n_part + 3) / 4, w0 = seg * per, w1 = min(n_part, w0 + per);
@@ -442,58 +533,17 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     }
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser (Steele, Lea, Flood 2014)
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 // ReplayBuffer.sample (replay_buffer.py:42-47: random.sample = uniform WITHOUT replacement) plus the 2 x batch x 8
-// tau draws of the step (model.py:149), one workgroup.  Every slot draws uniformly from [0, n); a slot whose value is
-// also held by a lower slot redraws, until all are distinct.  A slot only ever rejects values that end up owned by a
-// lower slot, so slot k's value is uniform over what slots < k left: exactly sequential sampling without
-// replacement.  Counter-based RNG: value = mix64(seed, call counter, slot, attempt); state = {seed, counter} on the
-// device, advanced by the kernel (so the launch arguments never change: hipGraph-capturable).
-constexpr int MAX_BATCH = 1024;
+// tau draws of the step (model.py:149), one workgroup (the stand-alone form of what iqn_train_fwdbwd does in its prologue when
+// it is given the generator state instead of index / tau buffers).  Counter-based RNG: value = mix64(seed, call counter, slot,
+// attempt); state = {seed, counter} on the device, advanced by the kernel (so the launch arguments never change).
 __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, uint64_t *__restrict__ state,
                                                          int64_t *__restrict__ idx, float *__restrict__ taus, int n_taus) {
     __shared__ __align__(16) int val[MAX_BATCH];
-    const uint64_t seed = state[0], ctr = state[1];
-    const uint64_t base = mix64(seed + 0x9E3779B97F4A7C15ull * (ctr + 1));
-    for (int e = threadIdx.x; e < n_taus; e += 256) {
-        const uint64_t x = mix64(base ^ (0xD1B54A32D192ED03ull * (uint64_t)(e + 1)));
-        taus[e] = (float)(x >> 40) * (1.0f / 16777216.0f);          // 24-bit uniform in [0, 1), like torch.rand
-    }
-    const int padded = (batch + 3) & ~3;
-    int attempt[MAX_BATCH / 256];
-    for (int k = threadIdx.x, q = 0; k < padded; k += 256, ++q) {
-        attempt[q] = 0;
-        const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1));
-        val[k] = k < batch ? (int)__umul64hi(x, (uint64_t)n) : -1;
-    }
-    __syncthreads();
-    for (;;) {
-        int clash = 0;
-        bool redo[MAX_BATCH / 256];
-        for (int k = threadIdx.x, q = 0; k < batch; k += 256, ++q) {
-            const int v = val[k];
-            bool c = false;
-            for (int j = 0; j < k; j += 4) {      // wave-uniform broadcast reads, four candidates each
-                const int4 w = *reinterpret_cast<const int4 *>(&val[j]);
-                c |= (w.x == v) | ((w.y == v) & (j + 1 < k)) | ((w.z == v) & (j + 2 < k)) | ((w.w == v) & (j + 3 < k));
-            }
-            redo[q] = c;
-            clash |= c;
-        }
-        if (!__syncthreads_or(clash)) break;
-        for (int k = threadIdx.x, q = 0; k < batch; k += 256, ++q) {
-            if (!redo[q]) continue;
-            ++attempt[q];
-            const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1) + 0x9FB21C651E98DF25ull * (uint64_t)attempt[q]);
-            val[k] = (int)__umul64hi(x, (uint64_t)n);
-        }
-        __syncthreads();
-    }
+    __shared__ int flag[MAX_BATCH];
+    const uint64_t ctr = state[1], base = sample_base(state);
+    for (int e = threadIdx.x; e < n_taus; e += 256) taus[e] = sample_tau(base, e);
+    sample_rows<256>(val, flag, n, batch, base);
     for (int k = threadIdx.x; k < batch; k += 256) idx[k] = val[k];
     if (threadIdx.x == 0) state[1] = ctr + 1;
 }
@@ -514,13 +564,15 @@ extern "C" int64_t mn_iqn_train_workspace_floats(int32_t batch) {
     return (int64_t)(batch / BE) * (P_TOTAL + 1) + N_SQ;
 }
 
-extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
-                                 const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev,
-                                 const float *taus_target_dev, const float *taus_local_dev, const float *params_local,
-                                 const float *params_target, float *workspace, float *grad_out, float *loss_out,
-                                 int32_t batch, int32_t num_taus, float gamma, void *stream) {
-    if (!ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones || !idx_dev || !taus_target_dev ||
-        !taus_local_dev || !params_local || !params_target || !workspace || !grad_out || !loss_out)
+static int launch_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                       const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev, const float *taus_target_dev,
+                       const float *taus_local_dev, const float *params_local, const float *params_target, float *workspace,
+                       float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma, uint64_t *rng_state_dev,
+                       int64_t ring_size, int64_t *idx_out, float *taus_out, void *stream) {
+    if (!ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones || !params_local || !params_target ||
+        !workspace || !grad_out || !loss_out)
+        return MN_ERR_INVALID;
+    if (rng_state_dev ? (batch > MAX_BATCH || ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
         return MN_ERR_INVALID;
     if (batch <= 0 || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
     {   // raise the dynamic-LDS limit once per device; guarded so that concurrent first calls from two threads are safe
@@ -541,10 +593,31 @@ extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_nex
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_part), dim3(THREADS), LDS_BYTES, s, ring_states, ring_next_states, ring_actions,
                        ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev, params_local, params_target, partial,
-                       loss_partial, batch, gamma);
+                       loss_partial, batch, gamma, (const uint64_t *)rng_state_dev, ring_size, idx_out, taus_out);
     hipLaunchKernelGGL(iqn_grad_reduce, dim3(N_SQ), dim3(1024), 0, s, partial, loss_partial, n_part, grad_out,
-                       loss_out);
+                       loss_out, rng_state_dev);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                                 const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev,
+                                 const float *taus_target_dev, const float *taus_local_dev, const float *params_local,
+                                 const float *params_target, float *workspace, float *grad_out, float *loss_out,
+                                 int32_t batch, int32_t num_taus, float gamma, void *stream) {
+    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev,
+                       params_local, params_target, workspace, grad_out, loss_out, batch, num_taus, gamma, nullptr, 0, nullptr, nullptr,
+                       stream);
+}
+
+extern "C" int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                                         const float *ring_rewards, const float *ring_dones, int64_t ring_size,
+                                         uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, const float *params_local,
+                                         const float *params_target, float *workspace, float *grad_out, float *loss_out,
+                                         int32_t batch, int32_t num_taus, float gamma, void *stream) {
+    if (!rng_state_dev) return MN_ERR_INVALID;
+    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local,
+                       params_target, workspace, grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out,
+                       stream);
 }
 
 extern "C" int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev,

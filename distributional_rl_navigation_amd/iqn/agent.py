@@ -282,8 +282,8 @@ class IQNAgent:
             m = self.memory
             ft = self._fused_trainer()
             self._enter_train_path("hip")
-            idx, taus = ft.sample(m.size, self.BATCH_SIZE)                   # replay_buffer.py:47 + model.py:149
-            loss = ft.step((m.states, m.actions, m.rewards, m.next_states, m.dones), idx, taus[0], taus[1])
+            # replay_buffer.py:47 + model.py:149 + agent.py:269-304: the batch is drawn inside the forward / backward launch
+            loss = ft.step_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE)
             self.grad_steps += 1
             return loss
         return self.train(self.memory.sample())

@@ -126,6 +126,28 @@ class FusedTrainer:
             raise _capi.MarineNavHipError(f"mn_iqn_sample failed ({rc}): need batch <= 1024 and ring_size >= batch")
         return idx, taus
 
+    def step_sampled(self, ring, ring_size, batch):
+        """`self.train(self.memory.sample())` (agent.py:131-133) in one call: the batch (ReplayBuffer.sample's uniform draw without
+        replacement over the first `ring_size` rows + the step's tau draws) is drawn INSIDE the forward / backward kernel from this
+        trainer's generator state -- bit-identical to `sample()` followed by `step()`, one launch less.  Returns the loss."""
+        ag = self.agent
+        states, actions, rewards, next_states, dones = ring
+        for t in ring:
+            assert t.is_cuda and t.is_contiguous()
+        assert states.dtype == torch.float32 and actions.dtype == torch.int64 and dones.dtype == torch.float32
+        if batch not in self._idx:
+            self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
+            self._taus[batch] = torch.empty(2, batch, ag.N, dtype=torch.float32, device=self.device)
+        L = _capi.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = L.mn_iqn_train_grad_sampled(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size),
+                                         _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target),
+                                         _p(self._workspace(batch)), _p(self.grad), _p(self.loss), batch, ag.N,
+                                         C.c_float(ag.GAMMA ** ag.n_step), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_train_grad_sampled failed ({rc}): need batch <= 1024 and ring_size >= batch")
+        return self._finish_step(batch)
+
     def step(self, ring, idx=None, taus_target=None, taus_local=None):
         """One optimizer step.  `ring` = (states [c,26] f32, actions [c,1] i64, rewards [c,1] f32, next_states [c,26] f32,
         dones [c,1] f32), all contiguous on the device; `idx` [B] i64 selects the batch rows (None: all rows in
@@ -156,6 +178,13 @@ class FusedTrainer:
                                  B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_grad failed ({rc})")
+        return self._finish_step(B)
+
+    def _finish_step(self, B):
+        """Gradient in self.grad -> (shared learner: all-reduce) -> clip + Adam -> loss."""
+        ag = self.agent
+        L = _capi.lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if ag.distributed:
             import torch.distributed as dist
             if dist.get_backend() == "gloo":

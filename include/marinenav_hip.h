@@ -319,6 +319,16 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
                       const float *taus_target_dev, const float *taus_local_dev, const float *params_local,
                       const float *params_target, float *workspace, float *grad_out, float *loss_out, int32_t batch,
                       int32_t num_taus, float gamma, void *stream);
+/* The same gradient step with the batch drawn inside the launch: every workgroup of the forward / backward kernel runs
+ * mn_iqn_sample's (cheap, deterministic) draw of the batch's ring rows from {seed, call counter} and keeps its own, so the
+ * separate sampling launch disappears (8-11 us of a 57 us step).  Bit-identical to mn_iqn_sample followed by
+ * mn_iqn_train_grad from the same state; the call counter is advanced once (by the reduction kernel).  idx_out [batch] i64
+ * and taus_out [2][batch][8] receive the batch (NULL: not written).  Needs batch <= 1024, batch <= ring_size < 2^31. */
+int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                              const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,
+                              int64_t *idx_out, float *taus_out, const float *params_local, const float *params_target,
+                              float *workspace, float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma,
+                              void *stream);
 int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
                       int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
 

@@ -389,3 +389,39 @@ def test_hip_and_torch_gradient_steps_share_one_adam_state(torch):
     assert int(mixed._fused.step_dev) == 7
     st = mixed.optimizer.state[p0]
     assert st["exp_avg"].data_ptr() == mixed._fused.exp_avg.data_ptr()           # same memory, not a copy
+
+
+def test_sampled_gradient_step_equals_sample_then_step(torch):
+    """`mn_iqn_train_grad_sampled` draws the batch inside the forward / backward kernel (every workgroup runs the draw and keeps its
+    own rows): same rows, same taus, same gradient step, bit for bit, as `mn_iqn_sample` followed by `mn_iqn_train_grad` from the
+    same generator state, and the call counter advances by one per step either way."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    agents = []
+    for _ in range(2):
+        g = torch.Generator(device=dev); g.manual_seed(21)
+        ag = IQNAgent(26, 9, BATCH_SIZE=256, seed=9, BUFFER_SIZE=3000, device=dev)
+        s_, ac, r, ns, d = _random_batch(torch, 2500, g)
+        ag.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
+        agents.append(ag)
+    a, b = agents
+    for step in range(4):
+        la = a.train_from_memory()                                             # sampled inside the kernel
+        m, ft = b.memory, b._fused_trainer()
+        b._enter_train_path("hip")
+        idx, taus = ft.sample(m.size, 256)                                     # two-launch form
+        lb = ft.step((m.states, m.actions, m.rewards, m.next_states, m.dones), idx, taus[0], taus[1])
+        fa = a._fused
+        assert torch.equal(fa._idx[256], idx) and torch.equal(fa._taus[256], taus), step
+        assert float(la) == float(lb) and torch.equal(fa.local, ft.local) and torch.equal(fa.grad, ft.grad), step
+        assert torch.equal(fa.rng_state, ft.rng_state) and int(fa.rng_state[1]) == step + 1
+        assert idx.unique().numel() == 256 and int(idx.max()) < 2500
+    # a small ring and a batch that is not a multiple of the workgroup count's granularity
+    c = IQNAgent(26, 9, BATCH_SIZE=32, seed=3, BUFFER_SIZE=64, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    s_, ac, r, ns, d = _random_batch(torch, 40, g)
+    c.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
+    for _ in range(3):
+        assert np.isfinite(float(c.train_from_memory()))
+        i3 = c._fused._idx[32]
+        assert i3.unique().numel() == 32 and int(i3.min()) >= 0 and int(i3.max()) < 40
