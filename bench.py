@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "f64"],
                     help="env kernels: mixed (default; float32 field / sonar decisions, 1e-5 on float32 outputs) or f64 (everything float64, 1e-9)")
-    ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout")
+    ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2, 3), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout, 3 = split-f16 on 32x32x16 tiles")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
 
@@ -336,11 +336,14 @@ def main():
         }
         if fused and act_ms > 0:
             alg_tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
-            if args.act_variant == 2:
+            if args.act_variant in (2, 3):
                 # split-f16 kernel: the matrix pipe executes three f16 MFMAs per float32 product; `achieved` counts the FLOPs it
                 # ISSUES (incl. the 3x and the K padding) against the f16 dense peak, i.e. the fraction of the pipe that is busy
-                tf = ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
-                kern, peak = "iqn_qvals_split_kernel (3 x v_mfma_f32_16x16x32_f16 per f32 product, f32-class accuracy)", F16_MFMA_PEAK_TFLOPS
+                issued = ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else 198 * 32768
+                tf = issued * n / (act_ms * 1e-3) / 1e12
+                kern = ("iqn_qvals_split_kernel (3 x v_mfma_f32_16x16x32_f16 per f32 product, f32-class accuracy)" if args.act_variant == 2 else
+                        "iqn_qvals_split32_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, f32-class accuracy)")
+                peak = F16_MFMA_PEAK_TFLOPS
             else:
                 tf = alg_tf
                 kern = "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)"
@@ -348,10 +351,10 @@ def main():
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
                 "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak,
                 "unit": "TFLOP/s", "frac": tf / peak,
-                "traffic": PMC_TRAFFIC_BYTES["act_split" if args.act_variant == 2 else "act"] if n == 65536 else None,
+                "traffic": PMC_TRAFFIC_BYTES["act_split" if args.act_variant in (2, 3) else "act"] if n == 65536 else None,
                 "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch: observations + taus in, actions out), "
-                                  + ("profiles/r02_full_loop_kernel_stats_split_act.txt" if args.act_variant == 2 else "profiles/r01_full_loop_kernel_stats.txt") + "; not live",
-                "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else ACT_FLOP_PER_ENV_STEP,
+                                  + ("profiles/r02_full_loop_kernel_stats_split_act.txt" if args.act_variant in (2, 3) else "profiles/r01_full_loop_kernel_stats.txt") + "; not live",
+                "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else (198 * 32768 if args.act_variant == 3 else ACT_FLOP_PER_ENV_STEP),
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
                 "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,
                 "launch_ms": act_ms, "launches_timed": act_launches,

@@ -736,6 +736,7 @@ __global__ __launch_bounds__(256) void iqn_prep32_kernel(IqnWeights w, float *__
 }  // namespace v32
 
 #include "iqn_act_split.h"
+#include "iqn_act_split32.h"
 
 }  // namespace
 
@@ -751,8 +752,9 @@ struct mn_iqn_ctx {
     float *packed = nullptr;       // weight image of the 16x16x4 kernel (act_eval's quantile variant, variant 1)
     float *packed32 = nullptr;     // weight image of the 32x32x2 kernel (default acting path)
     uint32_t *packed_sp = nullptr; // weight image of the split-f16 kernel (iqn_act_split.h)
+    uint32_t *packed_sp32 = nullptr;   // ... and of its 32x32x16 form (iqn_act_split32.h)
     float *consts_sp = nullptr;    // its scale / bound constants
-    bool dirty = true, dirty32 = true, dirty_sp = true;
+    bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
@@ -772,7 +774,9 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(v32::iqn_qvals32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp32::iqn_qvals_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
         return MN_ERR_HIP;
     mn_iqn_ctx *c = new mn_iqn_ctx();
     c->device = dev;
@@ -780,10 +784,12 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
     if (hipMalloc(reinterpret_cast<void **>(&c->packed), OFF_FB * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed32), v32::OFF_FB * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->packed_sp32), sp32::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST * sizeof(float)) != hipSuccess) {
         (void)hipFree(c->packed);
         (void)hipFree(c->packed32);
         (void)hipFree(c->packed_sp);
+        (void)hipFree(c->packed_sp32);
         delete c;
         return MN_ERR_ALLOC;
     }
@@ -800,6 +806,7 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->packed);
     (void)hipFree(c->packed32);
     (void)hipFree(c->packed_sp);
+    (void)hipFree(c->packed_sp32);
     (void)hipFree(c->consts_sp);
     if (moved) (void)hipSetDevice(cur);
     delete c;
@@ -811,11 +818,12 @@ extern "C" int mn_iqn_weights_changed(mn_iqn_ctx *c) {
     c->dirty = true;
     c->dirty32 = true;
     c->dirty_sp = true;
+    c->dirty_sp32 = true;
     return MN_OK;
 }
 
 extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
-    if (!c || variant < 0 || variant > 2) return MN_ERR_INVALID;
+    if (!c || variant < 0 || variant > 3) return MN_ERR_INVALID;
     c->variant = variant;
     return MN_OK;
 }
@@ -868,25 +876,36 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
     // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 1 = exact-f32 32x32x2 kernel, 2 = split-f16 kernel
     // (iqn_act_split.h); quantile capture (act_eval) always runs on the exact 16x16x4 kernel
-    const bool use_sp = !quantiles_dev && c->variant == 2;
+    const bool use_sp = !quantiles_dev && c->variant == 2, use_sp32 = !quantiles_dev && c->variant == 3;
     const bool use32 = !quantiles_dev && c->variant == 1;
-    if (use_sp) {
-        const int pack_blocks = c->dirty_sp ? sp::PACK_BLOCKS : 0;
+    if (use_sp || use_sp32) {
+        bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
+        uint32_t *image = use_sp32 ? c->packed_sp32 : c->packed_sp;
+        const int pack_blocks = dirty_s ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
         if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
             int rng_blocks = (int)((groups + 255) / 256);
             if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
-            hipLaunchKernelGGL(sp::iqn_split_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
-                               c->packed_sp, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
+            if (use_sp32)
+                hipLaunchKernelGGL(sp32::iqn_split32_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                                   image, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
+            else
+                hipLaunchKernelGGL(sp::iqn_split_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                                   image, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
             taus_dev = draws_dev;
             explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
         } else if (pack_blocks) {
-            hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
+            if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
+            else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
         }
-        c->dirty_sp = false;
-        hipLaunchKernelGGL(sp::iqn_qvals_split_kernel, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                           (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+        dirty_s = false;
+        if (use_sp32)
+            hipLaunchKernelGGL(sp32::iqn_qvals_split32_kernel, dim3(blocks), dim3(512), sp32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+        else
+            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }

@@ -88,7 +88,8 @@ __device__ __forceinline__ float pow2_to_2p15(float amax) {
     return __builtin_bit_cast(float, (uint32_t)(268 - e) << 23);         // 2^(141 - e)
 }
 
-// consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3
+// consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3,
+// [10], [11] = 2^k4, 2^-k4 (output layer)
 // (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 1024 threads: coalesced max-reductions
 // over the three weight matrices; the 64 row sums of W2 / W3 by 16 threads per row (a thread per row walking its row serially
 // took 28 us -- 208 dependent L2 round trips -- and this kernel runs after every optimizer step); one combined reduction.
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, fl
     __shared__ float red[16][8];
     const int tid = threadIdx.x;
     // v[0..2] = max |W1|, |W2|, |W3|;  v[3], v[4] = row sums of W2, W3 (row = tid / 16, 16 threads per row);  v[5], v[6] = |b2|, |b3|
-    float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // v[7] = max |W4| (the 32x32 kernel runs the output layer on the matrix pipe)
     for (int i = tid; i < F * N_COS; i += 1024) v[0] = fmaxf(v[0], fabsf(w.W1[i]));
     for (int i = tid; i < H * F; i += 1024) v[1] = fmaxf(v[1], fabsf(w.W2[i]));
     for (int i = tid; i < H * H; i += 1024) v[2] = fmaxf(v[2], fabsf(w.W3[i]));
@@ -104,21 +105,22 @@ __global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, fl
     for (int j = k; j < F; j += 16) v[3] += fabsf(w.W2[row * F + j]);
     for (int j = k; j < H; j += 16) v[4] += fabsf(w.W3[row * H + j]);
     if (tid < H) { v[5] = fabsf(w.b2[tid]); v[6] = fabsf(w.b3[tid]); }
+    if (tid < A_OUT * H) v[7] = fabsf(w.W4[tid]);
     // the row sums first (within 16 lanes), then all seven maxima through the same shuffle rounds and ONE pass through LDS
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) { v[3] += __shfl_xor(v[3], off); v[4] += __shfl_xor(v[4], off); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int q = 0; q < 7; ++q) v[q] = fmaxf(v[q], __shfl_xor(v[q], off));
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], __shfl_xor(v[q], off));
     if ((tid & 63) == 0)
 #pragma unroll
-        for (int q = 0; q < 7; ++q) red[tid >> 6][q] = v[q];
+        for (int q = 0; q < 8; ++q) red[tid >> 6][q] = v[q];
     __syncthreads();
     if (tid == 0) {
-        float r[7];
+        float r[8];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
+        for (int q = 0; q < 8; ++q) {
             r[q] = red[0][q];
             for (int i = 1; i < 16; ++i) r[q] = fmaxf(r[q], red[i][q]);
         }
@@ -128,7 +130,9 @@ __global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, fl
         consts[3] = 1.0f / s1; consts[4] = 1.0f / s2; consts[5] = 1.0f / s3;      // exact: powers of two
         consts[6] = r2 * infl; consts[7] = b2m * infl;
         consts[8] = r3 * r2 * infl * infl; consts[9] = (r3 * b2m * infl + b3m) * infl;
-        for (int i = 10; i < N_CONST; ++i) consts[i] = 0.f;
+        const float s4 = pow2_to_2p15(r[7]);
+        consts[10] = s4; consts[11] = 1.0f / s4;                                  // output layer scale (32x32 kernel)
+        for (int i = 12; i < N_CONST; ++i) consts[i] = 0.f;
     }
 }
 
@@ -410,7 +414,7 @@ struct EncState {
 };
 template <int IDX>
 __device__ __forceinline__ void enc_substep(const float *__restrict__ lds, const f32x4 *__restrict__ ldsv, int enc_w, int enc_f, int lane,
-                                            const float (&ov)[28], EncState &st) {
+                                            const float (&ov)[28], EncState &st, int off_wvg = OFF_WVG) {
     if constexpr (IDX < 24) {
         constexpr int j = IDX / 8, k = IDX % 8;
         if constexpr (k == 0) {
@@ -428,7 +432,7 @@ __device__ __forceinline__ void enc_substep(const float *__restrict__ lds, const
             st.bnd = fmaxf(st.bnd, fabsf(a) * (valid ? lds[enc_f + 32 + 64 * j] : 0.f));
         }
     } else {
-        const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + OFF_WVG)[lane & 31];
+        const f32x2 wv = reinterpret_cast<const f32x2 *>(lds + off_wvg)[lane & 31];
         const float i0 = lane < 16 ? ov[0] : ov[2], i1 = lane < 16 ? ov[1] : ov[3];
         const float a = lane < 32 ? lds[enc_f + (OFF_BE - OFF_BND)] + wv[0] * i0 + wv[1] * i1 : 0.f;
         st.fval[3] = a;

@@ -246,8 +246,10 @@ int mn_iqn_weights_changed(mn_iqn_ctx *c);
  *      from a guaranteed bound, so the result has the error class of float32 arithmetic (measured against a float64
  *      evaluation it is as close as the exact kernel and as eager PyTorch float32) at ~1/3 of the time;
  *   0: the exact-f32 v_mfma_f32_16x16x4_f32 kernel (also the one that always writes the quantiles of act_eval);
- *   1: the exact-f32 v_mfma_f32_32x32x2_f32 re-layout (measured 2.6 % slower than 0 on MI355X, kept for comparison).
- * Same network in all three; they differ by float32 rounding only. */
+ *   1: the exact-f32 v_mfma_f32_32x32x2_f32 re-layout (measured 2.6 % slower than 0 on MI355X, kept for comparison);
+ *   3: the split-f16 kernel on v_mfma_f32_32x32x16_f16 tiles, output layer on the matrix pipe too (half the MFMA instructions
+ *      of 2; measured 4 % slower on MI355X, kept for comparison).
+ * Same network in all four; they differ by float32 rounding only. */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
 
 /* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with

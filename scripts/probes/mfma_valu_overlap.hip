@@ -53,6 +53,43 @@ static float run_dist(int iters, float *dout) {
     return ms;
 }
 
+// (e) the same matrix work as 32x32x16 MFMAs (8 passes, 2 x the FLOPs of a 16x16x32): one MFMA + K2 fillers
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int K2>
+__global__ __launch_bounds__(512) void kern32(float *out, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 1e-3f); b[i] = (_Float16)1.0f; }
+    f32x16 acc[4];
+    float v[8];
+    for (int j = 0; j < 4; ++j) for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = threadIdx.x * 0.001f + j;
+    const float m = 0.999f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < K2; ++k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[(j + k) & 7]) : "v"(m));
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < 4; ++j) s += acc[j][0];
+    for (int j = 0; j < 8; ++j) s += v[j];
+    if (s == 12345.f) out[0] = s;
+}
+template <int K2>
+static float run32(int iters, float *dout) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        (void)hipEventRecord(e0);
+        kern32<K2><<<256, 512>>>(dout, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    return ms;
+}
+
 template <int K, int MODE>
 __global__ __launch_bounds__(512) void kern(float *out, int iters, int valu_only_first) {
     f16x8 a, b;
@@ -112,5 +149,11 @@ int main() {
     printf("   K=0: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<0, 8>(iters, dout) * per / 2, run_dist<0, 4>(iters, dout) * per / 2, run_dist<0, 2>(iters, dout) * per / 2, run_dist<0, 1>(iters, dout) * per / 2);
     printf("   K=2: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<2, 8>(iters, dout) * per / 2, run_dist<2, 4>(iters, dout) * per / 2, run_dist<2, 2>(iters, dout) * per / 2, run_dist<2, 1>(iters, dout) * per / 2);
     printf("   K=3: dist 8 %.2f  4 %.2f  2 %.2f  1 %.2f\n", run_dist<3, 8>(iters, dout) * per / 2, run_dist<3, 4>(iters, dout) * per / 2, run_dist<3, 2>(iters, dout) * per / 2, run_dist<3, 1>(iters, dout) * per / 2);
+    {
+        const double per32 = 1e6 / (iters * 4.0) / 2;     // ns per 32x32x16 MFMA per SIMD (two waves) = two 16x16x32 slots of matrix work
+        printf("(e) TWO waves per SIMD, v_mfma_f32_32x32x16_f16 + K2 fillers: ns per MFMA (= 2 slots of (c)): K2=0 %.2f  2 %.2f  4 %.2f  6 %.2f  8 %.2f  10 %.2f\n",
+               run32<0>(iters, dout) * per32, run32<2>(iters, dout) * per32, run32<4>(iters, dout) * per32, run32<6>(iters, dout) * per32, run32<8>(iters, dout) * per32,
+               run32<10>(iters, dout) * per32);
+    }
     return 0;
 }

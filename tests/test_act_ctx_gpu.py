@@ -156,7 +156,7 @@ def test_iqn_ctx_c_abi_errors(torch):
 @pytest.mark.parametrize("weights", ["seeded", "pretrained"])
 def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
     """The acting kernel exists in three forms (`mn_iqn_set_variant`: 2 = split-f16 MFMA, the default; 0 = exact-f32 16x16x4;
-    1 = the exact-f32 32x32x2 re-layout).  Same network, float32-class results in all: each matches eager PyTorch to float32
+    1 = the exact-f32 32x32x2 re-layout; 3 = the split-f16 kernel on 32x32x16 tiles).  Same network, float32-class results in all: each matches eager PyTorch to float32
     rounding on ragged batch sizes, they match each other, and they pick the same greedy action wherever the top-2 gap is
     above the rounding noise."""
     from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
@@ -172,12 +172,12 @@ def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
         with torch.no_grad():
             ref = net.get_qvals(obs, 1.0, taus=taus)
         out = {}
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):
             ctx.set_variant(variant)
             out[variant] = fused_act(net, obs, 0.0, 1.0, taus=taus, want_qvals=True)
         ctx.set_variant(ctx.DEFAULT_VARIANT)
         scale = max(1.0, float(ref.abs().max()))
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):
             a, q = out[variant]
             assert float((q - ref).abs().max()) < 3e-5 * scale, (variant, n)
             top2 = ref.topk(2, dim=1).values
@@ -185,6 +185,7 @@ def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
             assert torch.equal(a.long()[clear], ref.argmax(dim=1)[clear])
         assert float((out[0][1] - out[1][1]).abs().max()) < 3e-5 * scale
         assert float((out[0][1] - out[2][1]).abs().max()) < 3e-5 * scale
+        assert float((out[0][1] - out[3][1]).abs().max()) < 3e-5 * scale
     # exploration epilogue of the 32x32x2 kernel: same rule as the default kernel (greedy iff u > eps)
     ctx.set_variant(1)
     n = 20000
