@@ -572,7 +572,8 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     // the pipeline's issue gaps) was built and measured: 359 us against 326 us -- the kernel is
     // bound by the SIMD's aggregate instruction issue (~1 instruction per 5 cycles over both waves, the same rate as
     // profiles/r02_mfma_valu_overlap_probe.txt at K = 3), so moving instructions around buys nothing and the extra live
-    // registers cost spills.
+    // registers cost spills.  Requesting ONLY the next environment's taus and observation row one iteration ahead (2 VGPRs,
+    // 28 SGPRs) changes nothing either (338 vs 337 us, alternating runs on one GPU): that latency is covered by the partner wave.
     for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
         float tau[NT];
 #pragma unroll
