@@ -168,3 +168,31 @@ def test_act_rng_path_and_exploration_on_the_split_kernel(torch):
     frac = float((a.long() == ref.argmax(dim=1)).float().mean())
     assert 0.70 < frac < 0.77 and bool(((a >= 0) & (a < 9)).all())
     assert int(rng.state[1]) == 1          # the act kernel advanced the call counter
+
+
+def test_greedy_policy_is_the_same_on_the_split_and_the_exact_kernel(torch, tmp_path):
+    """Policy-level equivalence: the shipped IQN model evaluated greedily on the reference's 30 evaluation worlds, once acting
+    through the exact-f32 kernel and once through the split-f16 kernel, with the same tau draws (same generator seed and call
+    sequence).  Q-values differ by float32 rounding only, so the episodes are the same action for action unless a decision is a
+    tie at the 1e-7 level."""
+    import json
+    import numpy as np
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    with open(os.path.join(G, "eval_config_seed3.json")) as f:
+        cfg = json.load(f)
+    res = {}
+    for variant in (EXACT, SPLIT):
+        agent = IQNAgent(26, 9, device="cuda:0", seed=0, BUFFER_SIZE=1024)
+        agent.load_model(os.path.join(G, "pretrained_IQN_seed3"), "cuda:0")
+        act_context(agent.qnetwork_local).set_variant(variant)
+        env = VecMarineNavEnv(30, device="cuda:0", precision="f64")
+        res[variant] = agent.evaluation_vec(env, cfg, greedy=True, eval_log_path=None)
+        env.close()
+    same = sum(a == b for a, b in zip(res[EXACT]["actions"], res[SPLIT]["actions"]))
+    assert same >= 28, (same, res[EXACT]["successes"], res[SPLIT]["successes"])
+    assert abs(sum(res[EXACT]["successes"]) - sum(res[SPLIT]["successes"])) <= 1
+    if same == 30:
+        assert np.allclose(res[EXACT]["rewards"], res[SPLIT]["rewards"], rtol=0, atol=1e-9)
+    print(f"identical episodes: {same}/30; successes exact {sum(res[EXACT]['successes'])}, split {sum(res[SPLIT]['successes'])}")
