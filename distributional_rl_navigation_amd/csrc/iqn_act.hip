@@ -502,12 +502,6 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-// sum over the 32 lanes of a half wave (lanes sharing l >> 5): the 16-lane row sum, then the other row of the half
-__device__ __forceinline__ float half_sum32(float v) {
-    v = row_sum16(v);
-    return v + __shfl_xor(v, 16);
-}
-
 __global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                              const float *__restrict__ packed, float *__restrict__ qvals,
                                                              const float *__restrict__ explore_u, float eps,

@@ -364,11 +364,11 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
                 }
         }
         // ---- the MFMA of this slot
-        if (m < N_L2) {
-            const int p = m / (4 * NT), mt = (m % (4 * NT)) / NT, nt = m % NT;
+        if constexpr (m < N_L2) {
+            constexpr int p = m / (4 * NT), mt = (m % (4 * NT)) / NT, nt = m % NT;
             if (!((SP_ABL & 16) && p < 2)) acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
-        } else if (NTI_W > 0) {
-            const int q = m - N_L2, kb = q / PER_KB, r = q % PER_KB, p = r / (NTI_W * NT), ti = (r % (NTI_W * NT)) / NT, nt = r % NT;
+        } else if constexpr (NTI_W > 0) {
+            constexpr int q = m - N_L2, kb = q / PER_KB, r = q % PER_KB, p = r / (NTI_W * NT), ti = (r % (NTI_W * NT)) / NT, nt = r % NT;
             if (!((SP_ABL & 16) && p < 2))
                 accW[ti][nt] = mf(p == 0 ? a1l[kb][ti] : a1h[kb][ti], p == 1 ? cbl[kb][nt] : cbh[kb][nt],
                                   (kb == 0 && p == ((SP_ABL & 16) ? 2 : 0)) ? bias[ti] : accW[ti][nt]);
@@ -498,14 +498,14 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
                     a3l[kb][mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
                 }
             }
-        if (m < 24) {                           // layer 2, last K block: tiles {0, 1} then {2, 3}
-            const int half = m / 12, q = m % 12, p = q / 4, mt = 2 * half + (q % 4) / 2, nt = q % 2;
+        if constexpr (m < 24) {                 // layer 2, last K block: tiles {0, 1} then {2, 3}
+            constexpr int half = m / 12, q = m % 12, p = q / 4, mt = 2 * half + (q % 4) / 2, nt = q % 2;
             if (!((SP_ABL & 16) && p < 2)) acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
-        } else if (m < 48) {                    // layer 3, K block 0
-            const int q = m - 24, p = q / 8, mt = (q % 8) / 2, nt = q % 2;
+        } else if constexpr (m < 48) {          // layer 3, K block 0
+            constexpr int q = m - 24, p = q / 8, mt = (q % 8) / 2, nt = q % 2;
             if (!((SP_ABL & 16) && p < 2)) acc3[mt][nt] = mf(p == 0 ? a3l[0][mt] : a3h[0][mt], p == 1 ? b3l[0][nt] : b3h[0][nt], acc3[mt][nt]);
         } else {                                // layer 3, K block 1: tiles {0, 1} then {2, 3}
-            const int q = m - 48, half = q / 12, r = q % 12, p = r / 4, mt = 2 * half + (r % 4) / 2, nt = r % 2;
+            constexpr int q = m - 48, half = q / 12, r = q % 12, p = r / 4, mt = 2 * half + (r % 4) / 2, nt = r % 2;
             if (!((SP_ABL & 16) && p < 2)) acc3[mt][nt] = mf(p == 0 ? a3l[1][mt] : a3h[1][mt], p == 1 ? b3l[1][nt] : b3h[1][nt], acc3[mt][nt]);
         }
         // epilogue sub-steps (48 = 2 halves x 8 register pairs x 3): half 0 two per slot in slots 12..23, half 1 one per slot in 24..47

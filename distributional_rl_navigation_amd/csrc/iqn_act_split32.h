@@ -206,11 +206,11 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
             }
         }
         // the MFMA of this slot
-        if (m < N_L2) {
-            const int ks = m / 6, r = m % 6, p = r / 2, mt = r % 2;
+        if constexpr (m < N_L2) {
+            constexpr int ks = m / 6, r = m % 6, p = r / 2, mt = r % 2;
             acc2[mt] = mf(p == 0 ? a2l[ks][mt] : a2h[ks][mt], p == 1 ? bl[ks] : bh[ks], acc2[mt]);
         } else {
-            const int q = m - N_L2, s = q / 3, p = q % 3;
+            constexpr int q = m - N_L2, s = q / 3, p = q % 3;
             accW = mf(p == 0 ? a1l[s] : a1h[s], p == 1 ? cbl[s] : cbh[s], q == 0 ? bias : accW);
         }
         // epilogue sub-steps of this slot: sub-step u goes after MFMA (u + 1) NM / (N_SUB + 1)
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64 * sp::WAVES) void iqn_qvals_split32_kernel(const
             for (int i = 0; i < 16; ++i) acc2[mt][i] = 0.f;
         f32x16 accA, accB;
         f16x8 bhA[2], blA[2], bhB[2], blB[2];
-        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB);      // layer-1 tile 0
+        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accA, bhB, blB);      // layer-1 tile 0 (no epilogue yet: accR unused)
         stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);      // layer-1 tile 1, epilogue of tile 0
         stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
         stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
