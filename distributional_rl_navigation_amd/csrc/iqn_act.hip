@@ -767,7 +767,9 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
                             LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(v32::iqn_qvals32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp32::iqn_qvals_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
@@ -869,8 +871,9 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
     // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 1 = exact-f32 32x32x2 kernel, 2 = split-f16 kernel
-    // (iqn_act_split.h); quantile capture (act_eval) always runs on the exact 16x16x4 kernel
-    const bool use_sp = !quantiles_dev && c->variant == 2, use_sp32 = !quantiles_dev && c->variant == 3;
+    // (iqn_act_split.h), 3 = split-f16 on 32x32x16 tiles (iqn_act_split32.h)
+    // quantile capture (act_eval): the split-f16 kernel's QUANT form for variants 2 and 3, the exact 16x16x4 kernel's for 0 and 1
+    const bool use_sp = c->variant == 2 || (quantiles_dev && c->variant == 3), use_sp32 = !quantiles_dev && c->variant == 3;
     const bool use32 = !quantiles_dev && c->variant == 1;
     if (use_sp || use_sp32) {
         bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
@@ -897,9 +900,12 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         if (use_sp32)
             hipLaunchKernelGGL(sp32::iqn_qvals_split32_kernel, dim3(blocks), dim3(512), sp32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+        else if (quantiles_dev)
+            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<true>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev);
         else
-            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
+            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<false>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }

@@ -42,7 +42,7 @@
 // a layer's accumulators, split in place, ARE the next layer's B operands.  Layer 2's K = 208 is 6.5 blocks: the 7th
 // block's upper half is zero (weights and activations).
 //
-// act_eval's per-tau quantile output keeps using the exact kernel (iqn_qvals_kernel<true>).
+// act_eval's per-tau quantile output (QUANT = true) runs the output layer on the matrix pipe as well.
 
 #ifndef SP_ABL
 #define SP_ABL 0      // measurement builds only (scripts/act_split_ablation.sh): 1 no operand split, 2 no weight LDS reads, 4 no ReLU / Hadamard, 8 no cos, 16 half the MFMAs
@@ -73,11 +73,12 @@ constexpr int OFF_CST = OFF_BND + F;                    // [16] c1 c2 c3 (accumu
 constexpr int OFF_WS = OFF_CST + 16;                    // [6 i4][176 sf][4] sensor encoder, inputs 4 + 4 i4 + c
 constexpr int OFF_WVG = OFF_WS + 6 * 176 * 4;           // [32 f][2] velocity / goal encoders
 constexpr int OFF_BE = OFF_WVG + 64;                    // [208] encoder biases
-constexpr int OFF_FB = OFF_BE + F;                      // [waves][208] per-wave scaled features
+constexpr int OFF_W4H = OFF_BE + F;                     // [2 kb][piece][64 l] x 8 halves: output layer as an MFMA A operand (act_eval's per-tau quantiles)
+constexpr int OFF_FB = OFF_W4H + 2 * 2 * 64 * 4;        // [waves][208] per-wave scaled features
 constexpr int WAVES = 8;                                // one 512-thread workgroup per CU, two waves per SIMD
 constexpr int LDS_FLOATS = OFF_FB + WAVES * F;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS image of the split-f16 act kernel must fit the CU's 160 KB");
-static_assert(OFF_WS % 4 == 0 && OFF_WVG % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0 && OFF_CST % 4 == 0, "16-byte aligned blocks");
+static_assert(OFF_WS % 4 == 0 && OFF_WVG % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0 && OFF_CST % 4 == 0 && OFF_W4H % 4 == 0, "16-byte aligned blocks");
 constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;       // one thread per 32-bit word of the image
 constexpr int N_CONST = 16;
 
@@ -164,6 +165,18 @@ __device__ __forceinline__ uint32_t pack_word(const IqnWeights &w, const float *
         }
         return out;
     }
+    if (i >= OFF_W4H) {              // output layer, A-operand order of layer 3's K blocks, scaled by 2^k4 and split like the others
+        const int k = i - OFF_W4H, u4 = k >> 2, pair = k & 3, lane = u4 & 63, piece = (u4 >> 6) & 1, kb = u4 >> 7, g = lane >> 4, row = lane & 15;
+        uint32_t out = 0;
+        for (int j = 0; j < 2; ++j) {
+            const int i8 = 2 * pair + j, feat = 16 * (2 * kb + (i8 >> 2)) + 4 * g + (i8 & 3);
+            const float x = (row < A_OUT ? w.W4[row * H + feat] : 0.f) * consts[10];
+            const _Float16 hi = (_Float16)x;
+            const _Float16 v16 = piece == 0 ? hi : (_Float16)(x - (float)hi);
+            out |= half_bits(v16) << (16 * j);
+        }
+        return out;
+    }
     float v;
     if (i < OFF_B1) {                // W4p[t2][l][r] = W4[l & 15][16 t2 + 4 (l >> 4) + r] (rows >= 9 are zero)
         const int k = i - OFF_W4, r = k & 3, l = (k >> 2) & 63, t2 = k >> 8;
@@ -177,7 +190,7 @@ __device__ __forceinline__ uint32_t pack_word(const IqnWeights &w, const float *
         float s = fabsf(w.b1[j]);
         for (int k = 0; k < N_COS; ++k) s += fabsf(w.W1[j * N_COS + k]);
         v = s * 1.0009765625f;
-    } else if (i < OFF_WS) {         // CST[j] = consts[3 + j]: c1 c2 c3 a2 d2 a3 d3
+    } else if (i < OFF_WS) {         // CST[j] = consts[3 + j]: c1 c2 c3 a2 d2 a3 d3 2^k4 2^-k4
         const int j = i - OFF_CST;
         v = 3 + j < N_CONST ? consts[3 + j] : 0.f;
     }
@@ -228,6 +241,14 @@ __device__ __forceinline__ void split2(float x, float y, f16x2 &h, f16x2 &l) {
 __device__ __forceinline__ f16x8 cat4(f16x2 a, f16x2 b, f16x2 c, f16x2 d) {
     const f16x4 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
     return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// two C tiles (registers of one lane) -> the hi / lo B operands of the K block they form
+__device__ __forceinline__ void split_tiles(f32x4 t0, f32x4 t1, f16x8 &bh, f16x8 &bl) {
+    f16x2 h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(t0[0], t0[1], h0, l0); split2(t0[2], t0[3], h1, l1);
+    split2(t1[0], t1[1], h2, l2); split2(t1[2], t1[3], h3, l3);
+    bh = cat4(h0, h1, h2, h3); bl = cat4(l0, l1, l2, l3);
 }
 
 // max(x, 0) as ONE instruction.  Written as a float compare / select (or fmaxf, or med3), a ReLU whose input is a raw MFMA
@@ -538,10 +559,15 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
     });
 }
 
+// QUANT = false: acting / training (tau mean before the linear output layer, f32 VALU mat-vec).
+// QUANT = true : IQNAgent.act_eval (agent.py:217-236): the output layer runs per tau on the matrix pipe (12 more MFMAs on a padded
+//                16-row tile), the [n][32][9] quantile values are written out and Q is their mean.
+template <bool QUANT>
 __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                                  const uint32_t *__restrict__ packed, float *__restrict__ qvals,
                                                                  const float *__restrict__ explore_u, float eps,
-                                                                 int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state) {
+                                                                 int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state,
+                                                                 float *__restrict__ quantiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by the prep kernel
@@ -629,19 +655,68 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
         f32x4 acc3[4][NT];
         tail(lds4, ldsv, lb, c2, S, bhA, blA, acc2, acc3);
-        // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
-        float part = 0.f;
+        float qv;
+        if constexpr (!QUANT) {
+            // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
+            float part = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * S;
-            const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3, sb)), h1 = relu4s(fma4(acc3[mt][1], c3, sb));
-            const f32x4 a = ldsv[lb.w_hi + ((OFF_W4 >> 2) - 4096) + mt * 64];
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * S;
+                const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3, sb)), h1 = relu4s(fma4(acc3[mt][1], c3, sb));
+                const f32x4 a = ldsv[lb.w_hi + ((OFF_W4 >> 2) - 4096) + mt * 64];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
+                for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
+            }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            qv = part * (invS * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
+        } else {
+            // ---- quantile values Z(tau, a) = W4 h3(tau) + b4 (model.py:185): layer 3 epilogue + split, then the output layer as 12 MFMAs
+            // on a padded 16-row tile; lane (g, col) ends up with actions 4 g + r of tau 16 nt + col (scaled by S 2^k4)
+            f16x8 b4h[2][NT], b4l[2][NT];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const f32x4 sb0 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb)] * S, sb1 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb + 1)] * S;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    split_tiles(relu4s(fma4(acc3[2 * kb][nt], c3, sb0)), relu4s(fma4(acc3[2 * kb + 1][nt], c3, sb1)), b4h[kb][nt], b4l[kb][nt]);
+            }
+            f32x4 acc4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc4[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const u32x4 *w4 = reinterpret_cast<const u32x4 *>(lds + OFF_W4H);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, w4[(kb * 2) * 64 + lane]), al = __builtin_bit_cast(f16x8, w4[(kb * 2 + 1) * 64 + lane]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc4[nt] = mf(al, b4h[kb][nt], acc4[nt]);
+                    acc4[nt] = mf(ah, b4l[kb][nt], acc4[nt]);
+                    acc4[nt] = mf(ah, b4h[kb][nt], acc4[nt]);
+                }
+            }
+            const float unscale = invS * lds[OFF_CST + 8];        // 1 / (S 2^k4)
+            const f32x4 b4 = ldsv[(OFF_B4 >> 2) + g];
+            float mine = 0.f;      // lane `a` (< 9) ends up with Q(s, a) = mean over the 32 taus
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a_idx = 4 * g + r;
+                float sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float z = fmaf(acc4[nt][r], unscale, b4[r]);
+                    if (a_idx < A_OUT) quantiles[((size_t)e * K_TAUS + 16 * nt + col) * A_OUT + a_idx] = z;
+                    sum += z;
+                }
+                sum = row_sum16(sum);                    // over the 16 tau columns of the row group
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {         // hand action 4 gg + r to lane (4 gg + r)
+                    const float v = __shfl(sum, 16 * gg);
+                    if (lane == 4 * gg + r) mine = v;
+                }
+            }
+            qv = mine * (1.0f / K_TAUS);
         }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const float qv = part * (invS * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
         if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {

@@ -240,15 +240,15 @@ typedef struct mn_iqn_ctx mn_iqn_ctx;
 int mn_iqn_create(mn_iqn_ctx **out);
 int mn_iqn_destroy(mn_iqn_ctx *c);
 int mn_iqn_weights_changed(mn_iqn_ctx *c);
-/* Which acting kernel serves calls that do not ask for quantiles.
+/* Which acting kernel serves the context's calls (with or without quantile output).
  *   2 (default): the split-f16 kernel -- every float32 operand is split into two f16 pieces (hi = RNE16(x), lo = RNE16(x - hi))
  *      and a product is accumulated as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16 with power-of-two range scaling chosen
  *      from a guaranteed bound, so the result has the error class of float32 arithmetic (measured against a float64
  *      evaluation it is as close as the exact kernel and as eager PyTorch float32) at ~1/3 of the time;
- *   0: the exact-f32 v_mfma_f32_16x16x4_f32 kernel (also the one that always writes the quantiles of act_eval);
+ *   0: the exact-f32 v_mfma_f32_16x16x4_f32 kernel;
  *   1: the exact-f32 v_mfma_f32_32x32x2_f32 re-layout (measured 2.6 % slower than 0 on MI355X, kept for comparison);
  *   3: the split-f16 kernel on v_mfma_f32_32x32x16_f16 tiles, output layer on the matrix pipe too (half the MFMA instructions
- *      of 2; measured 4 % slower on MI355X, kept for comparison).
+ *      of 2; measured 4 % slower on MI355X, kept for comparison; quantile output is served by kernel 2).
  * Same network in all four; they differ by float32 rounding only. */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
 

@@ -196,3 +196,34 @@ def test_greedy_policy_is_the_same_on_the_split_and_the_exact_kernel(torch, tmp_
     if same == 30:
         assert np.allclose(res[EXACT]["rewards"], res[SPLIT]["rewards"], rtol=0, atol=1e-9)
     print(f"identical episodes: {same}/30; successes exact {sum(res[EXACT]['successes'])}, split {sum(res[SPLIT]['successes'])}")
+
+
+def test_quantile_output_of_the_split_kernel(torch):
+    """`act_eval` (agent.py:217-236) on the split kernel: the per-tau quantile values Z(tau, a) against a float64 evaluation of the
+    network, against the exact kernel's, and Q as their mean over the 32 taus."""
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
+    for which in ("seeded", "pretrained"):
+        net = _nets(torch, which)
+        net64 = copy.deepcopy(net).double()
+        obs, taus = _inputs(torch, 4099, 5.0, seed=17)
+        with torch.no_grad():
+            ref, _ = net64.forward(obs.double(), net.K, 1.0, taus=taus.double())
+        ctx = act_context(net)
+        out = {}
+        try:
+            for v in (EXACT, SPLIT):
+                ctx.set_variant(v)
+                out[v] = fused_act(net, obs, 0.0, 1.0, taus=taus, want_quantiles=True, want_qvals=True)
+        finally:
+            ctx.set_variant(ctx.DEFAULT_VARIANT)
+        a0, z0, t0, q0 = out[EXACT]
+        a2, z2, t2, q2 = out[SPLIT]
+        scale = float(z0.abs().max())
+        assert z2.shape == (4099, 32, 9) and bool(torch.isfinite(z2).all())
+        assert float((z2 - z0).abs().max()) < 3e-6 * scale
+        assert float((z2.mean(dim=1) - q2).abs().max()) < 2e-6 * scale and float((q2 - q0).abs().max()) < 3e-6 * scale
+        assert torch.equal(t2, taus.view(4099, 32, 1))
+        if True:
+            e0 = float(((z0.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+            e2 = float(((z2.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+            assert e2 < 1.25 * e0 + 2e-8, (which, e0, e2)
