@@ -4,10 +4,11 @@
 // Why: the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) runs at the f32 VECTOR rate, 1/16 of the f16 rate, and the act kernel
 // built on it sits at 84 % of that peak -- the only way to go substantially faster is to leave that
 // pipe.  Here every f32 operand x is split into two f16 pieces, hi = RNE16(x), lo = RNE16(x - hi) (the subtraction is exact,
-// so x = hi + lo + e with |e| <= 2^-24 |x| as long as lo stays above the f16 subnormal floor), and a product of two
-// operands is accumulated as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16: f16 x f16 products are exact in the f32
-// accumulator, the dropped lo.lo term and the two e terms are each <= 2^-24 relative.  That is the error class of one f32
-// rounding per product; measured against a float64 reference the three-product scheme is as close as the exact-f32 MFMA
+// so x = hi + lo + e with |e| <= 2^-22 |x| in the worst case and ~2^-24.4 |x| rms, as long as lo stays above the f16 subnormal
+// floor), and a product of two operands is accumulated as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16: f16 x f16 products
+// are exact in the f32 accumulator, the dropped lo.lo term and the two e terms are each <= 2^-22 relative (worst case; random in
+// sign, ~2^-24 typical).  That is the error class of one f32 rounding per product -- whose accumulated effect over a K = 64..224
+// dot product is what the exact-f32 MFMA has too; measured against a float64 reference the three-product scheme is as close as the exact-f32 MFMA
 // on these layer shapes (profiles/r02_f16_split_probe.txt: rms error 1.7e-7 vs 1.95e-7 relative, K = 224), f16 subnormal
 // inputs are not flushed by the matrix pipe, and three f16 MFMAs cost 3/16 of the f32 instruction they replace
 // (2057 vs 145.5 TFLOP/s sustained in the same probe).
@@ -18,14 +19,14 @@
 //   * weights of layer l: 2^k_l with max |W_l| 2^k_l in [2^14, 2^15)                    (static, part of the weight image);
 //   * cos embedding: in [-1, 1], not scaled (an f16 pair keeps an absolute error of 2^-25 for ANY |x| <= 1, i.e. 2^-25 of
 //     the largest element, which is what a dot product's error is measured against);
-//   * hidden activations: ONE power of two S per environment, carried through all layers (ReLU is positively
-//     homogeneous: relu(W (S h) + S b) = S relu(W h + b)); S is chosen from a guaranteed bound, not from the data:
+//   * hidden activations: one power of two PER LAYER AND ENVIRONMENT, S_l, chosen from a guaranteed bound, not from the data:
 //         |h1_j| <= B1_j |f_j|,  B1_j = sum_k |W1_jk| + |b1_j|     (|cos| <= 1),      m1 = max_j B1_j |f_j|   (per env)
-//         |h2_i| <= R2 m1 + beta2,  R2 = max_i sum_j |W2_ij|,  beta2 = max |b2|;   |h3| <= R3 (R2 m1 + beta2) + beta3
-//     and S = 2^(14 - floor(log2 M)) for M = the largest of the three bounds, so S |h| < 2^15 always: no overflow for
-//     any weights and any observation.  The bound is conservative (row-sum norms), typically by 2^6..2^10; that costs
-//     nothing as long as the largest activation stays above 2^-1 after scaling (17 binades of slack), see the probe's
-//     "scale 2^-10 lower" rows.
+//         |h2_i| <= M2 = R2 m1 + beta2,  R2 = max_i sum_j |W2_ij|,  beta2 = max |b2|;   |h3| <= M3 = R3 M2 + beta3
+//     and S_l = 2^(14 - floor(log2 M_l)), so S_l |h_l| < 2^15 always: no overflow for any weights and any observation.  Layer
+//     l + 1 receives S_l h_l; its accumulator (which carries S_l 2^k) is brought to S_(l+1) by the per-environment factor
+//     2^-k S_(l+1) / S_l in the v_fma that adds the bias S_(l+1) b -- no extra instruction.  Each bound is conservative only by
+//     its own row-sum slack (2^3..2^7 here), which costs nothing as long as the largest activation of a layer stays above 2^-1
+//     after scaling (17 binades of slack), see the probe's "scale 2^-10 lower" rows and tests/test_act_split_scheme_cpu.py.
 // The observation encoders, the tau-mean and the 9 x 64 output layer stay f32 VALU work as in the exact kernel.
 //
 // Schedule.  With the matrix work cut 4.7 x the kernel is bound by instruction issue: a SIMD issues about one instruction per
@@ -462,14 +463,27 @@ __device__ __forceinline__ void enc_substep(const float *__restrict__ lds, const
 }
 constexpr int N_ENC_SUB = 25;
 
-// the per-environment scale from the lanes' bounds (see the header): S, 1 / S
-__device__ __forceinline__ void env_scale(float bnd, float a2, float d2, float a3, float d3, float &S, float &invS) {
-    const float m1 = wave_max_nonneg(bnd);
-    float M = fmaxf(fmaxf(m1, fmaf(a2, m1, d2)), fmaf(a3, m1, d3));
+// the per-environment scales from the lanes' bounds (see the header): one power of two per hidden layer, S_l |h_l| < 2^15
+struct EnvScale {
+    float S1, S2, S3;      // layer-1 / -2 / -3 activations are carried as S_l h_l
+    float r21, r32;        // S2 / S1, S3 / S2 (exact powers of two): folded into the accumulator unscale of layers 2, 3
+    float invS3;
+};
+__device__ __forceinline__ int bound_exponent(float M) {       // e with M in [2^(e-127), 2^(e-126)), M clamped to a sane range
     M = fminf(fmaxf(M, 1e-30f), 1e30f);
-    const int eM = (int)(__builtin_bit_cast(uint32_t, M) >> 23);          // M in [2^(eM-127), 2^(eM-126))
-    S = __builtin_bit_cast(float, (uint32_t)(268 - eM) << 23);           // 2^(141 - eM): S M < 2^15
-    invS = __builtin_bit_cast(float, (uint32_t)(eM - 14) << 23);         // 2^(eM - 141)
+    return (int)(__builtin_bit_cast(uint32_t, M) >> 23);
+}
+__device__ __forceinline__ EnvScale env_scale(float bnd, float a2, float d2, float a3, float d3) {
+    const float m1 = wave_max_nonneg(bnd);
+    const int e1 = bound_exponent(m1), e2 = bound_exponent(fmaf(a2, m1, d2)), e3 = bound_exponent(fmaf(a3, m1, d3));
+    EnvScale sc;
+    sc.S1 = __builtin_bit_cast(float, (uint32_t)(268 - e1) << 23);           // 2^(141 - e): S M < 2^15
+    sc.S2 = __builtin_bit_cast(float, (uint32_t)(268 - e2) << 23);
+    sc.S3 = __builtin_bit_cast(float, (uint32_t)(268 - e3) << 23);
+    sc.r21 = __builtin_bit_cast(float, (uint32_t)(127 + e1 - e2) << 23);
+    sc.r32 = __builtin_bit_cast(float, (uint32_t)(127 + e2 - e3) << 23);
+    sc.invS3 = __builtin_bit_cast(float, (uint32_t)(e3 - 14) << 23);         // 2^(e - 141)
+    return sc;
 }
 // S 2^-k1 feature -> this wave's LDS buffer (the Hadamard multiplier of the layer-1 epilogue)
 __device__ __forceinline__ void store_features(float *__restrict__ lds, int fb_f, int lane, const EncState &st, float Sc) {
@@ -484,7 +498,7 @@ __device__ __forceinline__ void store_features(float *__restrict__ lds, int fb_f
 //   slots 12..23  the same for tiles 2, 3            || layer-2 epilogue of tiles 0, 1 (unscale + bias, ReLU, split)
 //   slots 24..47  layer-3 MFMAs of K block 0         || layer-2 epilogue of tiles 2, 3
 //   slots 48..71  layer-3 MFMAs of K block 1 (output tiles 0, 1 first)
-// S h2 = relu(acc2 2^-k2 + S b2); the layer-3 accumulators are left in acc3.
+// S2 h2 = relu(acc2 c2 + S b2) with c2 = 2^-k2 S2 / S1 and S = S2 passed by the caller; the layer-3 accumulators are left in acc3.
 __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float S,
                                      const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f32x4 (&acc3)[4][NT]) {
     f16x8 a2h[4], a2l[4];
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
         // observation encoders, per-environment scale S, S 2^-k1 features -> this wave's LDS buffer
-        float S, invS;
+        EnvScale sc;
         {
             const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
             float ov[28];
@@ -629,8 +643,8 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
             for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
             EncState st;
             static_for<N_ENC_SUB>([&](auto I_) { enc_substep<decltype(I_)::value>(lds, ldsv, enc_w, enc_f, lane, ov, st); });
-            env_scale(st.bnd, a2, d2, a3, d3, S, invS);
-            store_features(lds, fb_f, lane, st, S * c1);
+            sc = env_scale(st.bnd, a2, d2, a3, d3);
+            store_features(lds, fb_f, lane, st, sc.S1 * c1);
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -654,32 +668,33 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
         stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
         f32x4 acc3[4][NT];
-        tail(lds4, ldsv, lb, c2, S, bhA, blA, acc2, acc3);
+        tail(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3);
+        const float c3e = c3 * sc.r32;      // layer-3 accumulators carry S2 2^k3: to S3
         float qv;
         if constexpr (!QUANT) {
             // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
             float part = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * S;
-                const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3, sb)), h1 = relu4s(fma4(acc3[mt][1], c3, sb));
+                const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * sc.S3;
+                const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3e, sb)), h1 = relu4s(fma4(acc3[mt][1], c3e, sb));
                 const f32x4 a = ldsv[lb.w_hi + ((OFF_W4 >> 2) - 4096) + mt * 64];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
             }
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
-            qv = part * (invS * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
+            qv = part * (sc.invS3 * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
         } else {
             // ---- quantile values Z(tau, a) = W4 h3(tau) + b4 (model.py:185): layer 3 epilogue + split, then the output layer as 12 MFMAs
             // on a padded 16-row tile; lane (g, col) ends up with actions 4 g + r of tau 16 nt + col (scaled by S 2^k4)
             f16x8 b4h[2][NT], b4l[2][NT];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const f32x4 sb0 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb)] * S, sb1 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb + 1)] * S;
+                const f32x4 sb0 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb)] * sc.S3, sb1 = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * (2 * kb + 1)] * sc.S3;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    split_tiles(relu4s(fma4(acc3[2 * kb][nt], c3, sb0)), relu4s(fma4(acc3[2 * kb + 1][nt], c3, sb1)), b4h[kb][nt], b4l[kb][nt]);
+                    split_tiles(relu4s(fma4(acc3[2 * kb][nt], c3e, sb0)), relu4s(fma4(acc3[2 * kb + 1][nt], c3e, sb1)), b4h[kb][nt], b4l[kb][nt]);
             }
             f32x4 acc4[NT];
 #pragma unroll
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
                     acc4[nt] = mf(ah, b4h[kb][nt], acc4[nt]);
                 }
             }
-            const float unscale = invS * lds[OFF_CST + 8];        // 1 / (S 2^k4)
+            const float unscale = sc.invS3 * lds[OFF_CST + 8];    // 1 / (S3 2^k4)
             const f32x4 b4 = ldsv[(OFF_B4 >> 2) + g];
             float mine = 0.f;      // lane `a` (< 9) ends up with Q(s, a) = mean over the 32 taus
 #pragma unroll

@@ -269,7 +269,7 @@ __device__ __forceinline__ void half_finish(const HalfSplit &hs, f16x8 &bh, f16x
 // The end of an environment's pipeline: the layer-2 K step of the half tile 6, the layer-2 epilogue, layer 3, its epilogue and the
 // output layer, MFMAs and VALU sub-steps interleaved wherever two independent pieces exist.  Leaves the quantile-value tile
 // (rows = actions, padded to 32; columns = taus; scaled by S 2^k4) in acc4.
-__device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float c3, float S,
+__device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float c3, float S2, float S3,
                                      const f16x8 (&bh)[2], const f16x8 (&bl)[2], f32x16 (&acc2)[2], f32x16 &acc4) {
     f16x8 a2h[2], a2l[2];
 #pragma unroll
@@ -281,8 +281,8 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
     f32x16 sb2[2], sb3[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        sb2[mt] = ld_vec16(ldsv, lb.fl + ((OFF_B2 - OFF_B1) >> 2), mt) * S;
-        sb3[mt] = ld_vec16(ldsv, lb.fl + ((OFF_B3 - OFF_B1) >> 2), mt) * S;
+        sb2[mt] = ld_vec16(ldsv, lb.fl + ((OFF_B2 - OFF_B1) >> 2), mt) * S2;
+        sb3[mt] = ld_vec16(ldsv, lb.fl + ((OFF_B3 - OFF_B1) >> 2), mt) * S3;
     }
     f16x8 a3h[4][2], a3l[4][2], a4h[4], a4l[4];
     f16x8 b3h[4], b3l[4], b4h[4], b4l[4];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * sp::WAVES) void iqn_qvals_split32_kernel(const
             cbl[s] = cat4(ll[0], ll[1], ll[2], ll[3]);
         }
         // observation encoders, per-environment scale S, S 2^-k1 features -> this wave's (permuted) LDS buffer
-        float S, invS;
+        sp::EnvScale sc;
         {
             const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
             float ov[28];
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(64 * sp::WAVES) void iqn_qvals_split32_kernel(const
             for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
             sp::EncState st;
             static_for<sp::N_ENC_SUB>([&](auto I_) { sp::enc_substep<decltype(I_)::value>(lds, ldsv, enc_w, enc_f, lane, ov, st, OFF_WVG); });
-            sp::env_scale(st.bnd, a2, d2, a3, d3, S, invS);
-            const float Sc = S * c1;
+            sc = sp::env_scale(st.bnd, a2, d2, a3, d3);
+            const float Sc = sc.S1 * c1;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int sf = lane + 64 * j;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * sp::WAVES) void iqn_qvals_split32_kernel(const
         stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
         stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
         f32x16 acc4;
-        tail(lds4, ldsv, lb, c2, c3, S, bhA, blA, acc2, acc4);
+        tail(lds4, ldsv, lb, c2 * sc.r21, c3 * sc.r32, sc.S2, sc.S3, bhA, blA, acc2, acc4);
 
         // ---- tau mean of the quantile values: lane (h, c) holds actions 4 h + r of tau c in registers r = 0..3 and (h = 0) action 8
         // in register 4; Q(s, a) = mean over the 32 taus, unscaled by 2^-k4 / S (model.py:185,190)
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * sp::WAVES) void iqn_qvals_split32_kernel(const
         const float mine = r4 == 0 ? s0 : (r4 == 1 ? s1 : (r4 == 2 ? s2 : s3));     // action 4 h + (lane & 3)
         const float got = __shfl(mine, lane < 4 ? lane : 32 + (lane & 3));          // lanes 4..7 take half 1's value
         const float qraw = lane == 8 ? s8 : got;
-        const float qv = qraw * (invS * c4 * (1.0f / K_TAUS)) + lds[OFF_B4 + (lane & 15)];     // Q(s, action = lane), valid for lane < 9
+        const float qv = qraw * (sc.invS3 * c4 * (1.0f / K_TAUS)) + lds[OFF_B4 + (lane & 15)];     // Q(s, action = lane), valid for lane < 9
         if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {
