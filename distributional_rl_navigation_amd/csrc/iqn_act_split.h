@@ -46,7 +46,7 @@
 // act_eval's per-tau quantile output (QUANT = true) runs the output layer on the matrix pipe as well.
 
 #ifndef SP_ABL
-#define SP_ABL 0      // measurement builds only (scripts/act_split_ablation.sh): 1 no operand split, 2 no weight LDS reads, 4 no ReLU / Hadamard, 8 no cos, 16 half the MFMAs
+#define SP_ABL 0      // measurement builds only (scripts/act_split_ablation.sh): 1 no operand split, 2 no weight LDS reads, 4 no ReLU / Hadamard, 8 no cos, 16 only the hi.hi products, 64 s_memtime phase timing (printf)
 #endif
 
 namespace sp {
@@ -267,6 +267,27 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, float c, f32x4 b) {
     f32x4 r;
     r.x = fmaf(a.x, c, b.x); r.y = fmaf(a.y, c, b.y); r.z = fmaf(a.z, c, b.z); r.w = fmaf(a.w, c, b.w);
     return r;
+}
+
+// sums over the 16 lanes of a row for 16 values at once, step by step over all values: the DPP steps of one value depend on each
+// other (and a DPP read of a register just written needs wait states), the 16 values do not
+__device__ __forceinline__ void row_sum16_x16(float (&v)[16]) {
+#define SP_DPP_STEP(ctrl)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                                              \
+        v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, 0xF, 0xF, true));
+    SP_DPP_STEP(0xB1)      // quad xor 1
+    SP_DPP_STEP(0x4E)      // quad xor 2
+    SP_DPP_STEP(0x141)     // row_half_mirror
+    SP_DPP_STEP(0x140)     // row_mirror
+#undef SP_DPP_STEP
+}
+// sum over the four 16-lane rows of a wave, result in every lane: two v_permlane*_swap (VALU, no LDS round trip)
+__device__ __forceinline__ float sum_rows4(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));     // a = rows [0 0 2 2], b = rows [1 1 3 3]
+    float c = a + b, d = c;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));     // c = halves [lo lo], d = halves [hi hi]
+    return c + d;
 }
 
 // max over the wave of a non-negative value (uniform result)
@@ -614,7 +635,12 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     // profiles/r02_mfma_valu_overlap_probe.txt at K = 3), so moving instructions around buys nothing and the extra live
     // registers cost spills.  Requesting ONLY the next environment's taus and observation row one iteration ahead (2 VGPRs,
     // 28 SGPRs) changes nothing either (338 vs 337 us, alternating runs on one GPU): that latency is covered by the partner wave.
+    [[maybe_unused]] int sp_iter = 0;
     for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
+        [[maybe_unused]] unsigned long long tk[16];
+#define SP_TICK(i) do { if (SP_ABL & 64) { __builtin_amdgcn_sched_barrier(0); tk[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+        SP_TICK(0);
+        const float u_explore = (explore_u && eps > 0.f) ? explore_u[__builtin_amdgcn_readfirstlane(e)] : 2.0f;     // used ~10 us later
         float tau[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e * K_TAUS + 16 * nt + col];
@@ -634,6 +660,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
                 cbh[kb][nt] = cat4(h[0], h[1], h[2], h[3]);
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
+        SP_TICK(1);
         // observation encoders, per-environment scale S, S 2^-k1 features -> this wave's LDS buffer
         EnvScale sc;
         {
@@ -649,6 +676,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 
+        SP_TICK(2);
         // ---- layers 1 + 2 fused over the 7 K blocks of layer 2, software-pipelined as in the exact kernel: the layer-1
         // MFMAs of block b + 1 are issued before the VALU epilogue of block b
         f32x4 acc2[4][NT];
@@ -660,30 +688,45 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         f32x4 accA[2][NT], accB[2][NT];
         f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
         stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB);      // layer-1 block 0
+        SP_TICK(3);
         stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);      // layer-1 block 1, epilogue of block 0
+        SP_TICK(4);
         stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        SP_TICK(5);
         stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        SP_TICK(6);
         stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        SP_TICK(7);
         stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        SP_TICK(8);
         stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        SP_TICK(9);
         stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        SP_TICK(10);
         f32x4 acc3[4][NT];
         tail(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3);
+        SP_TICK(11);
         const float c3e = c3 * sc.r32;      // layer-3 accumulators carry S2 2^k3: to S3
         float qv;
         if constexpr (!QUANT) {
-            // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S) ---------
-            float part = 0.f;
+            // ---- layer 3 epilogue, tau mean, f32 output layer (as in the exact kernel; the sums carry the factor S3) ---------
+            float hs[16];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const f32x4 sb = ldsv[lb.fl + ((OFF_B3 - OFF_B1) >> 2) + 4 * mt] * sc.S3;
                 const f32x4 h0 = relu4s(fma4(acc3[mt][0], c3e, sb)), h1 = relu4s(fma4(acc3[mt][1], c3e, sb));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hs[4 * mt + r] = h0[r] + h1[r];
+            }
+            row_sum16_x16(hs);                          // sum over the 32 taus of h3[16 mt + 4 g + r], in every lane of row group g
+            float part = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
                 const f32x4 a = ldsv[lb.w_hi + ((OFF_W4 >> 2) - 4096) + mt * 64];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part = fmaf(a[r], row_sum16(h0[r] + h1[r]), part);
+                for (int r = 0; r < 4; ++r) part = fmaf(a[r], hs[4 * mt + r], part);
             }
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
+            part = sum_rows4(part);                     // the four row groups' shares of action `col`
             qv = part * (sc.invS3 * (1.0f / K_TAUS)) + lds[OFF_B4 + col];     // Q(s, action = col), valid for col < 9
         } else {
             // ---- quantile values Z(tau, a) = W4 h3(tau) + b4 (model.py:185): layer 3 epilogue + split, then the output layer as 12 MFMAs
@@ -735,22 +778,27 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
         // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
         if (actions) {
-            float best = -INFINITY;
+            // lane a holds action a: nine v_readlane (no LDS round trip); first maximum wins, like np.argmax
+            float best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), 0));
             int arg = 0;
-#pragma unroll
-            for (int a = 0; a < A_OUT; ++a) {
-                const float v = __shfl(qv, a);
-                if (v > best) { best = v; arg = a; }
-            }
+#define SP_ARG(a) { const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), a)); if (v > best) { best = v; arg = a; } }
+            SP_ARG(1) SP_ARG(2) SP_ARG(3) SP_ARG(4) SP_ARG(5) SP_ARG(6) SP_ARG(7) SP_ARG(8)
+#undef SP_ARG
             if (lane == 0) {
                 int act = arg;
                 if (explore_u && eps > 0.f) {
-                    const float u = explore_u[e];            // greedy iff u > eps (agent.py:200)
+                    const float u = u_explore;               // greedy iff u > eps (agent.py:200); requested at the top of the iteration
                     if (!(u > eps)) { act = (int)(u / eps * (float)A_OUT); act = act > A_OUT - 1 ? A_OUT - 1 : act; }
                 }
                 actions[e] = act;
             }
         }
+        SP_TICK(12);
+        if ((SP_ABL & 64) && blockIdx.x == 3 && wave == 1 && lane == 0 && ++sp_iter == 6)
+            printf("phase cycles (block 3, wave 1, 6th env): cos %llu  encoder+scale %llu  stage-2 %llu  stage-1 %llu  stages0..5 %llu %llu %llu %llu %llu %llu  tail %llu  output %llu  | env total %llu\n",
+                   tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6], tk[8] - tk[7], tk[9] - tk[8], tk[10] - tk[9],
+                   tk[11] - tk[10], tk[12] - tk[11], tk[12] - tk[0]);
+#undef SP_TICK
     }
 }
 
