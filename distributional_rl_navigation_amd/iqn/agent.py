@@ -1,9 +1,10 @@
 """IQN agent: batched act / learn around the HIP vector env.
 
-Keeps the reference's `IQNAgent` surface (thirdparty/IQN/agent.py:10-407: constructor keywords,
-act / act_eval / act_adaptive / adjust_cvar / train / soft_update / evaluation / load_model /
-learn) and adds the batched counterparts that the MI355X path actually runs:
-`act_batch`, `learn_vec`, `evaluation_vec`.  Optional data-parallel training over RCCL:
+Keeps the reference's `IQNAgent` surface (thirdparty/IQN/agent.py:10-407): the constructor keywords, `train`,
+`soft_update`, `load_model` here; the reference-shaped single-env methods (`learn`, `evaluation`, `act`, `act_eval`,
+`act_adaptive`, `adjust_cvar`, `linear_eps`) are the boundary layer and live in `iqn/compat.py` (`ReferenceLoopMixin`).
+This file is the batched code the MI355X path actually runs: `act_batch`, `vec_step`, `learn_vec`, `evaluation_vec`,
+the fused / pipelined gradient step.  Optional data-parallel training over RCCL:
 one flat 35 785-float gradient bucket, one all_reduce per grad step.
 """
 import os
@@ -13,6 +14,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from .compat import ReferenceLoopMixin
 from .model import ObsEncoder
 from .replay_buffer import ReplayBuffer
 
@@ -22,7 +24,7 @@ def calculate_huber_loss(td_errors, k=1.0):
     return torch.where(td_errors.abs() <= k, 0.5 * td_errors.pow(2), k * (td_errors.abs() - 0.5 * k))
 
 
-class IQNAgent:
+class IQNAgent(ReferenceLoopMixin):
     def __init__(self, state_size, action_size, layer_size=64, n_step=1, BATCH_SIZE=32, BUFFER_SIZE=1_000_000,
                  LR=1e-4, TAU=1.0, GAMMA=0.99, UPDATE_EVERY=4, learning_starts=10000, target_update_interval=10000,
                  exploration_fraction=0.1, initial_eps=1.0, final_eps=0.05, device="cpu", seed=0,
@@ -95,29 +97,6 @@ class IQNAgent:
         self.optimizer = self._make_adam()
         self._train_path = None
 
-    # ---- schedules -----------------------------------------------------------------------------
-    def linear_eps(self, total_timesteps):
-        """agent.py:176-183."""
-        progress = self.current_timestep / total_timesteps
-        if progress < self.exploration_fraction:
-            r = progress / self.exploration_fraction
-            return self.initial_eps + r * (self.final_eps - self.initial_eps)
-        return self.final_eps
-
-    def adjust_cvar(self, state):
-        """agent.py:249-267: cvar = min(1, closest sonar return / 10)."""
-        sonar_points = state[4:]
-        closest_d = np.inf
-        for i in range(0, len(sonar_points), 2):
-            x, y = sonar_points[i], sonar_points[i + 1]
-            if np.abs(x) < 1e-3 and np.abs(y) < 1e-3:
-                continue
-            closest_d = min(closest_d, np.linalg.norm(sonar_points[i:i + 2]))
-        cvar = 1.0
-        if closest_d < 10.0:
-            cvar = closest_d / 10.0
-        return cvar
-
     def adjust_cvar_batch(self, states):
         """Batched adjust_cvar on device: states [n, 26] -> cvar [n]."""
         p = states[:, 4:].view(states.shape[0], -1, 2)
@@ -127,39 +106,6 @@ class IQNAgent:
         return torch.where(closest < 10.0, closest / 10.0, torch.ones_like(closest))
 
     # ---- acting --------------------------------------------------------------------------------
-    def act(self, state, eps, cvar=1.0):
-        """agent.py:186-205, one state (numpy) -> python int."""
-        state = torch.from_numpy(np.asarray(state)).float().unsqueeze(0).to(self.device)
-        self.qnetwork_local.eval()
-        with torch.no_grad():
-            action_values = self.qnetwork_local.get_qvals(state, cvar)
-        self.qnetwork_local.train()
-        if random.random() > eps:
-            return int(np.argmax(action_values.cpu().data.numpy()))
-        return int(random.choice(np.arange(self.action_size)))
-
-    def act_adaptive(self, state, eps):
-        cvar = self.adjust_cvar(state)
-        return self.act(state, eps, cvar), cvar
-
-    def act_eval(self, state, eps=0.0, cvar=1.0):
-        """agent.py:217-236: action + the K quantiles and taus behind it."""
-        state = torch.from_numpy(np.asarray(state)).float().unsqueeze(0).to(self.device)
-        self.qnetwork_local.eval()
-        with torch.no_grad():
-            quantiles, taus = self.qnetwork_local.forward(state, self.qnetwork_local.K, cvar)
-            action_values = quantiles.mean(dim=1)
-        self.qnetwork_local.train()
-        if random.random() > eps:
-            action = int(np.argmax(action_values.cpu().data.numpy()))
-        else:
-            action = int(random.choice(np.arange(self.action_size)))
-        return action, quantiles.cpu().data.numpy(), taus.cpu().data.numpy()
-
-    def act_adaptive_eval(self, state, eps=0.0):
-        cvar = self.adjust_cvar(state)
-        return self.act_eval(state, eps, cvar), cvar
-
     @torch.no_grad()
     def act_eval_batch(self, states, eps=0.0, cvar=1.0, taus=None):
         """Batched act_eval (agent.py:217-236): states [n,26] on the device -> (actions [n] i32, quantiles [n,32,9],
@@ -333,26 +279,36 @@ class IQNAgent:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             snap = [p.detach().clone() for p in self.qnetwork_local.parameters()]
-            opt_snap = None
+            # the optimizer's moment tensors may be views of the fused trainer's flat buffers (one Adam state for both
+            # paths, iqn/fused_train.py) and load_state_dict keeps the tensors it is given: snapshot the VALUES, the
+            # warm-up steps below update them in place
+            import copy
+            opt_snap = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else copy.deepcopy(vv)) for kk, vv in st.items()}
+                        for k, st in state["state"].items()}
             with torch.cuda.stream(side):   # warm-up iterations on a side stream (allocations, lazy init)
                 for _ in range(3):
                     self.optimizer.zero_grad(set_to_none=True)
                     self.compute_loss(self._g_in).backward()
                     torch.nn.utils.clip_grad_norm_(self.qnetwork_local.parameters(), 0.5)
-                    if opt_snap is None:
-                        import copy
-                        opt_snap = copy.deepcopy(self.optimizer.state_dict())
                     self.optimizer.step()
             torch.cuda.current_stream(dev).wait_stream(side)
-            # the warm-up must not count as training: restore weights and optimizer state
+            # the warm-up must not count as training: restore weights and optimizer state (values copied back INTO the
+            # tensors the optimizer holds, so moments shared with the fused trainer stay shared)
             with torch.no_grad():
                 for p_, s_ in zip(self.qnetwork_local.parameters(), snap):
                     p_.copy_(s_)
-            self.optimizer = optim.Adam(self.qnetwork_local.parameters(), lr=self.LR, capturable=True)
-            if state["state"]:
-                self.optimizer.load_state_dict(state)
-                for g_ in self.optimizer.param_groups:
-                    g_["capturable"] = True
+                live = self.optimizer.state_dict()["state"]
+                for k, st in opt_snap.items():
+                    for kk, vv in st.items():
+                        if torch.is_tensor(vv):
+                            live[k][kk].copy_(vv)
+                if not opt_snap:      # the optimizer had no state before the warm-up created it: zero what it made
+                    for st in live.values():
+                        for vv in st.values():
+                            if torch.is_tensor(vv):
+                                vv.zero_()
+            if self._fused is not None and self._fused.owns(self):
+                self._fused._adopt_optimizer_state(self.optimizer)     # re-attach the flat moment buffers to the new optimizer
             self._graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(self._graph):
@@ -365,6 +321,10 @@ class IQNAgent:
         for dst, src in zip(self._g_in, experiences):
             dst.copy_(src)
         self._graph.replay()
+        # a graph replay writes the weights without bumping the parameters' version counters: the act path's cached
+        # weight image (iqn/fused_act.py) has to be told (writes through `.data` / raw pointers need the same call)
+        from .fused_act import weights_changed
+        weights_changed(self.qnetwork_local)
         self.grad_steps += 1
         return self._g_loss
 
@@ -382,70 +342,6 @@ class IQNAgent:
                 return
             for tp, lp in zip(target_model.parameters(), local_model.parameters()):
                 tp.data.copy_(self.TAU * lp.data + (1.0 - self.TAU) * tp.data)
-
-    # ---- reference-shaped single-env loop (drop-in for train_IQN_model.py) -------------------------
-    def learn(self, total_timesteps, train_env, eval_env, eval_config, eval_freq, eval_log_path, verbose=True):
-        """agent.py:94-173 with a gym-shaped single env (the facade MarineNavEnv or the reference's)."""
-        state = train_env.reset()
-        ep_reward, ep_length, ep_num = 0.0, 0, 0
-        while self.current_timestep <= total_timesteps:
-            eps = self.linear_eps(total_timesteps)
-            action = self.act(state, eps)
-            next_state, reward, done, info = train_env.step(action)
-            ep_reward += train_env.discount ** ep_length * reward
-            ep_length += 1
-            self.memory.add(state, action, reward, next_state, done)
-            state = next_state
-            if self.current_timestep >= self.learning_starts:
-                if self.learning_timestep % self.UPDATE_EVERY == 0 and len(self.memory) > self.BATCH_SIZE:
-                    self.train_from_memory()
-                if self.learning_timestep % self.target_update_interval == 0:
-                    self.soft_update(self.qnetwork_local, self.qnetwork_target)
-                if self.learning_timestep % eval_freq == 0 and eval_env is not None:
-                    self.evaluation(eval_env, eval_config=eval_config, eval_log_path=eval_log_path)
-                    self.evaluation(eval_env, eval_config=eval_config, greedy=False, eval_log_path=eval_log_path)
-                    if eval_log_path is not None:
-                        self.qnetwork_local.save(eval_log_path)
-                self.learning_timestep += 1
-            if done:
-                ep_num += 1
-                if verbose:
-                    print("======== training info ========")
-                    print("current ep_length: ", ep_length)
-                    print("current ep_reward: ", ep_reward)
-                    print("current ep_result: ", info["state"])
-                    print("episodes_num: ", ep_num)
-                    print("exploration_rate: ", eps)
-                    print("current_timesteps: ", self.current_timestep)
-                    print("total_timesteps: ", total_timesteps)
-                    print("======== training info ========\n")
-                ep_reward, ep_length = 0.0, 0
-                state = train_env.reset()
-            self.current_timestep += 1
-
-    def evaluation(self, eval_env, eval_config, greedy=True, eval_log_path=None):
-        """agent.py:319-398 with a gym-shaped single env."""
-        action_data, reward_data, success_data, time_data, energy_data = [], [], [], [], []
-        for idx, config in enumerate(eval_config.values()):
-            observation = eval_env.reset_with_eval_config(config)
-            actions, cumulative_reward, length, energy, done = [], 0.0, 0, 0.0, False
-            info = {"state": "normal"}
-            while not done and length < 1000:
-                if greedy:
-                    action = self.act(observation, eps=0.0)
-                else:
-                    action, _ = self.act_adaptive(observation, eps=0.0)
-                observation, reward, done, info = eval_env.step(action)
-                cumulative_reward += eval_env.discount ** length * reward
-                length += 1
-                energy += eval_env.robot.compute_action_energy_cost(int(action))
-                actions.append(int(action))
-            action_data.append(actions)
-            reward_data.append(cumulative_reward)
-            success_data.append(info["state"] == "reach goal")
-            time_data.append(eval_env.robot.dt * eval_env.robot.N * length)
-            energy_data.append(energy)
-        self._log_evaluation(greedy, action_data, reward_data, success_data, time_data, energy_data, eval_log_path)
 
     # ---- batched loop on the HIP vector env ----------------------------------------------------------
     def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,

@@ -301,6 +301,8 @@ class MarineNavEnv(_Base):
         self._push()
         self._venv.set_attrs(N=r["N"], dt=r["dt"], max_speed=r["max_speed"], robot_r=r["r"], a=r["a"], w=r["w"],
                              sonar_range=r["sonar"]["range"], sonar_angle=r["sonar"]["angle"])
+        if int(r["N"]) > 64:      # robot._N was written directly above: grow the sub-step trajectory buffer like the N setter
+            self._venv.enable_trajectory(int(r["N"]))
         self._venv.load_worlds([VecMarineNavEnv.world_from_eval_config(eval_config)])
         self._pull_world()
         self.robot.action_history.clear(); self.robot.trajectory.clear()

@@ -98,9 +98,11 @@ def plan_cadence(total_timesteps, eval_freq, n_envs_total, batch, ref_batch=32, 
 
 
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
-              grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0):
+              grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0, precision="f64"):
     """train_IQN_model.py:74-121 on the vector env.  `params` is one trial of the reference's config grid
-    (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps."""
+    (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps.
+    `precision`: the env kernels' arithmetic.  "f64" (default: every float32 output within 1e-5 of the reference, no
+    outliers; measured free while an IQN acts in the loop) or "mixed" (float32 field / sonar decisions)."""
     import torch
     from .iqn.agent import IQNAgent
     from .marinenav_env.vec_env import VecMarineNavEnv
@@ -129,12 +131,12 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
                   f"grad steps; evaluation every {plan['eval_every_vector_steps']} vector steps")
 
     train_env = VecMarineNavEnv(n_envs, seed=params["seed"], first_index=rank * n_envs, schedule=TRAINING_SCHEDULE,
-                                timestep_scale=plan["timestep_scale"], device=device)
+                                timestep_scale=plan["timestep_scale"], device=device, precision=precision)
     eval_config = create_eval_configs(device)
     if writer:
         with open(os.path.join(exp_dir, "eval_config.json"), "w+") as f:
             json.dump(eval_config, f)
-    eval_env = VecMarineNavEnv(len(eval_config), device=device) if writer else None
+    eval_env = VecMarineNavEnv(len(eval_config), device=device, precision=precision) if writer else None
 
     agent = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
                      seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
@@ -171,6 +173,8 @@ def main(argv=None):
     ap.add_argument("--n-evals", type=int, default=None, help="evaluation points over the run (default: min(30, total_timesteps / eval_freq))")
     ap.add_argument("--cvar", type=float, default=1.0, help="CVaR level of the acting policy while training (configs[4]: 0.5)")
     ap.add_argument("--torch-train", action="store_true", help="gradient step through PyTorch instead of the fused HIP kernels")
+    ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
+                    help="env kernels: f64 (default; strict 1e-5 parity, free next to the IQN act kernel) or mixed")
     args = ap.parse_args(argv)
     params = json.load(args.config_file)
     import torch
@@ -186,7 +190,7 @@ def main(argv=None):
         p["training_time"] = stamp
         run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay,
                   grad_steps=args.grad_steps, torch_train=args.torch_train, total_grad_steps=args.total_grad_steps,
-                  n_evals=args.n_evals, cvar=args.cvar)
+                  n_evals=args.n_evals, cvar=args.cvar, precision=args.precision)
     if world > 1:
         dist.destroy_process_group()
 

@@ -226,6 +226,31 @@ def test_g3_single_step_golden(torch, precision, atol, rtol, lanes):
     env.close()
 
 
+def test_loop_default_precision_is_strict_1e5_with_zero_outliers(torch):
+    """The precision the training loop runs by default (bench.py with a learner, train_iqn, smoke): float64 env kernels,
+    float32 outputs as the IQN consumes them.  North-star tolerance on the reference's 2048 single steps (G3): every
+    float32 output (observation, reward) within 1e-5 ABSOLUTE, done / info identical -- no forgiveness clause."""
+    import inspect
+    import bench
+    from distributional_rl_navigation_amd import train_iqn
+    assert inspect.signature(train_iqn.run_trial).parameters["precision"].default == "f64"
+    assert bench.default_precision(learner=True) == "f64" and bench.default_precision(learner=False) == "mixed"
+    z = np.load(os.path.join(G, "g3_single_step.npz"))
+    n = len(z["action"])
+    env = make_env(n, bench.default_precision(learner=True))
+    _load_g3(env, z, 0, n)
+    env.step(torch.from_numpy(z["action"].astype(np.int32)).to(env.device))
+    obs32 = env.obs.cpu().numpy()
+    assert obs32.dtype == np.float32
+    assert np.array_equal(env.done.cpu().numpy().astype(bool), z["done"]) and np.array_equal(env.info.cpu().numpy(), z["info"])
+    assert np.array_equal(_miss(obs32.astype(np.float64)), _miss(z["obs"]))
+    err = np.abs(obs32.astype(np.float64) - z["obs"])
+    assert int((err > 1e-5).sum()) == 0, (int((err > 1e-5).sum()), err.max())
+    assert np.abs(env.reward.cpu().numpy().astype(np.float64) - z["reward"]).max() <= 1e-5
+    np.testing.assert_allclose(env.get_state()[0], z["state_out"], rtol=0, atol=1e-9)
+    env.close()
+
+
 def test_g4_sonar_edge_cases_on_device(torch):
     z = np.load(os.path.join(G, "g4_sonar_edge.npz"))
     n = len(z["names"])
