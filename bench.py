@@ -45,6 +45,13 @@ PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "act": 24.8e6, "act_
 APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
 
+def default_precision(learner):
+    """Env-kernel arithmetic when --precision is not given: the strict float64 kernels whenever an IQN is in the loop (every
+    float32 output within 1e-5 of the reference with no outliers; measured free next to the act kernel), the mixed-precision
+    kernels (SURVEY 8d's float32-SoA design point) for the kernel-only configs."""
+    return "f64" if learner else "mixed"
+
+
 def cpu_baseline(n_steps, world):
     """Scalar float64 oracle (oracle/marinenav_oracle.c), one host thread, resets included."""
     import numpy as np
@@ -81,6 +88,128 @@ def cpu_baseline_all_cores(n_steps_each, world, threads):
     return threads * n_steps_each / dt, dt
 
 
+def _timed(device, fn, steps, warmup, state, before_timed=None):
+    """W untimed + K timed calls of fn(state) -> state, bracketed by device synchronisation.  Returns (seconds, state)."""
+    import torch
+    for _ in range(warmup):
+        state = fn(state)
+    torch.cuda.synchronize(device)
+    if before_timed is not None:
+        before_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        state = fn(state)
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - t0, state
+
+
+def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
+    """The other configurations the README / DESIGN quote, timed by the same run so that they are driver-timed numbers too:
+      act_exact_f32      the main loop with the exact-f32 MFMA act kernel (variant 0) instead of the split-f16 one
+      train_cadence      the cadence that trains (train_iqn's default): 16 gradient steps per vector step, eps 0.05
+      config1            BASELINE configs[1]: 4 096 envs, random policy, step kernel only -- one launch pair per vector step, and
+                         mn_rollout with T = 100 steps per launch
+      shared_learner_ws1 learner alone (batch drawn in the launch), without and with a single-rank RCCL group (all-reduce executed)
+    Same synthetic worlds, same agent (its replay ring is full by now)."""
+    import torch
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    n = env.n_envs
+    out = {}
+    ctx = act_context(agent.qnetwork_local)
+
+    def loop_step(o, eps=None, cvar=args.cvar):
+        e = agent.linear_eps(total_timesteps) if eps is None else eps
+        return agent.vec_step(env, o, e, cvar, per_iter=n)[0]
+
+    # (a) exact-f32 act kernel
+    steps, warm = max(20, args.steps // 2), 10
+    ctx.set_variant(0)
+    dt, obs = _timed(device, loop_step, steps, warm, obs, lambda: ctx.profile_begin(min(steps, 50)))
+    act_ms, _ = ctx.profile_end()
+    ctx.set_variant(args.act_variant)
+    alg_tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12 if act_ms > 0 else None
+    out["act_exact_f32"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                            "act_kernel": "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "act_launch_ms": act_ms,
+                            "roofline_frac_f32_mfma": alg_tf / F32_MFMA_PEAK_TFLOPS if alg_tf else None}
+    # (b) the cadence that trains
+    ue, gs = agent.UPDATE_EVERY, agent.grad_steps_per_update
+    agent.UPDATE_EVERY, agent.grad_steps_per_update = 1, 16
+    g0 = agent.grad_steps
+    steps = max(20, args.steps // 2)
+    dt, obs = _timed(device, lambda o: agent.vec_step(env, o, 0.05, args.cvar, train_every=1, per_iter=n)[0], steps, 10, obs)
+    # _timed's warm-up steps train too: count the timed ones only
+    out["train_cadence"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                            "grad_steps_per_vector_step": 16, "eps": 0.05,
+                            "grad_steps_per_sec": 16 * steps / dt, "grad_steps_counted": agent.grad_steps - g0 - 16 * 10}
+    agent.UPDATE_EVERY, agent.grad_steps_per_update = ue, gs
+    # (c) configs[1]
+    n1 = 4096
+    e1 = VecMarineNavEnv(n1, seed=0, device=device, precision="mixed")
+    e1.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis={4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0))
+    e1.reset()
+    gen = torch.Generator(device=device); gen.manual_seed(0)
+    bytes_step = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
+
+    def pair(_):
+        e1.step(torch.randint(0, 9, (n1,), device=device, dtype=torch.int32, generator=gen))
+        return e1.reset_done()
+    dt, _ = _timed(device, pair, 1000, 100, None, lambda: e1.profile_begin(50))
+    k_ms, _ = e1.profile_end()
+    single = {"value": n1 * 1000 / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / 1000, "steps": 1000,
+              "step_kernel_ms": k_ms, "hbm_frac_406B": bytes_step * n1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+              "hbm_frac_406B_wall": bytes_step * n1 * 1000 / dt / 1e9 / HBM_PEAK_GBS}
+    T, ctr = 100, [0]
+
+    def roll_launch(_):
+        e1.rollout(T, action_seed=0, first_step=ctr[0], trace=("obs", "reward", "done"))
+        ctr[0] += T
+    dt, _ = _timed(device, roll_launch, 10, 2, None, lambda: e1.profile_begin(10))
+    k_ms, _ = e1.profile_end()
+    rollout = {"value": n1 * T * 10 / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / (T * 10), "steps": T * 10, "steps_per_launch": T,
+               "launch_ms": k_ms, "hbm_frac_406B": bytes_step * n1 * T / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
+    e1.close()
+    out["config1"] = {"envs": n1, "precision": "mixed", "single_launch_pair": single, "mn_rollout": rollout}
+    # (d) learner alone, without / with a single-rank RCCL group
+    def learner_rate(reps=400):
+        for _ in range(10):
+            agent.train_from_memory()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            agent.train_from_memory()
+        torch.cuda.synchronize(device)
+        return reps / (time.perf_counter() - t0)
+    sl = {}
+    was = agent.distributed
+    agent.distributed = False
+    sl["no_group"] = learner_rate()
+    made = False
+    try:
+        if not dist_up:
+            import socket
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+            made = True
+        agent.distributed = True
+        sl["nccl_ws1_allreduce"] = learner_rate()
+        sl["allreduce_overhead_us_per_step"] = 1e6 * (1.0 / sl["nccl_ws1_allreduce"] - 1.0 / sl["no_group"])
+    except Exception as e:      # the line must still come out if RCCL cannot initialise on this box
+        sl["nccl_ws1_error"] = repr(e)
+    finally:
+        agent.distributed = was
+        if made:
+            torch.cuda.synchronize(device)
+            dist.destroy_process_group()
+    sl["unit"] = "grad-steps/s (batch %d, drawn in the launch)" % agent.BATCH_SIZE
+    out["shared_learner_ws1"] = sl
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,11 +240,16 @@ def main():
                     help="with --no-learner: T vector steps per launch through mn_rollout (in-kernel random actions and resets); "
                          "--steps must be a multiple of T.  0 = one mn_step + mn_reset_done launch pair per vector step")
     ap.add_argument("--rollout-trace", default="obs,reward,done", help="per-step outputs mn_rollout writes ([T][n] traces), comma separated")
-    ap.add_argument("--precision", default="mixed", choices=["mixed", "f64"],
-                    help="env kernels: mixed (default; float32 field / sonar decisions, 1e-5 on float32 outputs) or f64 (everything float64, 1e-9)")
+    ap.add_argument("--precision", default=None, choices=["mixed", "f64"],
+                    help="env kernels: f64 (everything float64, 1e-9; default when an IQN is in the loop) or mixed (float32 field / sonar "
+                         "decisions; default with --no-learner)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra driver-timed legs (`also`: exact-f32 act kernel, training "
+                                                            "cadence, configs[1], single-rank RCCL learner) after the main timed region")
     ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2, 3), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout, 3 = split-f16 on 32x32x16 tiles")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     args = ap.parse_args()
+    if args.precision is None:
+        args.precision = default_precision(learner=not args.no_learner)
 
     import torch
     import torch.distributed as dist
@@ -217,6 +351,10 @@ def main():
             step_ctr[0] += roll
         return env.obs
 
+    fused = agent is not None and agent.use_fused_act
+    if fused:      # before the warm-up: the first timed launch must not contain the weight-image pack of a freshly selected kernel
+        from distributional_rl_navigation_amd.iqn.fused_act import act_context
+        act_context(agent.qnetwork_local).set_variant(args.act_variant)
     obs = run_steps(args.warmup, obs)
     g0 = agent.grad_steps if agent else 0
     fence()
@@ -227,10 +365,7 @@ def main():
     env.profile_begin(n_prof)
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
-    fused = agent is not None and agent.use_fused_act
     if fused:
-        from distributional_rl_navigation_amd.iqn.fused_act import act_context
-        act_context(agent.qnetwork_local).set_variant(args.act_variant)
         act_context(agent.qnetwork_local).profile_begin(n_prof)
     t0 = time.perf_counter()
     obs = run_steps(args.steps, obs)
@@ -268,6 +403,10 @@ def main():
             learner_only[mode] = reps / (time.perf_counter() - t1)
         agent.use_fused_train = was_fused
 
+    also = {}
+    if world == 1 and not args.no_also and agent is not None and fused and not roll and not args.torch_train and not args.torch_act:
+        also = also_legs(args, env, agent, obs, device, total_timesteps, use_dist)
+
     if rank == 0:
         env_steps = n * world * args.steps
         bytes_step = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
@@ -292,7 +431,8 @@ def main():
             "dtype_detail": ("IQN act: f32 results from split-f16 MFMA (hi/lo f16 pieces, 3 products per f32 product; error vs float64 equal to the "
                              "exact-f32 kernel's, tests/test_act_split_gpu.py), IQN train: f32 (exact-f32 MFMA); env kernels: " if args.act_variant == 2 else
                              "IQN act / train: f32 (exact-f32 MFMA); env kernels: ") + ("f64 pose integration + f64 sonar geometry, f32 field and sonar decisions"
-                                                                                      if args.precision == "mixed" else "f64 throughout"),
+                                                                                      if args.precision == "mixed" else "float64 throughout (strict: every float32 output within 1e-5 of the reference, zero outliers; "
+                                                                                      "tests/test_env_gpu.py::test_loop_default_precision_is_strict_1e5_with_zero_outliers)"),
             "data": "synthetic (seeded random worlds, random-init IQN)",
             "act_kernel_variant": args.act_variant,
             "config": {
@@ -314,6 +454,8 @@ def main():
             },
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
+            # further configurations timed by THIS run, after the main timed region (N = 1 only): see also_legs()
+            "also": also,
             "roofline_env_step": {
                 "precision": args.precision,
                 "kernel": "mn_rollout_kernel<float,false,L>" if roll else ("mn_step_kernel<float,false,L,APPEND=true> (step + replay append)" if fused_append else "mn_step_kernel<float,false,L>"),
@@ -323,9 +465,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
-                           (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n, args.cores, args.obstacles) == (65536, 8, 10) else None),
-                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch), profiles/r02_full_loop_kernel_stats_split_act.txt / r02_configs1_rollout.txt; not live",
+                "traffic": None,      # not counted live
+                "traffic_from_profile": {"bytes_per_launch": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
+                                         (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n, args.cores, args.obstacles, args.precision) == (65536, 8, 10, "mixed") else None),
+                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch), mixed-precision kernels: profiles/r02_full_loop_kernel_stats_split_act.txt / r02_configs1_rollout.txt"},
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "algorithmic_bytes_step_only": bytes_step,
                 "frac_step_bytes_only": (bytes_step * per_launch / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_kernel_ms > 0 else None,
@@ -351,9 +494,13 @@ def main():
             out["roofline"] = {   # dominant kernel of this workload (~85 % of GPU time): the fused IQN act kernel
                 "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak,
                 "unit": "TFLOP/s", "frac": tf / peak,
-                "traffic": PMC_TRAFFIC_BYTES["act_split" if args.act_variant in (2, 3) else "act"] if n == 65536 else None,
-                "traffic_source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch: observations + taus in, actions out), "
-                                  + ("profiles/r02_full_loop_kernel_stats_split_act.txt" if args.act_variant in (2, 3) else "profiles/r01_full_loop_kernel_stats.txt") + "; not live",
+                # `frac` counts the matrix FLOPs the kernel ISSUES (split-f16: 3 products per float32 product + K padding);
+                # `frac_algorithmic` is SURVEY 8d's figure: the network's 2 002 944 FLOP per env-step over the same peak
+                "frac_algorithmic": alg_tf / peak,
+                "traffic": None,      # HBM bytes are not counted live; the rocprofv3 PMC figure of the same kernel is next to it
+                "traffic_from_profile": {"bytes_per_launch": PMC_TRAFFIC_BYTES["act_split" if args.act_variant in (2, 3) else "act"] if n == 65536 else None,
+                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch: observations + taus in, actions out), "
+                                                   + ("profiles/r02_full_loop_kernel_stats_split_act.txt" if args.act_variant in (2, 3) else "profiles/r01_full_loop_kernel_stats.txt")},
                 "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else (198 * 32768 if args.act_variant == 3 else ACT_FLOP_PER_ENV_STEP),
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
                 "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,

@@ -88,8 +88,9 @@ SIGNATURES = [
     ("mn_iqn_train_workspace_floats", C.c_int64, [_i32]),
     ("mn_iqn_sample", C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     ("mn_iqn_train_grad", C.c_int, [_vp] * 13 + [_i32, _i32, C.c_float, _vp]),
-    ("mn_iqn_train_grad_sampled", C.c_int, [_vp] * 5 + [_i64] + [_vp] * 8 + [_i32, _i32, C.c_float, _vp]),
-    ("mn_iqn_train_adam", C.c_int, [_vp] * 6 + [_i32] + [C.c_double] * 5 + [_vp]),
+    ("mn_iqn_train_grad_sampled", C.c_int, [_vp] * 5 + [_i64] + [_vp] * 8 + [_i32, _i32, C.c_float, _i32, _vp]),
+    ("mn_iqn_train_adam", C.c_int, [_vp] * 6 + [_i32] + [C.c_double] * 5 + [C.c_float, _i32, _vp]),
+    ("mn_iqn_train_set_mode", C.c_int, [_i32]),
     ("mn_iqn_profile_begin", C.c_int, [_vp, _i32]),
     ("mn_iqn_profile_end", C.c_int, [_vp, _vp, _pd, _pi32]),
 ]

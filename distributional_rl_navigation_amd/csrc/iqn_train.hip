@@ -1,5 +1,5 @@
 // iqn_train.hip -- fused IQN gradient step for gfx950 (MI355X): forward of the target and the local network,
-// quantile-Huber TD loss, backward, gradient-norm clip and Adam in four kernels.
+// quantile-Huber TD loss, backward, gradient-norm clip and Adam in three launches.
 //
 // Replaces, for one optimizer step of IQNAgent.train (thirdparty/IQN/agent.py:269-304) on a batch drawn from the
 // device replay ring:
@@ -13,15 +13,24 @@
 // Hadamard product, three more linear layers).
 //
 // Why kernels: in PyTorch the step is ~150 tiny dependent kernels (forward x2, autograd, clip, Adam); even replayed
-// from a hipGraph it takes ~540 us, all launch latency -- the arithmetic is 0.5 GFLOP.  Here
-//   iqn_train_fwdbwd  one 512-thread workgroup per 2 batch elements (= 16 (sample, tau) rows = one MFMA M-tile):
-//                     gathers its transitions from the ring, runs the target forward on four waves and the local
-//                     forward on the other four at the same time, then the loss gradient and the whole backward
-//                     out of LDS on all eight, and writes its partial parameter gradient [35 785] to HBM;
-//   iqn_grad_reduce   sums the partials in a fixed order (deterministic, no float atomics) -> flat gradient, loss;
-//   iqn_sumsq         per-block sums of squares of the (possibly all-reduced) gradient, advances the step counter;
-//   iqn_adam          global norm, clip coefficient, Adam update (torch.optim.Adam arithmetic), one flat pass.
-// Between the last two the caller may all-reduce the flat gradient (shared learner over RCCL).
+// from a hipGraph it takes ~540 us, all launch latency -- the arithmetic is 0.5 GFLOP.  Here (round 3 structure):
+//   iqn_train_fwdbwd  2 x (batch / 2) workgroups of 512 threads, one per CU, in TWO ROLES.  Workgroups [0, batch/2) are
+//                     TARGET workgroups: each runs the target network on the next_states of 2 batch elements (16 (sample,
+//                     tau) rows = one MFMA M tile) and publishes the 16 TD targets as self-tagged 8-byte granules.
+//                     Workgroups [batch/2, batch) are LOCAL workgroups: local network forward on the states of the same 2
+//                     elements on all eight waves, pick up the 16 TD targets (they are ready by then: both roles run the
+//                     same forward at the same time on different CUs), loss gradient, the whole backward out of LDS, partial
+//                     parameter gradient [35 785] to HBM.  The batch's ring rows come from a keyed pseudo-random PERMUTATION
+//                     of [0, ring_size) (slot k -> row perm(k): distinct by construction, O(1) per slot), so no workgroup
+//                     has to look at another slot's draw.  Every weight operand of the forward, and the two transposed ones
+//                     of the backward, is requested into registers before the first barrier: the phases of the chain no
+//                     longer start with an L2 round trip.
+//   iqn_grad_reduce   sums the partials in a fixed order (deterministic, no float atomics), all loads of a thread in flight
+//                     at once -> flat gradient, loss, per-block sums of squares of the reduced gradient;
+//   iqn_adam          global norm (from the block sums, or -- after an all-reduce rewrote the gradient -- recomputed by every
+//                     block in one fixed order), clip coefficient, Adam update (torch.optim.Adam arithmetic), one flat pass.
+// Between the last two the caller may all-reduce the flat gradient (shared learner over RCCL); the 1 / world_size average
+// is folded into iqn_adam (`grad_scale`).
 //
 // MFMA mapping: exact-f32 v_mfma_f32_16x16x4_f32 throughout (the reference trains in float32).  Every product is a
 // 16x16 output tile accumulated over K in blocks of 16: lane l = (i = l & 15, g = l >> 4) feeds A[i][k] and B[k][i]
@@ -41,6 +50,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;   // global, for agent-scope (sc1) granule accesses
 
 constexpr int OBS = MN_OBS_DIM;  // 26
 constexpr int F = 208;           // feature width 16 + 16 + 176
@@ -53,9 +63,10 @@ constexpr int ROWS = BE * NQ;    // 16 = one MFMA M tile
 // flat parameter vector = ObsEncoder.named_parameters() order (model.py:120-136)
 constexpr int O_VW = 0, O_VB = 32, O_GW = 48, O_GB = 80, O_SW = 96, O_SB = 3968, O_W1 = 4144, O_B1 = 17456,
               O_W2 = 17664, O_B2 = 30976, O_W3 = 31040, O_B3 = 35136, O_W4 = 35200, O_B4 = 35776, P_TOTAL = 35785;
+constexpr int P_PAD = 35788;     // row stride of the per-workgroup partial gradients: 16-byte aligned rows
 constexpr int LDC = 68;          // row stride of the 64-wide LDS activations (16-byte aligned rows, bank skew)
 constexpr int LDF = 212;         // row stride of the 208-wide LDS activations
-// LDS layout (floats); every 2-D block starts 16-byte aligned.  Local-network pass (kept for the backward):
+// LDS layout (floats); every 2-D block starts 16-byte aligned.  Forward pass (kept for the backward in a local workgroup):
 constexpr int S_C = 0;                       // [16][LDC]  cos features
 constexpr int S_H1 = S_C + ROWS * LDC;       // [16][LDF]  relu(cos W1^T + b1)
 constexpr int S_X = S_H1 + ROWS * LDF;       // [16][LDF]  h1 * features
@@ -66,53 +77,83 @@ constexpr int S_DH2 = S_H3 + ROWS * LDC;     // [16][LDC]
 constexpr int S_DH3 = S_DH2 + ROWS * LDC;    // [16][LDC]
 constexpr int S_FEAT = S_DH3 + ROWS * LDC;   // [2][208]   encoder outputs
 constexpr int S_DF = S_FEAT + BE * F;        // [2][208]   dL/dfeatures
-constexpr int S_OBS = S_DF + BE * F;         // [2 which][2][28]  states / next_states
-constexpr int S_Q = S_OBS + 2 * BE * 28;     // [16][12]   quantile values
+constexpr int S_OBS = S_DF + BE * F;         // [2][28]    states (local role) / next_states (target role)
+constexpr int S_Q = S_OBS + BE * 28;         // [16][12]   quantile values
 constexpr int S_QT = S_Q + ROWS * 12;        // [16] TD targets
 constexpr int S_G = S_QT + ROWS;             // [16] dL/dQ_expected
-constexpr int S_TAU = S_G + ROWS;            // [2][16]    0: target taus, 1: local taus
-constexpr int S_MISC = S_TAU + 2 * ROWS;     // rew[2], done[2], loss terms[16]
-// target-network pass (runs concurrently on the other four waves; nothing of it is kept but q)
-constexpr int T_C = (S_MISC + 2 * BE + ROWS + 3) / 4 * 4;
+constexpr int S_TAU = S_G + ROWS;            // [16] this role's taus
+constexpr int S_MISC = S_TAU + ROWS;         // rew[2], done[2], loss terms[16]
+constexpr int S_LOCAL = (S_MISC + 2 * BE + ROWS + 3) / 4 * 4;
+// second set of forward buffers: only used when a local workgroup has to run the target forward itself (mode 1, or the
+// TD targets of its target workgroup did not arrive in time); the local pass's activations must survive for the backward
+constexpr int T_C = S_LOCAL;
 constexpr int T_X = T_C + ROWS * LDC;
 constexpr int T_H2 = T_X + ROWS * LDF;
 constexpr int T_H3 = T_H2 + ROWS * LDC;
 constexpr int T_FEAT = T_H3 + ROWS * LDC;
-constexpr int T_Q = T_FEAT + BE * F;
-constexpr int S_TOTAL = T_Q + ROWS * 12;
+constexpr int T_OBS = T_FEAT + BE * F;
+constexpr int T_Q = T_OBS + BE * 28;
+constexpr int T_TAU = T_Q + ROWS * 12;
+constexpr int S_TOTAL = T_TAU + ROWS;
 constexpr int LDS_BYTES = S_TOTAL * 4;
 constexpr int THREADS = 512;
+constexpr int NT1 = F / 16;      // 13 column tiles of layer 1
 
 struct PassBufs { float *c, *h1, *x, *h2, *h3, *feat, *q; };
 
-// One 16x16 output tile of C = A . B over K (a multiple of 16; compile-time so that every operand load of the tile is
-// issued before the first MFMA), accumulated into `acc`.
-//   AK: A element (m, k) lives at A[m * lda + k] (k contiguous, 16-byte aligned rows);  else at A[k * lda + m].
-//   BK: B element (k, n) lives at B[n * ldb + k] (k contiguous);                         else at B[k * ldb + n].
-// Rows n >= n_valid of a k-contiguous B are read as zeros (the 9-row output layer).
-template <bool AK, bool BK, int K>
-__device__ __forceinline__ f32x4 tile_gemm(const float *A, int lda, const float *B, int ldb, f32x4 acc, int n_valid = 16) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
-    constexpr int NB = K / 16;
-    float a[NB][4], b[NB][4];
+// Phase stamps of ONE target and ONE local workgroup (100 MHz wall clock), only in the profiling build
+// (-DMN_TRAIN_PHASES: scripts/train_phase_timing.py compiles its own copy of this file; the shipped library has no stamps).
+#ifdef MN_TRAIN_PHASES
+__device__ unsigned long long g_phase[2][32];
+__device__ unsigned long long g_phase2[2][2][8];      // [reduce, adam][block 0, a middle block][stamp]
+#define PH2(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) g_phase2[kern][blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
+#define PH(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_phase[blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
+#else
+#define PH(k) do { } while (0)
+#define PH2(kern, k) do { } while (0)
+#endif
+
+// ---- MFMA tile primitives --------------------------------------------------------------------------------------------
+// B operand of a 16x16 tile over K = 16 * NB, element (k, n), requested into registers (the loads are issued here; nothing waits).
+//   k-contiguous (nn.Linear weight used as W^T in the forward: element (k, n) at W[n * ldb + k]): one 16-byte load per block.
+template <int NB>
+__device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const float *__restrict__ W, int ldb, int row = -1) {
+    const int lane = threadIdx.x & 63, i = row < 0 ? lane & 15 : row, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
-        const int kb = kk * 16 + 4 * g;
-        if (AK) {
-            const float4 v = *reinterpret_cast<const float4 *>(A + i * lda + kb);
-            a[kk][0] = v.x; a[kk][1] = v.y; a[kk][2] = v.z; a[kk][3] = v.w;
-        } else {
+        const float4 v = *reinterpret_cast<const float4 *>(W + i * ldb + kk * 16 + 4 * g);
+        b[kk][0] = v.x; b[kk][1] = v.y; b[kk][2] = v.z; b[kk][3] = v.w;
+    }
+}
+//   the same, or -- when `real` is false -- NB requests of the one 16-byte word at `dummy` (a wave that has no such tile)
+template <int NB>
+__device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const float *__restrict__ W, int ldb, bool real,
+                                                  const float *__restrict__ dummy) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[kk][s] = A[(kb + s) * lda + i];
-        }
-        if (BK) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n_valid) v = *reinterpret_cast<const float4 *>(B + i * ldb + kb);
-            b[kk][0] = v.x; b[kk][1] = v.y; b[kk][2] = v.z; b[kk][3] = v.w;
-        } else {
+    for (int kk = 0; kk < NB; ++kk) {
+        const float4 v = *reinterpret_cast<const float4 *>(real ? W + i * ldb + kk * 16 + 4 * g : dummy);
+        b[kk][0] = v.x; b[kk][1] = v.y; b[kk][2] = v.z; b[kk][3] = v.w;
+    }
+}
+//   k-strided (the same weight used untransposed in the backward: element (k, n) at W[k * ldb + n]): four scalar loads per block.
+template <int NB>
+__device__ __forceinline__ void load_b_kstrided(float (&b)[NB][4], const float *__restrict__ W, int ldb) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) b[kk][s] = B[(kb + s) * ldb + i];
-        }
+    for (int kk = 0; kk < NB; ++kk)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[kk][s] = W[(kk * 16 + 4 * g + s) * ldb + i];
+}
+// acc += A . B with A (rows x k, k contiguous, 16-byte aligned rows) in LDS and B in registers.
+template <int NB>
+__device__ __forceinline__ f32x4 mma_a_lds(const float *A, int lda, const float (&b)[NB][4], f32x4 acc) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float a[NB][4];
+#pragma unroll
+    for (int kk = 0; kk < NB; ++kk) {
+        const float4 v = *reinterpret_cast<const float4 *>(A + i * lda + kk * 16 + 4 * g);
+        a[kk][0] = v.x; a[kk][1] = v.y; a[kk][2] = v.z; a[kk][3] = v.w;
     }
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk)
@@ -120,11 +161,47 @@ __device__ __forceinline__ f32x4 tile_gemm(const float *A, int lda, const float 
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][s], b[kk][s], acc, 0, 0, 0);
     return acc;
 }
+// NT tiles of C = A^T . B over the workgroup's 16 rows that share ONE A tile (16 columns of A) and take B column tiles
+// nk0, nk0 + step, ...: every LDS operand of the wave is requested before the first MFMA, every MFMA issued before the first
+// store (one tile at a time -- read, 4 MFMAs, store -- is a 750-cycle latency chain per tile).  Tiles beyond nk_end are computed
+// on a clamped copy and not stored.  st(nk, acc): acc[r] = C[4 g + r][i] of tile nk.
+template <int NT, typename Store>
+__device__ __forceinline__ void rows_gemm_fixed_a(const float *A, int lda, const float *B, int ldb, int nk0, int step, int nk_end,
+                                                  Store st) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float a[4], b[NT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = A[(4 * g + s) * lda + i];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nk = min(nk0 + j * step, nk_end - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[j][s] = B[(4 * g + s) * ldb + nk * 16 + i];
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[j][s], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nk = nk0 + j * step;
+        if (nk < nk_end) st(nk, acc[j]);
+    }
+}
 
+// ---- the batch draw ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser (Steele, Lea, Flood 2014)
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
     x ^= x >> 27; x *= 0x94D049BB133111EBull;
     return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // murmur3 finaliser
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    return x ^ (x >> 16);
 }
 
 constexpr int MAX_BATCH = 1024;
@@ -136,276 +213,497 @@ __device__ __forceinline__ float sample_tau(uint64_t base, int e) {
     const uint64_t x = mix64(base ^ (0xD1B54A32D192ED03ull * (uint64_t)(e + 1)));
     return (float)(x >> 40) * (1.0f / 16777216.0f);
 }
-// The batch's `batch` distinct ring rows into val[] (LDS), by ALL threads of the workgroup (any workgroup size: a slot's draws
-// depend only on the slot and its attempt number, and every round redraws all clashing slots at once).  Every slot draws
-// uniformly from [0, n); a slot whose value is also held by a lower slot redraws, until all are distinct.  A slot only ever
-// rejects values that end up owned by a lower slot, so slot k's value is uniform over what slots < k left: exactly sequential
-// sampling without replacement (replay_buffer.py:42-47, random.sample).
-template <int NTHREADS>
-__device__ __forceinline__ void sample_rows(int *val, int *flag, int64_t n, int batch, uint64_t base) {
-    constexpr int PER = MAX_BATCH / NTHREADS;
-    const int padded = (batch + 3) & ~3;
-    int attempt[PER];
-    for (int k = threadIdx.x, q = 0; k < padded; k += NTHREADS, ++q) {
-        attempt[q] = 0;
-        const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1));
-        val[k] = k < batch ? (int)__umul64hi(x, (uint64_t)n) : -1;
-        flag[k] = 0;
-    }
-    __syncthreads();
-    for (;;) {
-        // does a LOWER slot hold slot k's value?  Two work items per slot, each scanning half of [0, k) four candidates per LDS
-        // read; only the last, partial group needs index masks.  (One item per slot scanning all of [0, k) with masks on every
-        // candidate was 2 us per pass -- VALU-bound -- in every one of the 128 workgroups.)
-        for (int w = threadIdx.x; w < 2 * batch; w += NTHREADS) {
-            const int k = w >> 1, part = w & 1, v = val[k];
-            const int jmax = k & ~3, mid = (jmax >> 1) & ~3;
-            const int lo = part ? mid : 0, hi = part ? jmax : mid;
-            bool c = false;
-            for (int j = lo; j < hi; j += 4) {
-                const int4 q4 = *reinterpret_cast<const int4 *>(&val[j]);
-                c |= (q4.x == v) | (q4.y == v) | (q4.z == v) | (q4.w == v);
-            }
-            if (part) {
-                const int4 q4 = *reinterpret_cast<const int4 *>(&val[jmax]);
-                c |= ((q4.x == v) & (jmax < k)) | ((q4.y == v) & (jmax + 1 < k)) | ((q4.z == v) & (jmax + 2 < k));
-            }
-            if (c) flag[k] = 1;
+// ReplayBuffer.sample (replay_buffer.py:42-47: random.sample(memory, k) = k DISTINCT uniform rows): slot k of the batch reads ring
+// row perm(k), where perm is a pseudo-random permutation of [0, n) keyed by the step's `base` -- a 4-round balanced Feistel network
+// on the smallest even-width power-of-two domain >= n (Luby-Rackoff: three rounds of a good round function already give a
+// pseudo-random permutation), restricted to [0, n) by cycle walking (domain < 4 n: fewer than four evaluations expected).  The
+// first `batch` images of a uniformly random permutation ARE a uniform sample without replacement; distinctness holds by
+// construction, so a slot is O(1) and independent of the others -- every workgroup evaluates just its own two slots (round 2 ran
+// a draw-and-redraw loop over the whole batch in every workgroup: 4-6 us of the kernel).
+__device__ __forceinline__ uint32_t perm_row(uint64_t base, uint32_t n, uint32_t k) {
+    const int bits = n > 1 ? 32 - __builtin_clz(n - 1) : 1;
+    const int half = (bits + 1) >> 1;
+    const uint32_t mask = (1u << half) - 1u;
+    uint32_t rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rk[r] = (uint32_t)(mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(r + 1)) >> 32);
+    uint32_t x = k;
+    do {
+        uint32_t L = x >> half, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t t = L ^ (mix32(R + rk[r]) & mask);
+            L = R;
+            R = t;
         }
-        __syncthreads();
-        int clash = 0;
-        bool redo[PER];
-        for (int k = threadIdx.x, q = 0; k < batch; k += NTHREADS, ++q) {
-            redo[q] = flag[k] != 0;
-            clash |= redo[q];
-        }
-        if (!__syncthreads_or(clash)) break;
-        for (int k = threadIdx.x, q = 0; k < batch; k += NTHREADS, ++q) {
-            if (!redo[q]) continue;
-            ++attempt[q];
-            const uint64_t x = mix64(base + 0xA24BAED4963EE407ull * (uint64_t)(k + 1) + 0x9FB21C651E98DF25ull * (uint64_t)attempt[q]);
-            val[k] = (int)__umul64hi(x, (uint64_t)n);
-            flag[k] = 0;
-        }
-        __syncthreads();
-    }
+        x = (L << half) | R;
+    } while (x >= n);
+    return x;
 }
 
-// model.py:160-186 for the 16 rows of this workgroup, executed by ONE HALF of the workgroup (4 waves; the other half
-// runs the other network at the same time, so every __syncthreads() here is reached by all 512 threads):
-// `obs` [2][28], `tau` [16] in LDS, parameters `P` in HBM/L2.  Leaves cos, (h1,) x, h2, h3, features and q in LDS.
-__device__ __forceinline__ void forward_pass(const PassBufs &Bf, const float *__restrict__ P, const float *obs, const float *tau) {
-    const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-    // encoders: three linear maps, no activation (model.py:170-173)
-    for (int t = tid; t < BE * F; t += 256) {
-        const int be = t / F, o = t - be * F;
-        float acc;
-        if (o < 32) {
-            const int e = o < 16 ? 0 : 1, oo = o - 16 * e;
-            const float *w = P + (e ? O_GW : O_VW) + oo * 2, *in = obs + be * 28 + 2 * e;
-            acc = fmaf(w[1], in[1], fmaf(w[0], in[0], P[(e ? O_GB : O_VB) + oo]));
-        } else {
-            const float *w = P + O_SW + (o - 32) * 22, *in = obs + be * 28 + 4;
-            acc = P[O_SB + o - 32];
+// ---- forward pass ------------------------------------------------------------------------------------------------------
+// Weight operands of one forward pass, per wave (tile assignment: layer 1 tiles {wave, wave + 8}, layers 2 / 3 tile `wave` on
+// waves 0-3, output layer on wave 4), plus this thread's encoder row.
+struct FwdWeights {
+    float w1a[4][4], w1b[4][4];   // cos_embedding tiles wave, wave + 8 (K = 64)
+    float w2[13][4];              // hidden_layer tile (K = 208), waves 0-3
+    float w34[4][4];              // hidden_layer_2 tile (K = 64) on waves 0-3, output_layer (9 of 16 columns) on waves 4-7
+    float enc[22];                // encoder row of feature (tid % 208): 2 (velocity / goal) or 22 (sonar) weights
+    float enc_b, b1a, b1b, b2, b34;
+};
+
+// All loads are unconditional and in one straight line (clamped indices instead of branches): a divergent branch around a load
+// makes hipcc wait for every outstanding load at the join, which would turn the prefetch into a chain of round trips.
+__device__ __forceinline__ void prefetch_forward(FwdWeights &w, const float *__restrict__ P) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
+    {   // encoders: thread t < 416 computes feature o = t % 208 of batch element t / 208 (model.py:170-173); a velocity / goal
+        // feature uses the first two of the 22 values it loads (they stay inside the flat parameter vector)
+        const int o = tid % F;
+        const int e = o < 16 ? 0 : 1, oo = o - 16 * e;
+        const int woff = o < 32 ? (e ? O_GW : O_VW) + oo * 2 : O_SW + (o - 32) * 22;   // even: 8-byte aligned rows
+        const int boff = o < 32 ? (e ? O_GB : O_VB) + oo : O_SB + o - 32;
+        const float2 *row = reinterpret_cast<const float2 *>(P + (tid < BE * F ? woff : 0));      // threads >= 416: one shared line
 #pragma unroll
-            for (int k = 0; k < 22; ++k) acc = fmaf(w[k], in[k], acc);
+        for (int k = 0; k < 11; ++k) {
+            const float2 v = row[k];
+            w.enc[2 * k] = v.x; w.enc[2 * k + 1] = v.y;
         }
-        Bf.feat[t] = acc;
+        w.enc_b = P[boff];
+    }
+    // A wave without such a tile requests ONE 16-byte word instead (every lane the same address: a single cache-line request), so that
+    // the request stream stays branch-free without fetching the tile twice
+    const int t1b = min(wave + 8, NT1 - 1), t23 = wave & 3;
+    const bool has1b = wave + 8 < NT1, l3 = wave < 4;
+    load_b_kcontig<4>(w.w1a, P + O_W1 + wave * 16 * NC, NC);
+    w.b1a = P[O_B1 + wave * 16 + i];
+    load_b_kcontig_if<4>(w.w1b, P + O_W1 + t1b * 16 * NC, NC, has1b, P);
+    w.b1b = P[has1b ? O_B1 + t1b * 16 + i : 0];
+    load_b_kcontig_if<13>(w.w2, P + O_W2 + t23 * 16 * F, F, l3, P);
+    w.b2 = P[l3 ? O_B2 + t23 * 16 + i : 0];
+    // waves 0-3: their hidden_layer_2 tile; waves 4-7: the output layer (9 of 16 columns: columns 9..15 read row 8 again and are
+    // never stored) -- one load sequence, the address selects
+    load_b_kcontig<4>(w.w34, P + (l3 ? O_W3 + t23 * 16 * H : O_W4), H, l3 ? i : min(i, NA - 1));
+    w.b34 = P[l3 ? O_B3 + t23 * 16 + i : O_B4 + min(i, NA - 1)];
+}
+
+// Transposed weight operands of the backward (dh2 = dh3 . W3, dx = dh2 . W2: element (k, n) at W[k * ld + n]), per wave: requested
+// in the middle of the local forward pass, as soon as the 52 registers of the hidden_layer tile are free.
+struct BwdWeights {
+    float w3t[4][4];              // hidden_layer_2 columns of dh2 tile wave & 3 (waves 0-3 use it)
+    float w2ta[4][4], w2tb[4][4]; // hidden_layer columns of dx tiles wave, wave + 8
+};
+__device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const float *__restrict__ PL) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    load_b_kstrided<4>(bw.w3t, PL + O_W3 + (wave & 3) * 16, H);
+    load_b_kstrided<4>(bw.w2ta, PL + O_W2 + wave * 16, F);
+    load_b_kstrided<4>(bw.w2tb, PL + O_W2 + min(wave + 8, NT1 - 1) * 16, F);
+}
+
+// model.py:160-186 for the 16 rows of this workgroup on all eight waves: `obs` [2][28], `tau` [16] in LDS (visible: the caller
+// placed a barrier after writing them).  Leaves cos, (h1,) x, h2, h3, features and q in LDS; ends with a barrier.
+template <bool BWD_PREFETCH>
+__device__ __forceinline__ void forward_pass(const PassBufs &Bf, const FwdWeights &w, const float *obs, const float *tau,
+                                             BwdWeights *bw = nullptr, const float *__restrict__ PL = nullptr, int ph_local = -1) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+    {   // encoders: three linear maps, no activation (model.py:170-173).  Branch-free (a branch here would make hipcc wait for
+        // every outstanding weight request): threads >= 416 compute a copy of batch element 1's feature into a dead LDS slot
+        const int be = min(tid / F, BE - 1), o = tid % F;
+        const bool small = o < 32;
+        const float *in = obs + be * 28 + (o < 16 ? 0 : (small ? 2 : 4));
+        float acc = w.enc_b;
+#pragma unroll
+        for (int k = 0; k < 22; ++k) acc = fmaf(w.enc[k], (k < 2 || !small) ? in[k] : 0.f, acc);
+        float *dst = tid < BE * F ? Bf.feat + tid : Bf.x + tid;      // x is written by layer 1, after the barrier
+        *dst = acc;
     }
     // cos(tau * pi * i), pis = float32(pi * i) (model.py:130,149-155)
-    for (int t = tid; t < ROWS * NC; t += 256) {
-        const int r = t >> 6, c = t & 63;
+#pragma unroll
+    for (int e = 0; e < ROWS * NC / THREADS; ++e) {
+        const int t = tid + THREADS * e, r = t >> 6, c = t & 63;
         Bf.c[r * LDC + c] = cosf(tau[r] * (float)(M_PI * (double)c));
     }
     __syncthreads();
-    // h1 = relu(cos W1^T + b1); x = h1 * features   (13 column tiles over 4 waves)
-    for (int tile = wave; tile < F / 16; tile += 4) {
+    PH(2);   /* encoders + cos done */
+    // h1 = relu(cos W1^T + b1); x = h1 * features   (13 column tiles: waves 0-4 take two, 5-7 one)
+    {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<true, true, NC>(Bf.c, LDC, P + O_W1 + tile * 16 * NC, NC, acc);
-        const int o = tile * 16 + i;
-        const float bias = P[O_B1 + o];
+        acc = mma_a_lds<4>(Bf.c, LDC, w.w1a, acc);
+        const int o = wave * 16 + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * g + r;
-            const float v = fmaxf(acc[r] + bias, 0.f);
+            const float v = fmaxf(acc[r] + w.b1a, 0.f);
+            if (Bf.h1) Bf.h1[row * LDF + o] = v;
+            Bf.x[row * LDF + o] = v * Bf.feat[(row >> 3) * F + o];
+        }
+    }
+    if (wave + 8 < NT1) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_a_lds<4>(Bf.c, LDC, w.w1b, acc);
+        const int o = (wave + 8) * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            const float v = fmaxf(acc[r] + w.b1b, 0.f);
             if (Bf.h1) Bf.h1[row * LDF + o] = v;
             Bf.x[row * LDF + o] = v * Bf.feat[(row >> 3) * F + o];
         }
     }
     __syncthreads();
-    {   // h2 = relu(x W2^T + b2): one 16-column tile per wave, K = 208
+    PH(3);   /* layer 1 */
+    if (wave < 4) {   // h2 = relu(x W2^T + b2): one 16-column tile per wave, K = 208
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<true, true, F>(Bf.x, LDF, P + O_W2 + wave * 16 * F, F, acc);
+        acc = mma_a_lds<13>(Bf.x, LDF, w.w2, acc);
         const int o = wave * 16 + i;
-        const float bias = P[O_B2 + o];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Bf.h2[(4 * g + r) * LDC + o] = fmaxf(acc[r] + bias, 0.f);
+        for (int r = 0; r < 4; ++r) Bf.h2[(4 * g + r) * LDC + o] = fmaxf(acc[r] + w.b2, 0.f);
+    }
+    if constexpr (BWD_PREFETCH) prefetch_backward(*bw, PL);
+    __syncthreads();
+    PH(4);   /* layer 2 */
+    if (wave < 4) {   // h3 = relu(h2 W3^T + b3)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_a_lds<4>(Bf.h2, LDC, w.w34, acc);
+        const int o = wave * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bf.h3[(4 * g + r) * LDC + o] = fmaxf(acc[r] + w.b34, 0.f);
     }
     __syncthreads();
-    {   // h3 = relu(h2 W3^T + b3)
+    PH(5);   /* layer 3 */
+    if (wave == 4) {   // q = h3 W4^T + b4 (9 of 16 columns)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<true, true, H>(Bf.h2, LDC, P + O_W3 + wave * 16 * H, H, acc);
-        const int o = wave * 16 + i;
-        const float bias = P[O_B3 + o];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Bf.h3[(4 * g + r) * LDC + o] = fmaxf(acc[r] + bias, 0.f);
-    }
-    __syncthreads();
-    if (wave == 0) {   // q = h3 W4^T + b4 (9 of 16 columns)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<true, true, H>(Bf.h3, LDC, P + O_W4, H, acc, NA);
+        acc = mma_a_lds<4>(Bf.h3, LDC, w.w34, acc);
         if (i < NA) {
-            const float bias = P[O_B4 + i];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Bf.q[(4 * g + r) * 12 + i] = acc[r] + bias;
+            for (int r = 0; r < 4; ++r) Bf.q[(4 * g + r) * 12 + i] = acc[r] + w.b34;
         }
     }
     __syncthreads();
+    PH(6);   /* output layer */
 }
 
-__global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restrict__ ring_s, const float *__restrict__ ring_ns,
-                                                            const int64_t *__restrict__ ring_a, const float *__restrict__ ring_r,
-                                                            const float *__restrict__ ring_d, const int64_t *__restrict__ idx,
-                                                            const float *__restrict__ taus_t, const float *__restrict__ taus_l,
-                                                            const float *__restrict__ PL, const float *__restrict__ PT,
-                                                            float *__restrict__ partial, float *__restrict__ loss_partial,
-                                                            int batch, float gamma, const uint64_t *__restrict__ rng_state,
-                                                            int64_t ring_n, int64_t *__restrict__ idx_out, float *__restrict__ taus_out) {
+// TD targets r + gamma * max_a Q_target(next, tau_j) * (1 - done) (agent.py:281-283) of rows 0..15 from q [16][12] in LDS.
+__device__ __forceinline__ float td_target(const float *q, int row, float rew, float done, float gamma) {
+    float m = q[row * 12];
+#pragma unroll
+    for (int a = 1; a < NA; ++a) m = fmaxf(m, q[row * 12 + a]);
+    return rew + gamma * m * (1.f - done);
+}
+
+struct BatchArgs {
+    const float *ring_s, *ring_ns, *ring_r, *ring_d;
+    const int64_t *ring_a;
+    const int64_t *idx;                 // given batch (idx, taus) ...
+    const float *taus_t, *taus_l;
+    const uint64_t *rng_state;          // ... or drawn from {seed, call counter}
+    int64_t ring_n;
+    int64_t *idx_out;
+    float *taus_out;
+};
+
+// Workspace layout (floats): [n_part][P_PAD] partial gradients | [n_part] loss partials (padded to 4) | [N_RED] block sums of
+// squares (padded to 4) | [n_part][16] TD-target granules (u64) | epoch (u64), tickets, staging tag | [batch][72] the NEXT step's
+// batch, staged by iqn_grad_reduce.  The caller zero-fills the workspace once, before the first call, and passes it unchanged
+// afterwards (granule tags, epoch, tickets and the staged batch live there).
+#ifndef MN_RED_COLS
+#define MN_RED_COLS 32
+#endif
+#ifndef MN_RED_SEG
+#define MN_RED_SEG 8
+#endif
+constexpr int RED_COLS = MN_RED_COLS;                          // float4 columns per reduction block
+constexpr int N_COLS = P_PAD / 4;                              // 8947
+constexpr int N_RED = (N_COLS + RED_COLS - 1) / RED_COLS;      // 280 reduction blocks
+constexpr int RED_SEG = MN_RED_SEG;                            // partial-sum segments per column (fixed combination order)
+__host__ __device__ constexpr int64_t pad4(int64_t x) { return (x + 3) / 4 * 4; }
+__host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_part * P_PAD; }
+__host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
+__host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
+__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
+// epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64)
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_epoch(n_part) + 8; }
+constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
+__host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
+
+constexpr int MODE_TWO_ROLES = 0, MODE_LOCAL_ONLY = 1;
+
+
+// the caller's copies of a batch drawn in the launch (inspection, tests): by workgroup 0, after its real work
+__device__ __forceinline__ void write_batch_copies(const BatchArgs &ba, uint64_t base, int batch) {
+    if (!ba.rng_state) return;
+    if (ba.idx_out)
+        for (int k = threadIdx.x; k < batch; k += THREADS) ba.idx_out[k] = perm_row(base, (uint32_t)ba.ring_n, (uint32_t)k);
+    if (ba.taus_out)
+        for (int e = threadIdx.x; e < 2 * batch * NQ; e += THREADS) ba.taus_out[e] = sample_tau(base, e);
+}
+
+__global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const float *__restrict__ PL, const float *__restrict__ PT,
+                                                            float *__restrict__ ws, int batch, float gamma, int mode, int use_staged) {
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
-    __shared__ int64_t s_row[BE];
-    __shared__ __align__(16) int s_val[MAX_BATCH];
-    __shared__ int s_flag[MAX_BATCH];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const int b0 = blockIdx.x * BE;
-    float *out = partial + (size_t)blockIdx.x * P_TOTAL;
+    __shared__ int s_got;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int n_part = batch / BE;
+    const bool two_roles = mode == MODE_TWO_ROLES;
+#ifdef MN_TRAIN_PHASES
+    const int ph_local = two_roles ? n_part : 0;
+#endif
+    PH(0);
+    const bool is_target = two_roles && (int)blockIdx.x < n_part;        // target workgroups come FIRST in dispatch order:
+    const int part = two_roles && !is_target ? blockIdx.x - n_part : blockIdx.x;   // nothing they need is produced in this launch
+    const int b0 = part * BE;
+    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + (size_t)part * ROWS;
+    // hand-off tag of this launch: never 0 (the workspace starts zero-filled), different from the previous launches' tags;
+    // the epoch word is advanced by iqn_grad_reduce, i.e. between two launches of this kernel
+    const uint32_t tag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;
 
-    // The batch: either given (idx, taus_t, taus_l), or drawn here from the generator state -- EVERY workgroup runs the whole
-    // (cheap, deterministic) draw of the batch's rows and keeps its own two, which saves the separate sampling launch (8-11 us
-    // of a 57 us gradient step).  The state's call counter is advanced by iqn_grad_reduce, after all workgroups have read it.
-    if (rng_state) {
-        const uint64_t base = sample_base(rng_state);
-        sample_rows<THREADS>(s_val, s_flag, ring_n, batch, base);
-        if (tid < BE) s_row[tid] = s_val[b0 + tid];
-        if (tid < 2 * ROWS) S[S_TAU + tid] = sample_tau(base, (tid < ROWS ? 0 : batch * NQ) + b0 * NQ + (tid & (ROWS - 1)));
-        if (blockIdx.x == 0) {      // the caller's copies (inspection, tests)
-            if (idx_out) for (int k = tid; k < batch; k += THREADS) idx_out[k] = s_val[k];
-            if (taus_out) for (int e = tid; e < 2 * batch * NQ; e += THREADS) taus_out[e] = sample_tau(base, e);
+    // ---- The first requests of the kernel: (a) this workgroup's two batch slots as the previous step's reduction kernel STAGED them
+    // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
+    // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
+    const float *stage = ws + ws_stage(n_part);
+    const int st_slot = min(tid / STG, BE - 1), st_e = tid % STG;
+    // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
+    uint64_t rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;
+    if (ba.rng_state) {
+        const uint64_t *stg_tag = reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 4);
+        rs0 = ba.rng_state[0]; rs1 = ba.rng_state[1];
+        tg0 = stg_tag[0]; tg1 = stg_tag[1];
+    }
+    float st_v = 0.f;
+    if (use_staged) st_v = stage[(b0 + st_slot) * STG + st_e];      // kernel argument: a scalar branch
+    FwdWeights w;
+    prefetch_forward(w, is_target ? PT : PL);
+    PH(14);  /* all requests issued */
+    // the staged batch is this step's batch iff it was drawn for this call counter from a ring of this many rows
+    uint64_t base = 0;
+    bool staged = false;
+    if (ba.rng_state) {
+        base = mix64(rs0 + 0x9E3779B97F4A7C15ull * (rs1 + 1));      // = sample_base(rng_state)
+        staged = use_staged && tg0 == rs1 && tg1 == (uint64_t)ba.ring_n;
+    }
+    PH(15);  /* generator state / staging tag read */
+    int64_t row0 = 0, row1 = 0;      // (BE = 2; selects instead of an indexed array, which would live in scratch)
+    if (staged) {      // uniform
+        if (tid < BE * STG) {
+            const int o = st_slot * 28;
+            if (st_e < OBS) { if (!is_target) S[S_OBS + o + st_e] = st_v; }
+            else if (st_e < 2 * OBS) { if (is_target) S[S_OBS + o + st_e - OBS] = st_v; else if (!two_roles) S[T_OBS + o + st_e - OBS] = st_v; }
+            else if (st_e == 2 * OBS) s_act[st_slot] = (int)st_v;
+            else if (st_e == 2 * OBS + 1) S[S_MISC + st_slot] = st_v;
+            else if (st_e == 2 * OBS + 2) S[S_MISC + BE + st_slot] = st_v;
+            else if (st_e >= 56 && st_e < 64) { if (is_target) S[S_TAU + st_slot * NQ + st_e - 56] = st_v; else if (!two_roles) S[T_TAU + st_slot * NQ + st_e - 56] = st_v; }
+            else if (st_e >= 64) { if (!is_target) S[S_TAU + st_slot * NQ + st_e - 64] = st_v; }
         }
     } else {
-        if (tid < BE) s_row[tid] = idx[b0 + tid];
-        if (tid < 2 * ROWS) S[S_TAU + tid] = (tid < ROWS ? taus_t : taus_l)[b0 * NQ + (tid & (ROWS - 1))];
+        // ---- no (valid) staged batch: the batch rows of this workgroup (scalar arithmetic, or two loads in the given-batch form) ...
+        float tau_t = 0.f, tau_l = 0.f;
+        const int e_t = b0 * NQ + (tid & (ROWS - 1));
+        if (ba.rng_state) {
+            row0 = perm_row(base, (uint32_t)ba.ring_n, (uint32_t)b0);
+            row1 = perm_row(base, (uint32_t)ba.ring_n, (uint32_t)(b0 + 1));
+            // taus: target draws first (model.py:149 is called for the target network first, agent.py:279-286)
+            tau_t = sample_tau(base, e_t);
+            tau_l = sample_tau(base, batch * NQ + e_t);
+        } else {
+            row0 = ba.idx[b0];
+            row1 = ba.idx[b0 + 1];
+            tau_t = ba.taus_t[e_t];
+            tau_l = ba.taus_l[e_t];
+        }
+        // ---- ... then the transitions, in one straight line without branches (all threads load, clamped -- the few that matter
+        // store to LDS below)
+        const int g_be = (tid / OBS) & 1, g_k = tid % OBS;
+        const int64_t g_row = g_be ? row1 : row0, m_row = (tid & 1) ? row1 : row0;
+        const float g_obs = (is_target ? ba.ring_ns : ba.ring_s)[g_row * OBS + g_k];
+        const float g_tobs = ba.ring_ns[g_row * OBS + g_k];          // only kept when this workgroup runs both networks
+        const int g_act = (int)ba.ring_a[m_row];
+        const float g_rew = ba.ring_r[m_row], g_done = ba.ring_d[m_row];
+        if (tid < ROWS) {
+            S[S_TAU + tid] = is_target ? tau_t : tau_l;
+            if (!two_roles) S[T_TAU + tid] = tau_t;
+        }
+        // gathered transitions -> LDS (replay_buffer.py:42-57)
+        if (tid < BE * OBS) {
+            S[S_OBS + g_be * 28 + g_k] = g_obs;
+            if (!two_roles) S[T_OBS + g_be * 28 + g_k] = g_tobs;
+        }
+        if (tid < BE) {
+            s_act[tid] = g_act;
+            S[S_MISC + tid] = g_rew;
+            S[S_MISC + BE + tid] = g_done;
+        }
     }
+    PH(16);  /* wave 0 has its transitions in LDS */
     __syncthreads();
-    // gather this workgroup's transitions from the replay ring (replay_buffer.py:42-57)
-    for (int t = tid; t < 2 * BE * OBS; t += THREADS) {
-        const int which = t / (BE * OBS), rem = t - which * (BE * OBS), be = rem / OBS, k = rem - be * OBS;
-        S[S_OBS + which * (BE * 28) + be * 28 + k] = (which ? ring_ns : ring_s)[s_row[be] * OBS + k];
-    }
-    if (tid < BE) {
-        const int64_t row = s_row[tid];
-        s_act[tid] = (int)ring_a[row];
-        S[S_MISC + tid] = ring_r[row];
-        S[S_MISC + BE + tid] = ring_d[row];
-    }
-    __syncthreads();
+    PH(1);   /* draw + gather + weight requests */
 
-    // ---- waves 0-3: local network on states; waves 4-7: target network on next_states (agent.py:279-286).
-    // ONE call from uniform control flow -- the half a thread belongs to only selects its buffers / parameters / inputs,
-    // so all 512 threads reach the same five barrier sites inside forward_pass.
-    {
-        const bool tgt = tid >= 256;
-        const PassBufs B = {S + (tgt ? T_C : S_C), tgt ? nullptr : S + S_H1, S + (tgt ? T_X : S_X), S + (tgt ? T_H2 : S_H2),
-                            S + (tgt ? T_H3 : S_H3), S + (tgt ? T_FEAT : S_FEAT), S + (tgt ? T_Q : S_Q)};
-        forward_pass(B, tgt ? PT : PL, S + S_OBS + (tgt ? BE * 28 : 0), S + S_TAU + (tgt ? 0 : ROWS));
+    // output-layer row of the action taken, for dh3 (element tid + 512 e of the [16][64] tile: row 8 e + (tid >> 6), column tid & 63,
+    // i.e. batch element e): two more early requests
+    float w4row[2] = {0.f, 0.f};
+    if (!is_target) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) w4row[e] = PL[O_W4 + s_act[e] * H + (tid & 63)];
     }
-    // TD targets: r + gamma * max_a Q_target(next, tau_j) * (1 - done)   (agent.py:281-283)
-    if (tid < ROWS) {
-        float m = S[T_Q + tid * 12];
-        for (int a = 1; a < NA; ++a) m = fmaxf(m, S[T_Q + tid * 12 + a]);
-        const int be = tid >> 3;
-        S[S_QT + tid] = S[S_MISC + be] + gamma * m * (1.f - S[S_MISC + BE + be]);
-    }
-    __syncthreads();
+    const PassBufs Bl = {S + S_C, is_target ? nullptr : S + S_H1, S + S_X, S + S_H2, S + S_H3, S + S_FEAT, S + S_Q};
+    BwdWeights bw;
+    #ifndef MN_TRAIN_PHASES
+    const int ph_local = -1;
+#endif
+    if (is_target) forward_pass<false>(Bl, w, S + S_OBS, S + S_TAU, nullptr, nullptr, ph_local);
+    else forward_pass<true>(Bl, w, S + S_OBS, S + S_TAU, &bw, PL, ph_local);
 
-    // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407)
-    if (tid < ROWS) {
-        const int be = tid >> 3;
-        const float qe = S[S_Q + tid * 12 + s_act[be]], tau = S[S_TAU + ROWS + tid];
+    if (is_target) {
+        // publish the 16 TD targets: one self-tagged 8-byte granule each ({epoch, value}, agent-scope store: the data is the flag)
+        if (tid < ROWS) {
+            const int be = tid >> 3;
+            const float v = td_target(S + S_Q, tid, S[S_MISC + be], S[S_MISC + BE + be], gamma);
+            __hip_atomic_store(granules + tid, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        PH(7);   /* granules published */
+        if (blockIdx.x == 0) write_batch_copies(ba, base, batch);
+        return;
+    }
+
+    // ---- local workgroup
+    // ---- TD targets: from the target workgroup of the same two batch elements (ready by now -- it ran the same forward at the same
+    // time on another CU), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
+    // dispatch makes impossible -- kept so that a wait can never hang the device)
+    if (two_roles) {
+        if (wave == 0) {
+            bool ok = false;
+            float v = 0.f;
+            const uint64_t t0 = __builtin_readcyclecounter();
+            for (;;) {
+                uint64_t x = (uint64_t)tag << 32;
+                if (lane < ROWS) x = __hip_atomic_load(granules + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t)(x >> 32) == tag;
+                v = __uint_as_float((uint32_t)x);
+                if (__all(ok)) break;
+                if (__builtin_readcyclecounter() - t0 > 400000000ull) break;      // ~0.2 s of shader clocks
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const bool all_ok = __all(ok);
+            if (all_ok && lane < ROWS) S[S_QT + lane] = v;
+            if (lane == 0) s_got = all_ok ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (!two_roles || !s_got) {
+        if (two_roles) {   // late fallback: the target side's inputs, from the staged slots or gathered now
+            const int be = min(tid / OBS, BE - 1), k = tid % OBS;
+            if (staged) {
+                if (tid < BE * OBS) S[T_OBS + be * 28 + k] = stage[(b0 + be) * STG + OBS + k];
+                if (tid < ROWS) S[T_TAU + tid] = stage[(b0 + (tid >> 3)) * STG + 56 + (tid & 7)];
+            } else {
+                if (tid < BE * OBS) S[T_OBS + be * 28 + k] = ba.ring_ns[(be ? row1 : row0) * OBS + k];
+                if (tid < ROWS) {
+                    const int e_t = b0 * NQ + tid;
+                    S[T_TAU + tid] = ba.rng_state ? sample_tau(base, e_t) : ba.taus_t[e_t];
+                }
+            }
+            __syncthreads();
+        }
+        FwdWeights wt;
+        prefetch_forward(wt, PT);
+        const PassBufs Bt = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
+        forward_pass<false>(Bt, wt, S + T_OBS, S + T_TAU, nullptr, nullptr, -2);
+        if (tid < ROWS) {
+            const int be = tid >> 3;
+            S[S_QT + tid] = td_target(S + T_Q, tid, S[S_MISC + be], S[S_MISC + BE + be], gamma);
+        }
+        __syncthreads();
+    }
+
+    PH(8);   /* TD targets in LDS (hand-off wait, or own target forward) */
+    // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407); every thread evaluates the (cheap) gradient of
+    // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
+    float *out = ws + (size_t)part * P_PAD;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int t = tid + THREADS * e, r = t >> 6, k = t & 63, be = r >> 3;
+        const float qe = S[S_Q + r * 12 + s_act[be]], tau = S[S_TAU + r];
         float lsum = 0.f, gsum = 0.f;
+#pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const float td = S[S_QT + be * NQ + j] - qe, ad = fabsf(td);
             const float hub = ad <= 1.f ? 0.5f * td * td : ad - 0.5f;
-            const float w = fabsf(tau - (td < 0.f ? 1.f : 0.f));
-            lsum += w * hub;
-            gsum += w * fminf(fmaxf(td, -1.f), 1.f);
+            const float wq = fabsf(tau - (td < 0.f ? 1.f : 0.f));
+            lsum += wq * hub;
+            gsum += wq * fminf(fmaxf(td, -1.f), 1.f);
         }
         const float scale = 1.f / (float)(batch * NQ);
-        S[S_G + tid] = -gsum * scale;
-        S[S_MISC + 2 * BE + tid] = lsum * scale;
+        const float gr = -gsum * scale;
+        if (k == 0) {
+            S[S_G + r] = gr;
+            S[S_MISC + 2 * BE + r] = lsum * scale;
+        }
+        // output layer backward: only the taken action's row carries gradient
+        S[S_DH3 + r * LDC + k] = S[S_H3 + r * LDC + k] > 0.f ? gr * w4row[e] : 0.f;
     }
     __syncthreads();
+    PH(9);   /* loss + dh3 */
     if (tid == 0) {
         float l = 0.f;
         for (int r = 0; r < ROWS; ++r) l += S[S_MISC + 2 * BE + r];
-        loss_partial[blockIdx.x] = l;
+        ws[ws_loss(n_part) + part] = l;
     }
 
-    // ---- backward (all 8 waves).  Output layer: only the taken action's row carries gradient.
-    for (int t = tid; t < ROWS * H; t += THREADS) {
-        const int r = t >> 6, k = t & 63;
-        S[S_DH3 + r * LDC + k] = S[S_H3 + r * LDC + k] > 0.f ? S[S_G + r] * PL[O_W4 + s_act[r >> 3] * H + k] : 0.f;
+    // ---- backward (all 8 waves)
+    if (wave < 4) {   // dh2 = (dh3 W3) * [h2 > 0]
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mma_a_lds<4>(S + S_DH3, LDC, bw.w3t, acc);
+        const int c = wave * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+            S[S_DH2 + rr * LDC + c] = S[S_H2 + rr * LDC + c] > 0.f ? acc[r] : 0.f;
+        }
+    } else {
+        // dW3 = dh3^T h2 : 4 x 4 tiles, K = the 16 rows; wave 4 + mo takes the four tiles of output rows 16 mo ..
+        const int mo = wave - 4;
+        rows_gemm_fixed_a<4>(S + S_DH3 + mo * 16, LDC, S + S_H2, LDC, 0, 1, 4, [&](int nk, const f32x4 &acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[O_W3 + (mo * 16 + 4 * g + r) * H + nk * 16 + i] = acc[r];
+        });
     }
-    for (int e = tid; e < NA * H + NA; e += THREADS) {
+    for (int e = tid; e < NA * H + NA + H; e += THREADS) {   // dW4, db4, db3
         float v = 0.f;
         if (e < NA * H) {
             const int a = e >> 6, k = e & 63;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r] * S[S_H3 + r * LDC + k];
             out[O_W4 + e] = v;
-        } else {
+        } else if (e < NA * H + NA) {
             const int a = e - NA * H;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r];
             out[O_B4 + a] = v;
+        } else {
+            const int k = e - NA * H - NA;
+            for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + k];
+            out[O_B3 + k] = v;
         }
     }
     __syncthreads();
-    if (wave < 4) {   // dh2 = (dh3 W3) * [h2 > 0]
+    PH(10);  /* dh2, dW3, dW4 */
+    {   // dx = dh2 W2 : 13 column tiles, first on every wave (the chain continues through them) ...
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<true, false, H>(S + S_DH3, LDC, PL + O_W3 + wave * 16, H, acc);
-        const int c = wave * 16 + i;
+        acc = mma_a_lds<4>(S + S_DH2, LDC, bw.w2ta, acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * g + r;
-            S[S_DH2 + row * LDC + c] = S[S_H2 + row * LDC + c] > 0.f ? acc[r] : 0.f;
+        for (int r = 0; r < 4; ++r) S[S_DX + (4 * g + r) * LDF + wave * 16 + i] = acc[r];
+        if (wave + 8 < NT1) {
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+            acc2 = mma_a_lds<4>(S + S_DH2, LDC, bw.w2tb, acc2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[S_DX + (4 * g + r) * LDF + (wave + 8) * 16 + i] = acc2[r];
         }
     }
-    for (int tt = wave; tt < 16; tt += 8) {   // dW3 = dh3^T h2 : 4 x 4 tiles, K = the 16 rows
-        const int mo = tt >> 2, nk = tt & 3;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<false, false, ROWS>(S + S_DH3 + mo * 16, LDC, S + S_H2 + nk * 16, LDC, acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[O_W3 + (mo * 16 + 4 * g + r) * H + nk * 16 + i] = acc[r];
-    }
-    if (tid < H) {
-        float v = 0.f;
-        for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + tid];
-        out[O_B3 + tid] = v;
-    }
-    __syncthreads();
-    for (int job = wave; job < 5 * (F / 16); job += 8) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (job < F / 16) {   // dx = dh2 W2 : 13 column tiles
-            acc = tile_gemm<true, false, H>(S + S_DH2, LDC, PL + O_W2 + job * 16, F, acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[S_DX + (4 * g + r) * LDF + job * 16 + i] = acc[r];
-        } else {              // dW2 = dh2^T x : 4 x 13 tiles
-            const int tt = job - F / 16, mo = tt / (F / 16), nk = tt - mo * (F / 16);
-            acc = tile_gemm<false, false, ROWS>(S + S_DH2 + mo * 16, LDC, S + S_X + nk * 16, LDF, acc);
+    {   // ... then dW2 = dh2^T x : 4 x 13 tiles; wave w: output rows 16 (w & 3) .., column tiles (w >> 2), + 2, ...
+        const int mo = wave & 3;
+        rows_gemm_fixed_a<7>(S + S_DH2 + mo * 16, LDC, S + S_X, LDF, wave >> 2, 2, NT1, [&](int nk, const f32x4 &acc) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[O_W2 + (mo * 16 + 4 * g + r) * F + nk * 16 + i] = acc[r];
-        }
+        });
     }
     if (tid < H) {
         float v = 0.f;
@@ -413,11 +711,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
         out[O_B2 + tid] = v;
     }
     __syncthreads();
+    PH(11);  /* dx, dW2 */
     // Hadamard product: d(features) = sum over the sample's 8 rows of dx * h1;  d(pre-h1) = dx * features * [h1 > 0]
     for (int t = tid; t < BE * F; t += THREADS) {
         const int be = t / F, o = t - be * F;
         const float f = S[S_FEAT + t];
         float df = 0.f;
+#pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int r = be * NQ + q;
             const float d = S[S_DX + r * LDF + o], h = S[S_H1 + r * LDF + o];
@@ -427,12 +727,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
         S[S_DF + t] = df;
     }
     __syncthreads();
-    for (int tt = wave; tt < 4 * (F / 16); tt += 8) {   // dW1 = dh1^T cos : 13 x 4 tiles
-        const int mo = tt >> 2, nk = tt & 3;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = tile_gemm<false, false, ROWS>(S + S_DX + mo * 16, LDF, S + S_C + nk * 16, LDC, acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[O_W1 + (mo * 16 + 4 * g + r) * NC + nk * 16 + i] = acc[r];
+    PH(12);  /* Hadamard */
+    {   // dW1 = dh1^T cos : 13 x 4 tiles, computed transposed (cos^T dh1, the cos tile 16 (w & 3) .. shared by the wave's 6-7 tiles):
+        // acc[r] = dW1[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
+        const int nk = wave & 3;
+        rows_gemm_fixed_a<7>(S + S_C + nk * 16, LDC, S + S_DX, LDF, wave >> 2, 2, NT1, [&](int mo, const f32x4 &acc) {
+            *reinterpret_cast<float4 *>(out + O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        });
     }
     if (tid < F) {
         float v = 0.f;
@@ -454,101 +755,243 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const float *__restr
             out[O_SB + o - 32] = d0 + d1;
         }
     }
+    if (tid < P_PAD - P_TOTAL) out[P_TOTAL + tid] = 0.f;   // row padding: read (as zeros) by the reduction's 16-byte loads
+    PH(13);  /* dW1, encoder gradients issued */
+    if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
 }
 
-// grad[p] = sum over workgroups of partial[wg][p]: four quarter sums (one per thread row, partials in index order,
-// 8 loads in flight) combined in a fixed order -> deterministic.  Block 0 also sums the loss.
-__global__ __launch_bounds__(1024) void iqn_grad_reduce(const float *__restrict__ partial, const float *__restrict__ loss_partial,
-                                                        int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
-                                                        uint64_t *__restrict__ rng_state) {
-    __shared__ float red[4][256];
-    if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[1] += 1;   // the batch of this step was drawn by iqn_train_fwdbwd
-    const int px = threadIdx.x & 255, seg = threadIdx.x >> 8;
-    const int p = blockIdx.x * 256 + px;
-    const int per = (n_part + 3) / 4, w0 = seg * per, w1 = min(n_part, w0 + per);
-    float v = 0.f;
-    if (p < P_TOTAL) {
-#pragma unroll 8
-        for (int w = w0; w < w1; ++w) v += partial[(size_t)w * P_TOTAL + p];
+// grad[p] = sum over workgroups of partial[wg][p].  One thread = one float4 column of one of RED_SEG contiguous segments of the
+// partials: its (up to) n_part / 8 loads are all in flight before the first add (the round-2 kernel did four dependent rounds of
+// eight), summed in index order; the eight segment sums are combined in a fixed order -> deterministic.  Also: this block's sum of
+// squares of the reduced gradient (iqn_adam's norm), the loss (block 0), the generator's call counter and the hand-off epoch.
+constexpr int RED_MAX_PER = 128 / RED_SEG;   // covers batch <= 256 with every load in flight; larger batches loop
+__global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__restrict__ ws, int n_part, float *__restrict__ grad,
+                                                                       float *__restrict__ loss_out, uint64_t *__restrict__ rng_state,
+                                                                       BatchArgs ba, int prefetch_next) {
+    __shared__ float4 red[RED_SEG][RED_COLS];
+    __shared__ float sq[RED_COLS];
+    const int cx = threadIdx.x % RED_COLS, seg = threadIdx.x / RED_COLS;
+    const int col = blockIdx.x * RED_COLS + cx;
+    PH2(0, 0);
+    constexpr int BT = RED_COLS * RED_SEG;
+    float lpart = 0.f;      // block 0 sums the loss: its partials are requested now, summed at the end
+    if (blockIdx.x == 0)
+        for (int wq = threadIdx.x; wq < n_part; wq += BT) lpart += ws[ws_loss(n_part) + wq];
+    // ---- staging of the NEXT step's batch (prefetch_next; blocks 1..): slot k of call counter + 1 -- ring row perm(k), its transition,
+    // its 16 taus -- goes to a fixed address, so the next forward / backward launch starts with one round trip instead of three.
+    // Requested first: the loads ride on the reduction's own memory latency.  The ring must not change before that launch uses it
+    // (the caller passes use_staged only then); the tag written below ties the slots to {call counter, ring rows}.
+    constexpr int SPB = BT / STG;      // staged slots per block
+    const int batch = n_part * BE;
+    int st_slot = -1, st_e = 0;
+    float st_v = 0.f;
+    if (prefetch_next && rng_state && blockIdx.x >= 1) {
+        const int t_slot = threadIdx.x / STG;
+        st_e = threadIdx.x % STG;
+        for (int j = blockIdx.x - 1; j * SPB < batch; j += gridDim.x - 1)      // one pass unless the grid is tiny
+            if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
     }
-    red[seg][px] = v;
+    if (st_slot >= 0) {
+        const uint64_t base_n = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2));   // = sample_base after this step's increment
+        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)st_slot);
+        if (st_e < OBS) st_v = ba.ring_s[row * OBS + st_e];
+        else if (st_e < 2 * OBS) st_v = ba.ring_ns[row * OBS + st_e - OBS];
+        else if (st_e == 2 * OBS) st_v = (float)ba.ring_a[row];
+        else if (st_e == 2 * OBS + 1) st_v = ba.ring_r[row];
+        else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
+        else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
+    }
+    const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < N_COLS) {
+        const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
+        for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
+            float4 t[RED_MAX_PER];
+#pragma unroll
+            for (int u = 0; u < RED_MAX_PER; ++u)
+                t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < RED_MAX_PER; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+        }
+    }
+    PH2(0, 1);   /* this wave's partial sums formed (all loads back) */
+    red[seg][cx] = v;
     __syncthreads();
-    if (seg == 0 && p < P_TOTAL) grad[p] = ((red[0][px] + red[1][px]) + red[2][px]) + red[3][px];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float l = 0.f;
-        for (int w = 0; w < n_part; ++w) l += loss_partial[w];
-        *loss_out = l;
+    PH2(0, 2);
+    if (seg == 0) {
+        float4 s = red[0][cx];
+#pragma unroll
+        for (int q = 1; q < RED_SEG; ++q) { s.x += red[q][cx].x; s.y += red[q][cx].y; s.z += red[q][cx].z; s.w += red[q][cx].w; }
+        float ss = 0.f;
+        if (col < N_COLS) {
+            const int p = col * 4;
+            if (p + 3 < P_TOTAL) *reinterpret_cast<float4 *>(grad + p) = s;   // grad is 16-byte aligned, p a multiple of 4
+            else {
+                const float e[4] = {s.x, s.y, s.z, s.w};
+                for (int k = 0; k < 4; ++k)
+                    if (p + k < P_TOTAL) grad[p + k] = e[k];
+            }
+            ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
+        }
+        sq[cx] = ss;
     }
-}
-
-constexpr int N_SQ = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
-
-// Per-block sum of squares of the (possibly all-reduced) gradient; block 0 advances the optimizer step counter.
-__global__ __launch_bounds__(256) void iqn_sumsq(const float *__restrict__ grad, float *__restrict__ blocksq, int32_t *__restrict__ step) {
-    __shared__ float red[256];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const float gq = p < P_TOTAL ? grad[p] : 0.f;
-    red[threadIdx.x] = gq * gq;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        blocksq[blockIdx.x] = red[0];
-        if (blockIdx.x == 0) *step += 1;
+        float t = 0.f;
+        for (int k = 0; k < RED_COLS; ++k) t += sq[k];
+        ws[ws_sq(n_part) + blockIdx.x] = t;
+    }
+    if (blockIdx.x == 0) {      // the loss: every thread one partial (a single thread summing 128 dependent loads cost 11 us), fixed tree
+        __shared__ float lw[BT / 64];
+        float l = lpart;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+        if ((threadIdx.x & 63) == 0) lw[threadIdx.x >> 6] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int k = 0; k < BT / 64; ++k) t += lw[k];
+            *loss_out = t;
+        }
+    }
+    PH2(0, 3);
+    if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
+    // the block that finishes LAST advances the generator's call counter (the batch of this step was drawn by iqn_train_fwdbwd; the
+    // staging blocks above read the old value) and the hand-off epoch, and tags the staged batch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
+            uint64_t *stg_tag = reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part) + 4);
+            if (rng_state) {
+                const uint64_t c = rng_state[1] + 1;
+                rng_state[1] = c;
+                stg_tag[0] = c;
+                stg_tag[1] = prefetch_next ? (uint64_t)ba.ring_n : 0;      // 0 rows: never a valid ring
+            } else {
+                stg_tag[1] = 0;
+            }
+        }
     }
 }
+
+
+constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
 
 // clip_grad_norm_(max_norm) (torch/nn/utils/clip_grad.py: coef = min(1, max_norm / (norm + 1e-6))) followed by
 // torch.optim.Adam's update: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
-// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  `step` lives on the device (hipGraph-capturable).
-__global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
-                                                float *__restrict__ v, const float *__restrict__ blocksq,
-                                                const int32_t *__restrict__ step, double lr, double b1, double b2,
-                                                double eps_d, double max_norm_d) {
-    __shared__ float red[256];
-    red[threadIdx.x] = threadIdx.x < N_SQ ? blocksq[threadIdx.x] : 0.f;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  `step` lives on the device (hipGraph-capturable): this launch
+// computes with t = *step + 1; the advanced value is stored by whichever block finishes last (a ticket counter in the workspace),
+// so a block that is dispatched late -- another stream's kernel may hold the CUs -- still reads the old value.
+// The sum of squares comes from per-block partial sums: iqn_grad_reduce's, or -- after an all-reduce rewrote the gradient --
+// iqn_grad_sumsq's, which forms the same partial sums in the same order (so an exchange that returns the gradient unchanged, e.g.
+// an all-reduce over one rank, leaves the step bit-identical).  The gradient is multiplied by grad_scale first (1 / world_size
+// after an all-reduce(SUM); exactly 1.0f otherwise).
+__global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale) {
+    __shared__ float sq[RED_COLS];
+    const int q = (blockIdx.x * RED_COLS + threadIdx.x) * 4;
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q + 3 < P_TOTAL) {
+        const float4 x = *reinterpret_cast<const float4 *>(grad + q);
+        e[0] = x.x; e[1] = x.y; e[2] = x.z; e[3] = x.w;
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (q + k < P_TOTAL) e[k] = grad[q + k];
     }
-    const float norm = sqrtf(red[0]);
-    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
-    const int t = *step;   // already advanced by iqn_sumsq
-    // python-float (double) scalars of torch's Adam, rounded to float32 where the tensor kernels consume them
-    const float step_size = (float)(lr / (1.0 - pow(b1, (double)t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
-    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
+    for (int k = 0; k < 4; ++k) e[k] *= grad_scale;
+    sq[threadIdx.x] = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < RED_COLS; ++k) t += sq[k];
+        blocksq[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m,
+                                                float *__restrict__ v, const float *__restrict__ blocksq, int32_t *__restrict__ step,
+                                                unsigned *__restrict__ ticket, double lr, double b1, double b2, double eps_d,
+                                                double max_norm_d, float grad_scale) {
+    __shared__ float red[4];
+    __shared__ float s_bc[2];
     const int p = blockIdx.x * 256 + threadIdx.x;
+    PH2(1, 0);
+    // this thread's operands first: their latency overlaps the norm
+    float gq = 0.f, mp = 0.f, vp = 0.f, pp = 0.f;
+    if (p < P_TOTAL) { gq = grad[p] * grad_scale; mp = m[p]; vp = v[p]; pp = params[p]; }
+    float part = 0.f;
+    for (int c = threadIdx.x; c < N_RED; c += 256) part += blocksq[c];
+    int t_step = 0;
+    if (threadIdx.x == 255) {
+        t_step = *step + 1;
+        // python-float (double) scalars of torch's Adam, rounded to float32 where the tensor kernels consume them
+        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
+    }
+    // wave sums in a fixed order (DPP row / bank shuffles), then the four wave sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    PH2(1, 1);   /* norm partials summed, bias corrections computed */
+    const float sumsq = (red[0] + red[1]) + (red[2] + red[3]);
+    const float norm = sqrtf(sumsq);
+    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
+    const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
     if (p < P_TOTAL) {
-        const float gq = grad[p] * coef;
+        gq *= coef;
         grad[p] = gq;
-        const float mm = m[p] + (gq - m[p]) * w1;                 // lerp, as torch's _single_tensor_adam
-        const float vv = v[p] * b2f + w2 * (gq * gq);
+        const float mm = mp + (gq - mp) * w1;                 // lerp, as torch's _single_tensor_adam
+        const float vv = vp * b2f + w2 * (gq * gq);
         m[p] = mm;
         v[p] = vv;
-        params[p] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+    PH2(1, 2);
+    // the block that finishes LAST stores the advanced counter: every block's thread 255 read it before taking its ticket
+    if (threadIdx.x == 255) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *step = t_step;
+        }
     }
 }
 
 // ReplayBuffer.sample (replay_buffer.py:42-47: random.sample = uniform WITHOUT replacement) plus the 2 x batch x 8
-// tau draws of the step (model.py:149), one workgroup (the stand-alone form of what iqn_train_fwdbwd does in its prologue when
-// it is given the generator state instead of index / tau buffers).  Counter-based RNG: value = mix64(seed, call counter, slot,
-// attempt); state = {seed, counter} on the device, advanced by the kernel (so the launch arguments never change).
+// tau draws of the step (model.py:149), as a stand-alone launch: the batch iqn_train_fwdbwd draws for itself when it is given
+// the generator state instead of index / tau buffers.  Counter-based: state = {seed, call counter} on the device, advanced here.
 __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, uint64_t *__restrict__ state,
                                                          int64_t *__restrict__ idx, float *__restrict__ taus, int n_taus) {
-    __shared__ __align__(16) int val[MAX_BATCH];
-    __shared__ int flag[MAX_BATCH];
     const uint64_t ctr = state[1], base = sample_base(state);
+    __syncthreads();
     for (int e = threadIdx.x; e < n_taus; e += 256) taus[e] = sample_tau(base, e);
-    sample_rows<256>(val, flag, n, batch, base);
-    for (int k = threadIdx.x; k < batch; k += 256) idx[k] = val[k];
+    for (int k = threadIdx.x; k < batch; k += 256) idx[k] = perm_row(base, (uint32_t)n, (uint32_t)k);
     if (threadIdx.x == 0) state[1] = ctr + 1;
 }
 
+int g_train_mode = MODE_TWO_ROLES;
+
 }  // namespace
+
+#ifdef MN_TRAIN_PHASES
+extern "C" int mn_iqn_train_debug_phases(unsigned long long *out_host) {   // [2][32]: target workgroup 0, first local workgroup
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+extern "C" int mn_iqn_train_debug_phases2(unsigned long long *out_host) {   // [reduce, adam][block 0, middle block][8]
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase2), sizeof(unsigned long long) * 32) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+#endif
+
+extern "C" int mn_iqn_train_set_mode(int32_t mode) {
+    if (mode != MODE_TWO_ROLES && mode != MODE_LOCAL_ONLY) return MN_ERR_INVALID;
+    g_train_mode = mode;
+    return MN_OK;
+}
 
 extern "C" int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out,
                              int32_t n_taus_total, void *stream) {
@@ -561,20 +1004,20 @@ extern "C" int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_sta
 
 extern "C" int64_t mn_iqn_train_workspace_floats(int32_t batch) {
     if (batch <= 0 || batch % BE) return -1;
-    return (int64_t)(batch / BE) * (P_TOTAL + 1) + N_SQ;
+    return ws_total(batch / BE);
 }
 
 static int launch_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                        const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev, const float *taus_target_dev,
                        const float *taus_local_dev, const float *params_local, const float *params_target, float *workspace,
                        float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma, uint64_t *rng_state_dev,
-                       int64_t ring_size, int64_t *idx_out, float *taus_out, void *stream) {
+                       int64_t ring_size, int64_t *idx_out, float *taus_out, int32_t flags, void *stream) {
     if (!ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones || !params_local || !params_target ||
         !workspace || !grad_out || !loss_out)
         return MN_ERR_INVALID;
-    if (rng_state_dev ? (batch > MAX_BATCH || ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
+    if (rng_state_dev ? (ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
         return MN_ERR_INVALID;
-    if (batch <= 0 || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
+    if (batch <= 0 || batch > MAX_BATCH || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
     {   // raise the dynamic-LDS limit once per device; guarded so that concurrent first calls from two threads are safe
         static std::mutex mu;
         static bool attr_set[64] = {false};
@@ -589,13 +1032,18 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
         }
     }
     const int n_part = batch / BE;
-    float *partial = workspace, *loss_partial = workspace + (size_t)n_part * P_TOTAL;
+    // two-role launches need every local workgroup's target workgroup dispatched no later than itself: target workgroups have the
+    // lower block indices.  Beyond one workgroup per CU (batch > 256) a local workgroup computes its own targets instead.
+    const int mode = (g_train_mode == MODE_TWO_ROLES && 2 * n_part <= 256) ? MODE_TWO_ROLES : MODE_LOCAL_ONLY;
+    const BatchArgs ba = {ring_states, ring_next_states, ring_rewards, ring_dones, ring_actions, idx_dev, taus_target_dev,
+                          taus_local_dev, (const uint64_t *)rng_state_dev, ring_size, idx_out, taus_out};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_part), dim3(THREADS), LDS_BYTES, s, ring_states, ring_next_states, ring_actions,
-                       ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev, params_local, params_target, partial,
-                       loss_partial, batch, gamma, (const uint64_t *)rng_state_dev, ring_size, idx_out, taus_out);
-    hipLaunchKernelGGL(iqn_grad_reduce, dim3(N_SQ), dim3(1024), 0, s, partial, loss_partial, n_part, grad_out,
-                       loss_out, rng_state_dev);
+    const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
+    const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
+    hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(mode == MODE_TWO_ROLES ? 2 * n_part : n_part), dim3(THREADS), LDS_BYTES, s, ba,
+                       params_local, params_target, workspace, batch, gamma, mode, use_staged);
+    hipLaunchKernelGGL(iqn_grad_reduce, dim3(N_RED), dim3(RED_COLS * RED_SEG), 0, s, workspace, n_part, grad_out, loss_out,
+                       rng_state_dev, ba, prefetch_next);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 
@@ -606,28 +1054,32 @@ extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_nex
                                  int32_t batch, int32_t num_taus, float gamma, void *stream) {
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev,
                        params_local, params_target, workspace, grad_out, loss_out, batch, num_taus, gamma, nullptr, 0, nullptr, nullptr,
-                       stream);
+                       0, stream);
 }
 
 extern "C" int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                                          const float *ring_rewards, const float *ring_dones, int64_t ring_size,
                                          uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, const float *params_local,
                                          const float *params_target, float *workspace, float *grad_out, float *loss_out,
-                                         int32_t batch, int32_t num_taus, float gamma, void *stream) {
+                                         int32_t batch, int32_t num_taus, float gamma, int32_t flags, void *stream) {
     if (!rng_state_dev) return MN_ERR_INVALID;
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local,
                        params_target, workspace, grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out,
-                       stream);
+                       flags, stream);
 }
 
 extern "C" int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev,
                                  float *workspace, int32_t batch, double lr, double beta1, double beta2, double eps,
-                                 double max_norm, void *stream) {
+                                 double max_norm, float grad_scale, int32_t grad_rewritten, void *stream) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !workspace || batch <= 0 || batch % BE) return MN_ERR_INVALID;
+    if (!(grad_scale > 0.f)) return MN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    float *blocksq = workspace + (size_t)(batch / BE) * (P_TOTAL + 1);
-    hipLaunchKernelGGL(iqn_sumsq, dim3(N_SQ), dim3(256), 0, s, grad, blocksq, step_dev);
-    hipLaunchKernelGGL(iqn_adam, dim3(N_SQ), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, blocksq, step_dev, lr, beta1,
-                       beta2, eps, max_norm);
+    const float *blocksq = workspace + ws_sq(batch / BE);
+    unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(batch / BE) + 2);
+    float *blocksq_w = workspace + ws_sq(batch / BE);
+    if (grad_rewritten || grad_scale != 1.0f)      // the reduction kernel's partial sums of squares no longer describe grad
+        hipLaunchKernelGGL(iqn_grad_sumsq, dim3(N_RED), dim3(RED_COLS), 0, s, grad, blocksq_w, grad_scale);
+    hipLaunchKernelGGL(iqn_adam, dim3(N_ADAM), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, blocksq, step_dev, ticket, lr, beta1,
+                       beta2, eps, max_norm, grad_scale);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }

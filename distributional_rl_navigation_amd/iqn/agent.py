@@ -229,7 +229,7 @@ class IQNAgent(ReferenceLoopMixin):
             ft = self._fused_trainer()
             self._enter_train_path("hip")
             # replay_buffer.py:47 + model.py:149 + agent.py:269-304: the batch is drawn inside the forward / backward launch
-            loss = ft.step_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE)
+            loss = ft.step_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, m.version)
             self.grad_steps += 1
             return loss
         return self.train(self.memory.sample())

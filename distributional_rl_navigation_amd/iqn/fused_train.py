@@ -1,5 +1,6 @@
 """Host side of the fused HIP gradient step (csrc/iqn_train.hip): IQNAgent.train (thirdparty/IQN/agent.py:269-304)
-as three kernels behind `mn_iqn_train_grad` / `mn_iqn_train_adam`.
+as three launches (forward / backward with in-launch target hand-off, reduction, Adam) behind `mn_iqn_train_grad*` /
+`mn_iqn_train_adam`.
 
 The kernels work on FLAT parameter vectors (35 785 floats, `named_parameters()` order).  `FusedTrainer` allocates one
 flat buffer per network and re-points every `nn.Parameter` at a view of it, so the PyTorch modules (checkpoints,
@@ -55,6 +56,7 @@ class FusedTrainer:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws, self._ws_batch = None, 0
+        self._staged_key = None      # (ring, its version, rows, batch, workspace) the workspace holds a staged next batch for
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
         self.rng_state = torch.tensor([int(agent.memory.gen.initial_seed()) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
                                       device=self.device)
@@ -110,12 +112,14 @@ class FusedTrainer:
             n = _capi.lib().mn_iqn_train_workspace_floats(batch)
             if n < 0:
                 raise ValueError("fused IQN gradient step: the batch size must be even")
-            self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            # zero-filled once: the TD-target hand-off tags, their epoch word and the Adam ticket live in it between calls
+            self._ws = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._ws_batch = batch
         return self._ws
 
     def sample(self, ring_size, batch):
         """ReplayBuffer.sample's index draw + the step's tau draws in ONE kernel -> (idx [B] i64, taus [2, B, 8])."""
+        self._staged_key = None      # the call counter moves on: a staged batch belongs to a counter that is skipped
         if batch not in self._idx:
             self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
             self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)
@@ -126,10 +130,14 @@ class FusedTrainer:
             raise _capi.MarineNavHipError(f"mn_iqn_sample failed ({rc}): need batch <= 1024 and ring_size >= batch")
         return idx, taus
 
-    def step_sampled(self, ring, ring_size, batch):
+    def step_sampled(self, ring, ring_size, batch, ring_version=None):
         """`self.train(self.memory.sample())` (agent.py:131-133) in one call: the batch (ReplayBuffer.sample's uniform draw without
         replacement over the first `ring_size` rows + the step's tau draws) is drawn INSIDE the forward / backward kernel from this
-        trainer's generator state -- bit-identical to `sample()` followed by `step()`, one launch less.  Returns the loss."""
+        trainer's generator state -- bit-identical to `sample()` followed by `step()`, one launch less.  Returns the loss.
+        `ring_version` (ReplayBuffer.version): when given, every step also stages the NEXT step's batch (MN_TRAIN_STAGE_NEXT: its
+        rows, transitions and taus, gathered by the reduction kernel) and a step starts from the staged batch whenever the ring
+        has not been written since (MN_TRAIN_USE_STAGED) -- same batch, same result, one memory round trip at the head of the
+        launch instead of three."""
         ag = self.agent
         states, actions, rewards, next_states, dones = ring
         for t in ring:
@@ -140,10 +148,15 @@ class FusedTrainer:
             self._taus[batch] = torch.empty(2, batch, ag.N, dtype=torch.float32, device=self.device)
         L = _capi.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        flags = 0
+        if ring_version is not None:
+            key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr() if self._ws is not None else 0)
+            flags = 2 | (1 if key == self._staged_key else 0)
         rc = L.mn_iqn_train_grad_sampled(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size),
                                          _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target),
                                          _p(self._workspace(batch)), _p(self.grad), _p(self.loss), batch, ag.N,
-                                         C.c_float(ag.GAMMA ** ag.n_step), stream)
+                                         C.c_float(ag.GAMMA ** ag.n_step), flags, stream)
+        self._staged_key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr()) if ring_version is not None else None
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_grad_sampled failed ({rc}): need batch <= 1024 and ring_size >= batch")
         return self._finish_step(batch)
@@ -185,6 +198,7 @@ class FusedTrainer:
         ag = self.agent
         L = _capi.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        scale, rewritten = 1.0, 0
         if ag.distributed:
             import torch.distributed as dist
             if dist.get_backend() == "gloo":
@@ -194,10 +208,11 @@ class FusedTrainer:
                 self.grad.copy_(g)
             else:
                 dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)        # one 143 KB bucket over RCCL/xGMI
-            self.grad.div_(dist.get_world_size())
+            # the average (1 / world) is applied inside the Adam kernel: no separate launch over the bucket
+            scale, rewritten = 1.0 / dist.get_world_size(), 1
         rc = L.mn_iqn_train_adam(_p(self.local), _p(self.grad), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev),
                                  _p(self._workspace(B)), B, C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5),
-                                 stream)
+                                 C.c_float(scale), rewritten, stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_adam failed ({rc})")
         weights_changed(ag.qnetwork_local)      # the HIP Adam kernel wrote the weights: the act path's cached image is stale

@@ -26,6 +26,7 @@ class ReplayBuffer:
         self.dones = torch.zeros(c, 1, dtype=torch.float32, device=self.device)
         self.size = 0
         self.ptr = 0
+        self.version = 0      # bumped by every write to the ring (a batch the gradient kernels staged from it is then stale)
 
     def add(self, state, action, reward, next_state, done):
         """One transition (replay_buffer.py:26-34)."""
@@ -54,6 +55,7 @@ class ReplayBuffer:
         m = min(n, self.capacity)
         self.ptr = (self.ptr + m) % self.capacity
         self.size = min(self.capacity, self.size + m)
+        self.version += 1
 
     def add_batch(self, states, actions, rewards, next_states, dones):
         """n transitions at once; FIFO eviction like deque(maxlen)."""
@@ -74,12 +76,14 @@ class ReplayBuffer:
             return
         self.ptr = end % self.capacity
         self.size = min(self.capacity, self.size + n)
+        self.version += 1
 
     def advance(self, n):
         """Ring bookkeeping after `n` transitions were written at `ptr` by a kernel (mn_step_append)."""
         m = min(int(n), self.capacity)
         self.ptr = (self.ptr + m) % self.capacity
         self.size = min(self.capacity, self.size + m)
+        self.version += 1
 
     def sample_indices(self, b):
         """`b` distinct uniform row indices in [0, size) (random.sample, replay_buffer.py:47) without a full

@@ -301,18 +301,26 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  *                               (model.py:120-136): velocity_encoder.{weight[16][2],bias[16]}, goal_encoder.{[16][2],[16]},
  *                               sensor_encoder.{[176][22],[176]}, cos_embedding.{[208][64],[208]},
  *                               hidden_layer.{[64][208],[64]}, hidden_layer_2.{[64][64],[64]}, output_layer.{[9][64],[9]}
- *   workspace                 : mn_iqn_train_workspace_floats(batch) floats of scratch (per-workgroup partial gradients,
- *                               norm partials); pass the same buffer and batch to both calls
+ *   workspace                 : mn_iqn_train_workspace_floats(batch) floats (per-workgroup partial gradients, norm partials, the
+ *                               TD-target hand-off granules with their epoch word, the Adam ticket).  ZERO-FILL it once before the
+ *                               first call and then pass the same buffer and batch, untouched, to every call of one learner
  *   grad_out [35 785]         : d loss / d params_local (un-clipped); loss_out [1]: the loss
- * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics); the caller may average
- * grad_out over ranks (RCCL all-reduce) before mn_iqn_train_adam, which applies clip_grad_norm_(max_norm)
- * (agent.py:299) and one torch.optim.Adam update (agent.py:300; exp_avg / exp_avg_sq [35 785], step_dev: i32 step
- * counter on the device, incremented by the call; grad is overwritten with the clipped gradient).
- * batch must be even, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
+ * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics).  The forward / backward launch has
+ * two workgroup roles -- batch / 2 TARGET workgroups (lower block indices) run the target network and hand their 16 TD targets
+ * each to the LOCAL workgroup of the same two batch elements inside the launch -- so it wants batch <= 256 (one workgroup per CU);
+ * larger batches, and mn_iqn_train_set_mode(1), let every local workgroup compute its own targets.  The caller may average
+ * grad_out over ranks (RCCL all-reduce(SUM); pass grad_scale = 1 / world_size and grad_rewritten = 1) before mn_iqn_train_adam,
+ * which applies clip_grad_norm_(max_norm) (agent.py:299) to grad_scale * grad and one torch.optim.Adam update (agent.py:300;
+ * exp_avg / exp_avg_sq [35 785], step_dev: i32 step counter on the device, incremented by the call; grad is overwritten with the
+ * clipped gradient).  grad_rewritten = 0 promises that grad_out is exactly what the preceding mn_iqn_train_grad* call on the same
+ * workspace left there (the norm then comes from partial sums that call stored); with grad_rewritten != 0 or grad_scale != 1 the
+ * norm is recomputed from grad.
+ * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
-/* ReplayBuffer.sample (replay_buffer.py:42-47): `batch` DISTINCT uniform row indices in [0, ring_size) -> idx_out
- * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).
- * rng_state_dev: u64[2] = {seed, call counter} on the device; the counter is advanced by the call.
+/* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
+ * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).  Slot k reads
+ * row perm(k) of a keyed pseudo-random permutation of [0, ring_size) (4-round Feistel network + cycle walking): distinct by
+ * construction, O(1) per slot.  rng_state_dev: u64[2] = {seed, call counter} on the device; the counter is advanced by the call.
  * batch <= 1024, ring_size >= batch. */
 int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out,
                   int32_t n_taus_total, void *stream);
@@ -321,18 +329,31 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
                       const float *taus_target_dev, const float *taus_local_dev, const float *params_local,
                       const float *params_target, float *workspace, float *grad_out, float *loss_out, int32_t batch,
                       int32_t num_taus, float gamma, void *stream);
-/* The same gradient step with the batch drawn inside the launch: every workgroup of the forward / backward kernel runs
- * mn_iqn_sample's (cheap, deterministic) draw of the batch's ring rows from {seed, call counter} and keeps its own, so the
- * separate sampling launch disappears (8-11 us of a 57 us step).  Bit-identical to mn_iqn_sample followed by
- * mn_iqn_train_grad from the same state; the call counter is advanced once (by the reduction kernel).  idx_out [batch] i64
- * and taus_out [2][batch][8] receive the batch (NULL: not written).  Needs batch <= 1024, batch <= ring_size < 2^31. */
+/* The same gradient step with the batch drawn inside the launch: every workgroup of the forward / backward kernel evaluates
+ * mn_iqn_sample's permutation for its own two slots (and its own taus) from {seed, call counter}, so there is no sampling launch.
+ * Bit-identical to mn_iqn_sample followed by mn_iqn_train_grad from the same state; the call counter is advanced once (by the
+ * reduction kernel).  idx_out [batch] i64 and taus_out [2][batch][8] receive the batch (NULL: not written).  Needs
+ * batch <= ring_size < 2^31. */
+/* flags: MN_TRAIN_STAGE_NEXT -- the reduction kernel of this step also draws the NEXT step's batch (call counter + 1) from the ring
+ * as it is now and stages it (rows, transitions, taus) in the workspace; MN_TRAIN_USE_STAGED -- start from the batch a previous call
+ * staged instead of drawing and gathering it (one memory round trip at the head of the launch instead of three dependent ones).
+ * The staged batch is used only if it was drawn for this call counter and this ring_size (checked on the device; otherwise the
+ * launch draws and gathers as usual), and its transitions are those the ring held when it was staged: pass MN_TRAIN_USE_STAGED only
+ * if the ring was not written since the staging call (then the step is bit-identical to the unstaged one). */
+#define MN_TRAIN_USE_STAGED 1
+#define MN_TRAIN_STAGE_NEXT 2
 int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                               const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,
                               int64_t *idx_out, float *taus_out, const float *params_local, const float *params_target,
                               float *workspace, float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma,
-                              void *stream);
+                              int32_t flags, void *stream);
 int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
-                      int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
+                      int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, float grad_scale,
+                      int32_t grad_rewritten, void *stream);
+/* Process-wide switch of the forward / backward launch: 0 (default) = two workgroup roles with the in-launch TD-target hand-off,
+ * 1 = every local workgroup runs the target forward itself (no inter-workgroup communication; what batches > 256 always use).
+ * Same arithmetic either way: results are bit-identical. */
+int mn_iqn_train_set_mode(int32_t mode);
 
 /* Benchmark hook: HIP events on the launch stream around the next act launches of this context (weight / random-number
  * preparation launch included). */

@@ -1,0 +1,32 @@
+"""Learner alone: back-to-back fused gradient steps (batch drawn in the launch), per launch mode.
+usage: python scripts/learner_bench.py [reps] [batch]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from distributional_rl_navigation_amd import _capi
+from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dev = "cuda:0"
+ag = IQNAgent(26, 9, BATCH_SIZE=B, BUFFER_SIZE=100_000, device=dev, seed=1)
+g = torch.Generator(device=dev); g.manual_seed(0)
+n = 100_000
+ag.memory.add_batch(torch.randn(n, 26, device=dev, generator=g), torch.randint(0, 9, (n,), device=dev, generator=g),
+                    torch.randn(n, device=dev, generator=g), torch.randn(n, 26, device=dev, generator=g),
+                    (torch.rand(n, device=dev, generator=g) < 0.05).float())
+for mode in (0, 1, 0):
+    _capi.lib().mn_iqn_train_set_mode(mode)
+    for _ in range(20):
+        ag.train_from_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ag.train_from_memory()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"mode {mode}: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
+_capi.lib().mn_iqn_train_set_mode(0)

@@ -110,7 +110,11 @@ def test_graphed_train_step_equals_eager(torch):
             ag2 = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device="cuda:0", seed=9)
             ag.qnetwork_local.load_state_dict(ag2.qnetwork_local.state_dict())
             ag.qnetwork_target.load_state_dict(ag2.qnetwork_target.state_dict())
-            ag.optimizer = torch.optim.Adam(ag.qnetwork_local.parameters(), lr=ag.LR, capturable=True)
+            with torch.no_grad():            # the captured graph updates THIS optimizer's state tensors: back to a fresh Adam, in place
+                for st in ag.optimizer.state.values():
+                    for v_ in st.values():
+                        if torch.is_tensor(v_):
+                            v_.zero_()
             torch.manual_seed(1234)
         losses = [float(ag.train(b)) for b in batches]
         res.append((losses, [p.detach().clone() for p in ag.qnetwork_local.parameters()]))
@@ -287,7 +291,9 @@ def test_iqn_c_abi_argument_checks(torch):
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
     L = _capi.lib()
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35786 + 140
+    # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
+    # staging tag + the staged next batch (256 slots of 72 floats)
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 8 + 256 * 72
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -307,7 +313,9 @@ def test_iqn_c_abi_argument_checks(torch):
                          p(f), p(taus), B, K, C.c_float(0.99), None)
     assert L.mn_iqn_train_grad(*args(3, 8)) == INVALID      # odd batch
     assert L.mn_iqn_train_grad(*args(2, 32)) == INVALID     # training uses 8 taus
-    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, None) == INVALID
+    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, C.c_float(1.0), 0, None) == INVALID
+    assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), p(st), p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, C.c_float(0.0), 0, None) == INVALID   # grad_scale must be positive
+    assert L.mn_iqn_train_set_mode(2) == INVALID and L.mn_iqn_train_set_mode(0) == 0
     assert L.mn_iqn_act(None, p(ring[0]), p(taus), None, None, None, C.c_float(0.0), p(idx), None, 4, 32, None) == INVALID
 
 
@@ -425,3 +433,119 @@ def test_sampled_gradient_step_equals_sample_then_step(torch):
         assert np.isfinite(float(c.train_from_memory()))
         i3 = c._fused._idx[32]
         assert i3.unique().numel() == 32 and int(i3.min()) >= 0 and int(i3.max()) < 40
+
+
+def _filled_agent(torch, seed, B=256, ring=3000, fill=2500):
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    ag = IQNAgent(26, 9, BATCH_SIZE=B, seed=seed, BUFFER_SIZE=ring, device=dev)
+    s_, ac, r, ns, d = _random_batch(torch, fill, g)
+    ag.memory.add_batch(s_, ac.view(-1), r.view(-1), ns, d.view(-1))
+    with torch.no_grad():                       # a target network that differs from the local one
+        for p in ag.qnetwork_target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, device=dev, generator=g))
+    return ag
+
+
+def test_two_role_launch_equals_local_only_launch_bitwise(torch):
+    """Round-3 forward / backward launch: TARGET workgroups hand their 16 TD targets to the LOCAL workgroup of the same two batch
+    elements inside the launch (self-tagged granules).  `mn_iqn_train_set_mode(1)` makes every local workgroup run the target
+    forward itself -- no inter-workgroup communication.  Same arithmetic: losses, gradients, parameters, drawn batches are
+    bit-identical over several steps (batch 256 = 128 + 128 workgroups, and a small batch)."""
+    from distributional_rl_navigation_amd import _capi
+    L = _capi.lib()
+    for B, ring, fill in ((256, 3000, 2500), (6, 64, 40)):
+        runs = []
+        for mode in (0, 1):
+            assert L.mn_iqn_train_set_mode(mode) == 0
+            try:
+                ag = _filled_agent(torch, 9, B, ring, fill)
+                losses = [float(ag.train_from_memory()) for _ in range(5)]
+                ft = ag._fused
+                runs.append((losses, ft.local.clone(), ft.grad.clone(), ft._idx[B].clone(), ft._taus[B].clone(), int(ft.step_dev)))
+            finally:
+                L.mn_iqn_train_set_mode(0)
+        (l0, p0, g0, i0, t0, s0), (l1, p1, g1, i1, t1, s1) = runs
+        assert l0 == l1 and torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(i0, i1) and torch.equal(t0, t1)
+        assert s0 == s1 == 5 and all(np.isfinite(l0))
+
+
+def test_gradient_step_under_a_busy_gpu_is_bitwise_the_quiet_step(torch):
+    """The in-launch hand-off, the Adam step-counter ticket and the reduction must not depend on dispatch timing: the same 40
+    gradient steps with the act kernel of 65 536 envs running on a second stream (it holds every CU, so the gradient step's
+    workgroups are dispatched late and unevenly) give bit-identical parameters, and the step counter counts every step."""
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+    dev = "cuda:0"
+    quiet = _filled_agent(torch, 5)
+    for _ in range(40):
+        quiet.train_from_memory()
+    busy = _filled_agent(torch, 5)
+    obs = torch.randn(65536, 26, device=dev) * 5.0
+    actor = _filled_agent(torch, 6, B=32, ring=64, fill=40)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for it in range(40):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                fused_act(actor.qnetwork_local, obs, 0.1, 1.0, generator=None)
+        busy.train_from_memory()
+    torch.cuda.synchronize()
+    assert torch.equal(quiet._fused.local, busy._fused.local) and torch.equal(quiet._fused.exp_avg_sq, busy._fused.exp_avg_sq)
+    assert int(quiet._fused.step_dev) == int(busy._fused.step_dev) == 40
+
+
+def test_permutation_sampler_properties(torch):
+    """ReplayBuffer.sample = random.sample(memory, k): k distinct uniform rows.  The kernels read slot k's row from a keyed
+    pseudo-random permutation of [0, n): distinct for every ring size (powers of two, just above / below, tiny, the 100 000 of
+    the headline configuration), uniform (inclusion frequency of every row), no first-slot bias, fresh per call."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    ag = IQNAgent(26, 9, BATCH_SIZE=64, seed=4, BUFFER_SIZE=128, device=dev)
+    ft = ag._fused_trainer()
+    for n in (64, 65, 127, 128, 129, 1000, 4096, 4097, 100_000, 2 ** 31 - 1):
+        seen = set()
+        for _ in range(3):
+            idx, _t = ft.sample(n, 64)
+            v = idx.cpu().numpy()
+            assert len(np.unique(v)) == 64 and v.min() >= 0 and v.max() < n, n
+            seen.add(tuple(v))
+        assert len(seen) == 3
+    n = 300
+    cnt = np.zeros(n); first = np.zeros(n)
+    reps = 3000
+    for _ in range(reps):
+        v = ft.sample(n, 64)[0].cpu().numpy()
+        cnt[v] += 1; first[v[0]] += 1
+    p = 64 / n
+    assert abs(cnt.mean() / reps - p) < 1e-9 and (cnt / reps).std() < 1.5 * np.sqrt(p * (1 - p) / reps)
+    assert first.max() < 40 and (first > 0).sum() > 0.95 * n          # slot 0 is uniform over the ring as well (mean 10 per row)
+
+
+def test_staged_batch_step_equals_drawn_batch_step_bitwise(torch):
+    """`train_from_memory()` lets the reduction kernel of step k stage step k + 1's batch (rows, transitions, taus) and starts
+    step k + 1 from it (MN_TRAIN_STAGE_NEXT / MN_TRAIN_USE_STAGED).  Same batch, same arithmetic: bit-identical to steps that draw
+    and gather inside the launch -- also across a write to the ring (the staged batch is then not used: the ring version moved),
+    a change of the ring size and a generator state set from outside (tag mismatch on the device)."""
+    a = _filled_agent(torch, 9)
+    b = _filled_agent(torch, 9)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(77)
+    extra = _random_batch(torch, 200, g)
+
+    def step_b():
+        m, ft = b.memory, b._fused_trainer()
+        b._enter_train_path("hip")
+        return ft.step_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, b.BATCH_SIZE)      # no staging
+
+    for it in range(12):
+        if it == 5:      # ring written between two steps (and it grows: 2500 -> 2700 rows)
+            for ag in (a, b):
+                ag.memory.add_batch(extra[0], extra[1].view(-1), extra[2].view(-1), extra[3], extra[4].view(-1))
+        if it == 8:
+            for ag in (a, b):
+                ag._fused.rng_state.copy_(torch.tensor([int(ag._fused.rng_state[0]), 1000], dtype=torch.int64))
+        la, lb = float(a.train_from_memory()), float(step_b())
+        assert la == lb, it
+        assert torch.equal(a._fused.local, b._fused.local) and torch.equal(a._fused._idx[256], b._fused._idx[256]), it
+        assert torch.equal(a._fused._taus[256], b._fused._taus[256]) and torch.equal(a._fused.rng_state, b._fused.rng_state), it
+    assert a._fused._staged_key is not None and b._fused._staged_key is None
