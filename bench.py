@@ -103,7 +103,7 @@ def _timed(device, fn, steps, warmup, state, before_timed=None):
     return time.perf_counter() - t0, state
 
 
-def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
+def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch_leg=False):
     """The other configurations the README / DESIGN quote, timed by the same run so that they are driver-timed numbers too:
       act_exact_f32      the main loop with the exact-f32 MFMA act kernel (variant 0) instead of the split-f16 one
       train_cadence      the cadence that trains (train_iqn's default): 16 gradient steps per vector step, eps 0.05
@@ -123,6 +123,36 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
         e = agent.linear_eps(total_timesteps) if eps is None else eps
         return agent.vec_step(env, o, e, cvar, per_iter=n)[0]
 
+    if not one_batch_leg and n % 2 == 0:      # the main loop as two half batches on two streams (what --halves 2 runs)
+        from distributional_rl_navigation_amd.iqn.overlap import SplitBatchLoop
+        hv = [VecMarineNavEnv(n // 2, seed=0, first_index=env.first_index + h * (n // 2), device=device, precision=env.precision) for h in range(2)]
+        for e_ in hv:
+            e_.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis={4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0))
+        sp = SplitBatchLoop(agent, hv, act_grid=args.act_grid)
+        sp.reset()
+        steps = max(20, args.steps // 2)
+
+        def sp_step(_):
+            sp.step(agent.linear_eps(total_timesteps) if args.eps is None else args.eps, args.cvar, per_iter=n)
+        for _ in range(10):
+            sp_step(None)
+        sp.join(); torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sp_step(None)
+        sp.join(); torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out["two_halves_two_streams"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                                         "sub_batches": 2, "act_grid": args.act_grid,
+                                         "note": "same workload; each half's env kernels run under the other half's act kernel (iqn/overlap.py)"}
+        sp.close()
+        torch.cuda.synchronize(device)
+        for e_ in hv:
+            e_.close()
+    if one_batch_leg:      # the main loop as ONE batch on one stream (what --halves 1 runs)
+        steps = max(20, args.steps // 2)
+        dt, obs = _timed(device, loop_step, steps, 10, obs)
+        out["one_batch_one_stream"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
     # (a) exact-f32 act kernel
     steps, warm = max(20, args.steps // 2), 10
     ctx.set_variant(0)
@@ -247,6 +277,11 @@ def main():
                                                             "cadence, configs[1], single-rank RCCL learner) after the main timed region")
     ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2, 3), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout, 3 = split-f16 on 32x32x16 tiles")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
+    ap.add_argument("--halves", type=int, default=1,
+                    help="sub-batches of the envs, each with its own act -> step -> reset chain on its own HIP stream (iqn/overlap.py: the env "
+                         "kernels of one half run under the act kernel of the other; timed by the default run as also.two_halves_two_streams); "
+                         "1 (default) = one batch on one stream, which keeps one act launch = one vector step for the roofline figure")
+    ap.add_argument("--act-grid", type=int, default=1024, help="with --halves > 1: workgroups of an act launch (mn_iqn_set_grid)")
     args = ap.parse_args()
     if args.precision is None:
         args.precision = default_precision(learner=not args.no_learner)
@@ -287,10 +322,13 @@ def main():
 
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
-    env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision=args.precision, step_lanes=args.lanes,
-                          rollout_lanes=args.lanes if args.lanes != 1 else 0)
-    env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
-    obs = env.reset()
+    H = args.halves if (not args.no_learner and not args.torch_act and not args.separate_append and n % max(1, args.halves) == 0) else 1
+    envs = [VecMarineNavEnv(n // H, seed=0, first_index=rank * n + h * (n // H), device=device, precision=args.precision, step_lanes=args.lanes,
+                            rollout_lanes=args.lanes if args.lanes != 1 else 0) for h in range(H)]
+    for e_ in envs:
+        e_.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
+    env = envs[0]
+    obs = env.reset() if H == 1 else None
     agent = None
     if not args.no_learner:
         agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device=device,
@@ -317,6 +355,11 @@ def main():
             return getattr(self._e, k)
     loop_env = _NoAppend(env) if args.separate_append else env
     eps_seen = []
+    split = None
+    if H > 1:
+        from distributional_rl_navigation_amd.iqn.overlap import SplitBatchLoop
+        split = SplitBatchLoop(agent, envs, act_grid=args.act_grid)
+        split.reset()
 
     def one_step(o):
         if agent is None:
@@ -325,9 +368,13 @@ def main():
             return env.reset_done()
         eps = agent.linear_eps(total_timesteps) if args.eps is None else args.eps
         eps_seen.append(eps)
+        if split is not None:
+            return split.step(eps, args.cvar, per_iter=n * world)[0]
         return agent.vec_step(loop_env, o, eps, args.cvar, per_iter=n * world)[0]
 
     def fence():
+        if split is not None:
+            split.join()
         torch.cuda.synchronize(device)
         if use_dist:
             dist.barrier()
@@ -381,6 +428,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    also = {}
+    if world == 1 and not args.no_also and agent is not None and fused and not roll and not args.torch_train and not args.torch_act:
+        if split is not None:      # the extra legs run the one-batch loop on their own handle
+            split.close()
+            torch.cuda.synchronize(device)
+            for e_ in envs:
+                e_.close()
+            env = VecMarineNavEnv(n, seed=0, first_index=rank * n, device=device, precision=args.precision)
+            env.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)
+            obs = env.reset()
+            envs = [env]
+        also = also_legs(args, env, agent, obs, device, total_timesteps, use_dist, one_batch_leg=split is not None)
+
     # learner alone (outside the timed region): back-to-back IQN grad steps (sample + train), batch 256, 8 quantiles.
     # Eager = what the loop uses (there the ~130 launches hide behind the act kernel); back to back the eager step is
     # CPU-launch-bound, which is where the captured hipGraph (IQNAgent.use_train_graph) pays.
@@ -403,10 +463,6 @@ def main():
             learner_only[mode] = reps / (time.perf_counter() - t1)
         agent.use_fused_train = was_fused
 
-    also = {}
-    if world == 1 and not args.no_also and agent is not None and fused and not roll and not args.torch_train and not args.torch_act:
-        also = also_legs(args, env, agent, obs, device, total_timesteps, use_dist)
-
     if rank == 0:
         env_steps = n * world * args.steps
         bytes_step = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
@@ -414,7 +470,7 @@ def main():
         # the training loop's env kernel is mn_step_append: the step's 406 B + the transition it writes to the ring
         bytes_per = bytes_step + (APPEND_BYTES_PER_ENV_STEP if fused_append else 0)
         # one launch processes n env-steps (single step) or n * T env-steps (mn_rollout)
-        per_launch = n * max(1, roll)
+        per_launch = (n // H) * max(1, roll)
         achieved = bytes_per * per_launch / (step_kernel_ms * 1e-3) / 1e9 if step_kernel_ms > 0 else 0.0
         out = {
             "metric": "env steps/sec (whole node) at 65 536 envs; IQN grad-steps/sec",
@@ -449,6 +505,7 @@ def main():
                 "eps": None if agent is None else (sum(eps_seen[-args.steps:]) / max(1, len(eps_seen[-args.steps:]))),
                 "update_every_vector_steps": None if agent is None else args.update_every,
                 "grad_steps_per_event": None if agent is None else args.grad_steps,
+                "sub_batches": H, "act_grid": args.act_grid if H > 1 else 0,
                 "replay_append": "none" if agent is None else ("separate launch" if args.separate_append else "fused into the step kernel (mn_step_append)"),
                 "ablation": bool(_capi.lib().mn_build_info() & 1),     # from the loaded library: False = full kernels
             },
@@ -530,7 +587,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    env.close()
+    for e_ in envs:
+        e_.close()
     return result_line
 
 

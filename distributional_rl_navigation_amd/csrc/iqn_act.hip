@@ -750,9 +750,19 @@ struct mn_iqn_ctx {
     float *consts_sp = nullptr;    // its scale / bound constants
     bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
+    int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
+    uint32_t *slot_sp[2] = {nullptr, nullptr};   // mn_iqn_pack_slot: explicitly managed images of the split-f16 kernel (slot 1 allocated on demand)
+    float *slot_consts = nullptr;           // scale constants scratch of the slot packs
+    int sel_slot = -1;                      // mn_iqn_select_slot: >= 0 = act launches read slot_sp[sel_slot] and never pack
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
+
+extern "C" int mn_iqn_set_grid(mn_iqn_ctx *c, int32_t max_workgroups) {
+    if (!c || max_workgroups < 0) return MN_ERR_INVALID;
+    c->max_blocks = max_workgroups;
+    return MN_OK;
+}
 
 extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
     if (!out) return MN_ERR_INVALID;
@@ -804,6 +814,9 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->packed_sp);
     (void)hipFree(c->packed_sp32);
     (void)hipFree(c->consts_sp);
+    (void)hipFree(c->slot_sp[0]);
+    (void)hipFree(c->slot_sp[1]);
+    (void)hipFree(c->slot_consts);
     if (moved) (void)hipSetDevice(cur);
     delete c;
     return MN_OK;
@@ -866,7 +879,8 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
                           weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     int blocks = (n + 7) / 8;
-    if (blocks > c->n_cu) blocks = c->n_cu;
+    const int cap = c->max_blocks > 0 ? c->max_blocks : c->n_cu;
+    if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
@@ -878,7 +892,9 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     if (use_sp || use_sp32) {
         bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
         uint32_t *image = use_sp32 ? c->packed_sp32 : c->packed_sp;
-        const int pack_blocks = dirty_s ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
+        const bool slot = use_sp && c->sel_slot >= 0;      // explicitly managed image (mn_iqn_pack_slot / mn_iqn_select_slot): never packed here
+        if (slot) image = c->slot_sp[c->sel_slot];
+        const int pack_blocks = (dirty_s && !slot) ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
         if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
@@ -896,7 +912,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
             if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
             else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
         }
-        dirty_s = false;
+        if (!slot) dirty_s = false;
         if (use_sp32)
             hipLaunchKernelGGL(sp32::iqn_qvals_split32_kernel, dim3(blocks), dim3(512), sp32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
@@ -939,6 +955,56 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         hipLaunchKernelGGL(iqn_qvals_kernel<false>, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                            packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
     if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+extern "C" int mn_iqn_pack_slot(mn_iqn_ctx *c, const float *const *weights, int32_t slot, void *stream) {
+    if (!c || !weights || slot < 0 || slot > 1) return MN_ERR_INVALID;
+    for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MN_ERR_INVALID;
+    if (!c->slot_consts && hipMalloc(reinterpret_cast<void **>(&c->slot_consts), sp::N_CONST * sizeof(float)) != hipSuccess) return MN_ERR_ALLOC;
+    if (!c->slot_sp[slot] && hipMalloc(reinterpret_cast<void **>(&c->slot_sp[slot]), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
+    const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
+                          weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->slot_consts);
+    hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->slot_consts, c->slot_sp[slot]);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+extern "C" int mn_iqn_select_slot(mn_iqn_ctx *c, int32_t slot) {
+    if (!c || slot < -1 || slot > 1 || (slot >= 0 && !c->slot_sp[slot])) return MN_ERR_INVALID;
+    c->sel_slot = slot;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *stream) {
+    if (!c || !weights) return MN_ERR_INVALID;
+    for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MN_ERR_INVALID;
+    const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
+                          weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
+    hipStream_t s = (hipStream_t)stream;
+    if (c->variant == 2 || c->variant == 3) {
+        const bool use_sp32 = c->variant == 3;
+        bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
+        if (dirty_s) {
+            hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
+            if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp32);
+            else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
+            dirty_s = false;
+        }
+    } else {
+        const bool use32 = c->variant == 1;
+        bool &dirty = use32 ? c->dirty32 : c->dirty;
+        if (dirty) {
+            if (use32) hipLaunchKernelGGL(v32::iqn_pack32_kernel, dim3(v32::PACK_BLOCKS), dim3(256), 0, s, w, c->packed32);
+            else hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, c->packed);
+            dirty = false;
+        }
+    }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 

@@ -35,6 +35,7 @@ class ActContext:
             raise _capi.MarineNavHipError(f"mn_iqn_create failed ({rc})")
         self.h = h
         self._sig = None
+        self.variant = self.DEFAULT_VARIANT
         self._ptrs = (C.c_void_p * 14)()
         self._fin = weakref.finalize(self, _capi.lib().mn_iqn_destroy, h)
 
@@ -68,6 +69,34 @@ class ActContext:
         rc = _capi.lib().mn_iqn_set_variant(self.h, int(variant))
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")
+        self.variant = int(variant)
+
+    def set_grid(self, max_workgroups):
+        """0 = one persistent workgroup per CU (default); > 0 = up to that many shorter workgroups, so that other streams'
+        kernels get CUs while an act launch is in flight (C-ABI mn_iqn_set_grid)."""
+        rc = _capi.lib().mn_iqn_set_grid(self.h, int(max_workgroups))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_set_grid failed ({rc})")
+
+    def refresh(self, net):
+        """Rebuild the cached weight image now (current stream) if it is stale -- see mn_iqn_refresh."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_iqn_refresh(self.h, self.weights(net), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_refresh failed ({rc})")
+
+    def pack_slot(self, net, slot):
+        """Build the split-f16 image of the current weights into slot 0 / 1 on the current stream (mn_iqn_pack_slot)."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _capi.lib().mn_iqn_pack_slot(self.h, self.weights(net), int(slot), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_pack_slot failed ({rc})")
+
+    def select_slot(self, slot):
+        """Later act launches read image slot 0 / 1 and never pack; -1 = back to the cached image (mn_iqn_select_slot)."""
+        rc = _capi.lib().mn_iqn_select_slot(self.h, int(slot))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_select_slot failed ({rc})")
 
     def profile_begin(self, max_launches):
         rc = _capi.lib().mn_iqn_profile_begin(self.h, int(max_launches))

@@ -251,6 +251,24 @@ int mn_iqn_weights_changed(mn_iqn_ctx *c);
  *      of 2; measured 4 % slower on MI355X, kept for comparison; quantile output is served by kernel 2).
  * Same network in all four; they differ by float32 rounding only. */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
+/* Grid of the act kernel.  0 (default): at most one PERSISTENT workgroup per CU, each looping over its share of the observations --
+ * the weight image is staged into LDS once per CU, the fastest form when nothing else runs.  max_workgroups > 0: up to that many
+ * workgroups (more than CUs = several rounds of shorter workgroups, e.g. 2048 for 65 536 observations = 4 per wavefront, ~3 % more
+ * time in isolation): CUs are released every few tens of microseconds, so kernels of OTHER streams (the learner's gradient steps,
+ * the env kernels of another batch half) are dispatched in between instead of waiting for the whole act launch.  Results do not
+ * depend on it. */
+int mn_iqn_set_grid(mn_iqn_ctx *c, int32_t max_workgroups);
+/* Rebuilds the cached weight image of the selected acting kernel now, on `stream`, if it is stale (what the first act call after
+ * mn_iqn_weights_changed would do).  For callers that issue act calls of ONE context on several streams: refresh on one stream,
+ * make the others wait for it, and no act call has to write the image. */
+int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *stream);
+/* Two explicitly managed weight images of the split-f16 kernel (variant 2), for a learner that updates the weights on one stream
+ * while act launches of other streams are in flight: mn_iqn_pack_slot builds the image of the CURRENT weights into slot 0 or 1 on
+ * `stream` (stream-ordered after the writer of the weights); mn_iqn_select_slot(slot) makes every later act launch of the context
+ * read that slot (and never pack); -1 returns to the cached image.  The caller orders a slot's pack against the act launches that
+ * read it (events); launches already issued keep the image they were given. */
+int mn_iqn_pack_slot(mn_iqn_ctx *c, const float *const *weights, int32_t slot, void *stream);
+int mn_iqn_select_slot(mn_iqn_ctx *c, int32_t slot);
 
 /* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
  * K = 32 quantile samples + mean over them (model.py:141-191), then argmax and the epsilon-greedy choice.
