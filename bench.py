@@ -281,6 +281,7 @@ def main():
                     help="sub-batches of the envs, each with its own act -> step -> reset chain on its own HIP stream (iqn/overlap.py: the env "
                          "kernels of one half run under the act kernel of the other; timed by the default run as also.two_halves_two_streams); "
                          "1 (default) = one batch on one stream, which keeps one act launch = one vector step for the roofline figure")
+    ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--act-grid", type=int, default=1024, help="with --halves > 1: workgroups of an act launch (mn_iqn_set_grid)")
     args = ap.parse_args()
     if args.precision is None:
@@ -336,6 +337,7 @@ def main():
                          distributed=args.shared_learner and use_dist, act_chunk=args.act_chunk,
                          UPDATE_EVERY=args.update_every, rank=rank if args.shared_learner else 0)
         agent.grad_steps_per_update = args.grad_steps
+        agent.use_fused_graph = args.graph_train
     if agent is not None and args.torch_act:
         agent.use_fused_act = False
     if agent is not None and args.no_train_graph:
@@ -428,6 +430,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    all_reduce_ms = None
+    if use_dist and args.shared_learner:      # the shared learner's collective alone: 35 785-float bucket, back to back (max over ranks)
+        bucket = torch.zeros(35785, dtype=torch.float32, device=device)
+        for _ in range(20):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize(device)
+        tt = torch.tensor([(time.perf_counter() - t1) / 200 * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_ms = float(tt.item())
     also = {}
     if world == 1 and not args.no_also and agent is not None and fused and not roll and not args.torch_train and not args.torch_act:
         if split is not None:      # the extra legs run the one-batch loop on their own handle
@@ -510,6 +525,7 @@ def main():
                 "ablation": bool(_capi.lib().mn_build_info() & 1),     # from the loaded library: False = full kernels
             },
             "grad_steps_per_sec": grad_steps * (1 if args.shared_learner else world) / elapsed,
+            "all_reduce_ms": all_reduce_ms,      # shared learner only: one RCCL all-reduce of the 143 KB gradient bucket, back to back
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             # further configurations timed by THIS run, after the main timed region (N = 1 only): see also_legs()
             "also": also,

@@ -48,6 +48,7 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
         self._act_rng = None                         # the act path's own counter-based tau / exploration draws (fused_act.ActRng)
         self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
+        self.use_fused_graph = False                 # opt-in: the fused gradient steps of one training event as one captured hipGraph (train_steps_from_memory)
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
@@ -220,6 +221,24 @@ class IQNAgent(ReferenceLoopMixin):
             elif path == "hip" and self._train_path == "torch":
                 self._fused.sync_from_optimizer(self.optimizer)
         self._train_path = path
+
+    def train_steps_from_memory(self, n_steps):
+        """`n_steps` x train_from_memory().  With `use_fused_graph` (GPU, fused gradient step) the whole sequence -- every step's
+        forward / backward, reduction, RCCL all-reduce of a shared learner, Adam -- is ONE hipGraph launch (iqn/fused_train.py:
+        graphed_steps): the host enqueues one node instead of 3-4 launches per step, which is what a shared learner's 16 steps per
+        vector step need to stay ahead of the GPU.  Same arithmetic, same generator stream: bit-identical to the eager calls."""
+        if (self.use_fused_graph and self.use_fused_train and self.device.type == "cuda" and n_steps > 1
+                and len(self.memory) >= self.BATCH_SIZE):
+            m = self.memory
+            ft = self._fused_trainer()
+            self._enter_train_path("hip")
+            loss = ft.graphed_steps((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, n_steps)
+            self.grad_steps += n_steps
+            return loss
+        loss = None
+        for _ in range(n_steps):
+            loss = self.train_from_memory()
+        return loss
 
     def train_from_memory(self):
         """`self.train(self.memory.sample())` (agent.py:131-133).  With `use_fused_train` the HIP step gathers its batch
@@ -412,8 +431,7 @@ class IQNAgent(ReferenceLoopMixin):
         loss = None
         if self.current_timestep >= self.learning_starts:
             if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
-                for _ in range(self.grad_steps_per_update):      # 1 = the reference's cadence (agent.py:129-133)
-                    loss = self.train_from_memory()
+                loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
             if self.target_sync_grad_steps is None:
                 if self.learning_timestep % self.target_update_interval == 0:
                     self.soft_update(self.qnetwork_local, self.qnetwork_target)

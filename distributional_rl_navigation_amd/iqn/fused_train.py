@@ -57,6 +57,7 @@ class FusedTrainer:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws, self._ws_batch = None, 0
         self._staged_key = None      # (ring, its version, rows, batch, workspace) the workspace holds a staged next batch for
+        self._graph, self._graph_key = None, None
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
         self.rng_state = torch.tensor([int(agent.memory.gen.initial_seed()) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
                                       device=self.device)
@@ -160,6 +161,34 @@ class FusedTrainer:
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_grad_sampled failed ({rc}): need batch <= 1024 and ring_size >= batch")
         return self._finish_step(batch)
+
+    def graphed_steps(self, ring, ring_size, batch, n_steps):
+        """`n_steps` x step_sampled as ONE hipGraph launch (captured on first use, re-captured when the ring's tensors / size, the
+        batch or n_steps change): forward / backward, reduction, the shared learner's RCCL all-reduce (RCCL kernels are
+        capturable) and Adam of every step, with the generator's counter, the Adam step counter and the hand-off epoch on the
+        device -- a replay continues exactly where eager calls would.  The first step of a graph draws and gathers its batch in the
+        launch (the ring may have been written since the last call), steps 2.. start from the batch their predecessor staged.
+        Returns the loss of the last step.  Bit-identical to the eager sequence (tests)."""
+        states = ring[0]
+        key = (states.data_ptr(), int(ring_size), batch, int(n_steps), bool(self.agent.distributed))
+        if self._graph_key != key:
+            self._graph = None
+            torch.cuda.synchronize(self.device)
+            # warm-up outside the capture would advance the training state: everything the steps need is allocated here instead
+            self._workspace(batch)
+            if batch not in self._idx:
+                self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
+                self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._staged_key = None                  # step 0 draws and gathers in its launch; it stages step 1's batch, and so on
+                for k in range(n_steps):
+                    self.step_sampled(ring, ring_size, batch, ring_version=-1)      # -1: a version no ReplayBuffer ever has
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
+        self._staged_key = None      # the ring may change before the next call; the graph's first step does not use staging anyway
+        weights_changed(self.agent.qnetwork_local)
+        return self.loss[0]
 
     def step(self, ring, idx=None, taus_target=None, taus_local=None):
         """One optimizer step.  `ring` = (states [c,26] f32, actions [c,1] i64, rewards [c,1] f32, next_states [c,26] f32,

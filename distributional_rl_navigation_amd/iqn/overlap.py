@@ -128,8 +128,7 @@ class SplitBatchLoop:
                     if k != L:
                         s.wait_event(self.append_done[k])
                 if train_now:
-                    for _ in range(ag.grad_steps_per_update):
-                        loss = ag.train_from_memory()
+                    loss = ag.train_steps_from_memory(ag.grad_steps_per_update)
                 if sync_now:
                     ag.soft_update(ag.qnetwork_local, ag.qnetwork_target)
                     ag._last_sync_at = ag.grad_steps
@@ -149,8 +148,7 @@ class SplitBatchLoop:
         for ev in self.append_done:
             main.wait_event(ev)
         if train_now:
-            for _ in range(ag.grad_steps_per_update):
-                loss = ag.train_from_memory()
+            loss = ag.train_steps_from_memory(ag.grad_steps_per_update)
         if sync_now:
             ag.soft_update(ag.qnetwork_local, ag.qnetwork_target)
             ag._last_sync_at = ag.grad_steps

@@ -180,3 +180,37 @@ def test_bench_shared_learner_line(torch):
     assert j["config"]["process_group"] == "nccl" and j["config"]["ablation"] is False
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["grad_steps_per_sec"] > 0
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+
+
+def test_graphed_fused_steps_equal_eager_steps_bitwise_plain_and_under_nccl(torch):
+    """`IQNAgent.use_fused_graph`: the 8 gradient steps of a training event -- forward / backward, reduction, (shared learner) the RCCL
+    all-reduce of the flat gradient, Adam, every step -- captured once and replayed as ONE hipGraph launch.  Counters (generator, Adam
+    step, hand-off epoch) live on the device, so three replays continue where eager calls would: losses, parameters, moments,
+    generator state bit-identical to 24 eager steps; checked without a process group and with a single-rank RCCL group, and across a
+    write to the replay ring between two replays."""
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for distributed in (False, True):
+        if distributed:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=torch.device(dev))
+        try:
+            runs = []
+            for graphed in (False, True):
+                ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=512, device=dev, seed=5, distributed=distributed)
+                ag.use_fused_graph = graphed
+                ag.memory.add_batch(*_batch(torch, 7, 300, dev))
+                losses = []
+                for ev in range(3):
+                    if ev == 2:
+                        ag.memory.add_batch(*_batch(torch, 8, 100, dev))      # ring written (and grown): the graph is re-captured
+                    losses.append(float(ag.train_steps_from_memory(8)))
+                ft = ag._fused
+                runs.append((losses, ft.local.clone(), ft.exp_avg_sq.clone(), ft.rng_state.clone(), int(ft.step_dev), ag.grad_steps))
+            (l0, p0, v0, r0, s0, g0), (l1, p1, v1, r1, s1, g1) = runs
+            assert l0 == l1 and torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(r0, r1)
+            assert s0 == s1 == 24 and g0 == g1 == 24 and int(r0[1]) == 24
+        finally:
+            if distributed:
+                dist.destroy_process_group()
