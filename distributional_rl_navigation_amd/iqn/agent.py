@@ -417,7 +417,7 @@ class IQNAgent(ReferenceLoopMixin):
         train_every = self.UPDATE_EVERY if train_every is None else train_every
         per_iter = train_env.n_envs if per_iter is None else per_iter
         actions = self.act_batch(obs, eps, cvar)
-        if obs.is_cuda and hasattr(train_env, "step_append"):
+        if obs.is_cuda and hasattr(train_env, "step_append") and self.n_step == 1:
             # mn_step_append: the step kernel itself writes (obs_t, a, r, obs_t+1 incl. terminal observations, done)
             # into the replay ring -- no separate append launch, obs_t+1 is not re-read
             next_obs, reward, done, info = train_env.step_append(actions, obs, self.memory)

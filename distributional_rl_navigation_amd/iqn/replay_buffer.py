@@ -2,15 +2,21 @@
 
 The reference keeps a deque of python tuples and stacks a batch on every sample; here the
 transitions live in HBM as a ring of tensors and a whole vector step (n_envs transitions) is
-appended with one indexed copy.  n_step = 1 only (the only value the reference ever uses).
+appended with one indexed copy.
+
+n_step > 1 (replay_buffer.py:26-41; never used by the reference's scripts, part of the constructor surface): every
+environment stream keeps its last n_step transitions; once it holds n_step of them each further add emits
+(s_{t-n+1}, a_{t-n+1}, sum_i gamma^i r_{t-n+1+i}, s'_t, done_t) -- the reference's sliding window, which (as there) does
+not restart at episode ends.  Torch ops on the ring's device; the fused `mn_step_append` path stores 1-step transitions
+only, so the agent uses step + `add_vector_step` when n_step > 1.
 """
 import torch
 
 
 class ReplayBuffer:
     def __init__(self, buffer_size, batch_size, device, seed, gamma, n_step=1, state_size=26):
-        if n_step != 1:
-            raise NotImplementedError("n_step > 1 is never used by the reference training scripts")
+        if int(n_step) < 1:
+            raise ValueError("n_step must be >= 1")
         self.device = torch.device(device)
         self.capacity = int(buffer_size)
         self.batch_size = int(batch_size)
@@ -26,6 +32,7 @@ class ReplayBuffer:
         self.dones = torch.zeros(c, 1, dtype=torch.float32, device=self.device)
         self.size = 0
         self.ptr = 0
+        self._hist = None     # n_step > 1: per-stream window of the last n_step transitions
         self.version = 0      # bumped by every write to the ring (a batch the gradient kernels staged from it is then stale)
 
     def add(self, state, action, reward, next_state, done):
@@ -35,10 +42,33 @@ class ReplayBuffer:
                        as_t([reward], torch.float32), as_t(next_state, torch.float32).view(1, -1),
                        as_t([float(done)], torch.float32))
 
+    def _nstep_window(self, states, actions, rewards, next_states, dones):
+        """replay_buffer.py:26-41 for `k` parallel streams (row i of every call belongs to stream i): returns the k n-step
+        transitions this add completes, or None while the windows are still filling."""
+        k = states.shape[0]
+        n = self.n_step
+        h = self._hist
+        if h is None or h["s"].shape[1] != k:
+            h = self._hist = dict(s=torch.zeros(n, k, states.shape[1], dtype=torch.float32, device=self.device),
+                                  a=torch.zeros(n, k, dtype=torch.int64, device=self.device),
+                                  r=torch.zeros(n, k, dtype=torch.float32, device=self.device), count=0)
+        slot = h["count"] % n
+        h["s"][slot].copy_(states); h["a"][slot].copy_(actions.view(-1)); h["r"][slot].copy_(rewards.view(-1))
+        h["count"] += 1
+        if h["count"] < n:
+            return None
+        oldest = h["count"] % n                     # the slot the NEXT add overwrites = the window's first transition
+        ret = torch.zeros(k, dtype=torch.float32, device=self.device)
+        for i in range(n):                          # Return += gamma**idx * reward_idx, in the reference's order
+            ret = ret + (self.gamma ** i) * h["r"][(oldest + i) % n]
+        return h["s"][oldest].clone(), h["a"][oldest].clone(), ret, next_states, dones
+
     def add_vector_step(self, obs, actions_i32, reward, next_obs, done_u8):
         """One vector step of the HIP env (device tensors exactly as VecMarineNavEnv returns them:
         obs / next_obs [n,26] f32, actions [n] i32, reward [n] f32, done [n] u8) appended by ONE kernel
         (csrc/replay.hip); same FIFO semantics as add_batch."""
+        if self.n_step > 1:
+            return self.add_batch(obs, actions_i32.long(), reward, next_obs, done_u8.float())
         import ctypes as C
         from .. import _capi
         n = obs.shape[0]
@@ -58,7 +88,12 @@ class ReplayBuffer:
         self.version += 1
 
     def add_batch(self, states, actions, rewards, next_states, dones):
-        """n transitions at once; FIFO eviction like deque(maxlen)."""
+        """n transitions at once; FIFO eviction like deque(maxlen).  With n_step > 1 row i is the next transition of stream i."""
+        if self.n_step > 1:
+            out = self._nstep_window(states, actions, rewards, next_states, dones)
+            if out is None:
+                return
+            states, actions, rewards, next_states, dones = out
         n = states.shape[0]
         if n > self.capacity:   # only the newest `capacity` survive
             states, actions, rewards, next_states, dones = (t[-self.capacity:] for t in (states, actions, rewards, next_states, dones))
@@ -71,8 +106,12 @@ class ReplayBuffer:
             self.dones[sl, 0].copy_(dones.view(-1))
         else:
             k = self.capacity - self.ptr
-            self.add_batch(states[:k], actions[:k], rewards[:k], next_states[:k], dones[:k])
-            self.add_batch(states[k:], actions[k:], rewards[k:], next_states[k:], dones[k:])
+            n_step, self.n_step = self.n_step, 1      # the two halves are already n-step transitions
+            try:
+                self.add_batch(states[:k], actions[:k], rewards[:k], next_states[:k], dones[:k])
+                self.add_batch(states[k:], actions[k:], rewards[k:], next_states[k:], dones[k:])
+            finally:
+                self.n_step = n_step
             return
         self.ptr = end % self.capacity
         self.size = min(self.capacity, self.size + n)

@@ -21,6 +21,7 @@ Outputs (all small, committed):
   g9_planners.npz       APF / BA baseline actions for 2304 observations
   pretrained_IQN_seed3/ checkpoint data files shipped by the reference (weights only)
   g12_replay.npz        the reference ReplayBuffer: 1500 adds into maxlen 1000, contents, one sample()
+  g15_replay_nstep.npz  the reference ReplayBuffer with n_step = 3: 40 adds into maxlen 25, contents
   g13_learn_loop.npz    bookkeeping of the reference IQNAgent.learn loop over 400 timesteps on the reference env
   g14_iqn_episodes.npz  run_experiments.py's evaluation_IQN loop on the reference env + pretrained agent, injected taus:
                         per-step action / CVaR / quantiles / taus, per-episode outcome and trajectory
@@ -550,6 +551,27 @@ def g12_replay():
     np.savez_compressed(os.path.join(OUT, "g12_replay.npz"), **out)
 
 
+def g15_replay_nstep():
+    """The reference's ReplayBuffer with n_step = 3 (replay_buffer.py:26-41): 40 adds into maxlen 25 -- the sliding window does not
+    restart at `done` -- and the deque afterwards."""
+    _, ReplayBuffer = _import_iqn()
+    rng = np.random.RandomState(15)
+    n_in, cap, n_step, gamma = 40, 25, 3, 0.97
+    S = rng.normal(size=(n_in, 26)); NS = rng.normal(size=(n_in, 26))
+    A = rng.randint(9, size=n_in); R = rng.normal(size=n_in); D = rng.uniform(size=n_in) < 0.2
+    buf = ReplayBuffer(cap, 8, "cpu", seed=5, gamma=gamma, n_step=n_step)
+    sizes = []
+    for i in range(n_in):
+        buf.add(S[i], int(A[i]), float(R[i]), NS[i], bool(D[i]))
+        sizes.append(len(buf))
+    mem = list(buf.memory)
+    np.savez_compressed(os.path.join(OUT, "g15_replay_nstep.npz"), capacity=cap, n_step=n_step, gamma=gamma,
+                        in_states=S, in_actions=A, in_rewards=R, in_next=NS, in_dones=D, sizes=np.array(sizes),
+                        mem_states=np.stack([e.state for e in mem]), mem_actions=np.array([e.action for e in mem]),
+                        mem_rewards=np.array([e.reward for e in mem]), mem_next=np.stack([e.next_state for e in mem]),
+                        mem_dones=np.array([e.done for e in mem]))
+
+
 def g13_learn_loop():
     """The reference's IQNAgent.learn (thirdparty/IQN/agent.py:94-173) run on the reference env for 400 timesteps:
     the trajectory-independent bookkeeping of the loop -- counters, at which learning steps train() / soft_update() /
@@ -676,9 +698,11 @@ def g14_iqn_episodes():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g12", "g13", "g14", "g15"]
     if "g12" in which:
         g12_replay()
+    if "g15" in which:
+        g15_replay_nstep()
     if "g13" in which:
         g13_learn_loop()
     if "g14" in which:

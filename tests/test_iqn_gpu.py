@@ -549,3 +549,17 @@ def test_staged_batch_step_equals_drawn_batch_step_bitwise(torch):
         assert torch.equal(a._fused.local, b._fused.local) and torch.equal(a._fused._idx[256], b._fused._idx[256]), it
         assert torch.equal(a._fused._taus[256], b._fused._taus[256]) and torch.equal(a._fused.rng_state, b._fused.rng_state), it
     assert a._fused._staged_key is not None and b._fused._staged_key is None
+
+
+def test_n_step_agent_runs_the_vector_loop(torch):
+    """IQNAgent(n_step = 3) on the HIP vector env: the loop takes the step + add_vector_step path (the fused append stores 1-step
+    transitions), the ring receives one 3-step transition per env and vector step once the windows are full, the gradient step
+    discounts with gamma^3."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    env = VecMarineNavEnv(256, seed=0, device="cuda:0", precision="f64")
+    ag = IQNAgent(26, 9, n_step=3, BATCH_SIZE=64, BUFFER_SIZE=4096, device="cuda:0", seed=1, learning_starts=0, UPDATE_EVERY=2)
+    stats = ag.learn_vec(total_vector_steps=8, train_env=env, verbose=False)
+    torch.cuda.synchronize()
+    assert len(ag.memory) == 256 * (8 - 2) and ag.grad_steps >= 2 and np.isfinite(float(stats["loss"]))
+    env.close()

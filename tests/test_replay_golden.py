@@ -87,3 +87,32 @@ def test_vector_appends_match_reference_deque_on_device(chunks):
         assert len(buf) == min(CAP, lo)
     _check_contents(buf)
     _check_sample(buf)
+
+
+def test_n_step_returns_match_reference_deque():
+    """n_step = 3 against the reference's own n-step ReplayBuffer (golden G15, replay_buffer.py:26-41): sizes after every add, the
+    surviving transitions (first state / action of the window, discounted 3-step return, last next_state / done), the window sliding
+    across episode ends as the reference's does; then the same stream as stream 0 of a 4-stream vector add."""
+    Z15 = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_replay_nstep.npz"))
+    cap, n_step, gamma = int(Z15["capacity"]), int(Z15["n_step"]), float(Z15["gamma"])
+    buf = ReplayBuffer(cap, 8, "cpu", seed=5, gamma=gamma, n_step=n_step)
+    for i in range(len(Z15["in_actions"])):
+        buf.add(Z15["in_states"][i], int(Z15["in_actions"][i]), float(Z15["in_rewards"][i]), Z15["in_next"][i], bool(Z15["in_dones"][i]))
+        assert len(buf) == Z15["sizes"][i]
+    s, a, r, ns, d = _fifo(buf)
+    assert np.array_equal(s, Z15["mem_states"].astype(np.float32)) and np.array_equal(ns, Z15["mem_next"].astype(np.float32))
+    assert np.array_equal(a[:, 0], Z15["mem_actions"]) and np.array_equal(d[:, 0], Z15["mem_dones"].astype(np.float32))
+    np.testing.assert_allclose(r[:, 0], Z15["mem_rewards"], rtol=0, atol=1e-6)
+    # four parallel streams (a vector env): stream 0 carries the golden stream, the others shifted copies
+    K = 4
+    n_in = len(Z15["in_actions"])
+    vb = ReplayBuffer(K * n_in, 8, "cpu", seed=5, gamma=gamma, n_step=n_step)
+    for i in range(n_in):
+        rows = [(i + 7 * k) % n_in for k in range(K)]
+        vb.add_batch(torch.tensor(Z15["in_states"][rows], dtype=torch.float32), torch.tensor(Z15["in_actions"][rows]),
+                     torch.tensor(Z15["in_rewards"][rows], dtype=torch.float32), torch.tensor(Z15["in_next"][rows], dtype=torch.float32),
+                     torch.tensor(Z15["in_dones"][rows].astype(np.float32)))
+    assert len(vb) == K * (n_in - n_step + 1)
+    got = vb.rewards[0:len(vb):K, 0].numpy()[-cap:]          # stream 0's emissions, newest `cap`
+    np.testing.assert_allclose(got, Z15["mem_rewards"], rtol=0, atol=1e-6)
+    assert np.array_equal(vb.states[0:len(vb):K].numpy()[-cap:], Z15["mem_states"].astype(np.float32))
