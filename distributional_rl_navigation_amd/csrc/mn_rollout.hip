@@ -9,6 +9,11 @@
 // An env that finishes is reset on the spot by its own wavefront (mn_reset_env, mn_reset_body.h: the wave-cooperative
 // world generation of the reset kernel, same code, same bits), so the sequence of T x (mn_step, mn_reset_done) and one
 // mn_rollout are bit-identical in every output, every counter and every RNG stream.
+#ifdef MN_ABLATION
+// [0..5] phases of MnLane::step, [6] trace writes + done ballot, [7] in-kernel resets, [8] steps counted, [9] resets counted
+__device__ unsigned long long g_rollout_phase[16];
+#define MN_PHASE_VAR g_rollout_phase
+#endif
 #include "mn_reset_body.h"
 #include "mn_step_body.h"
 
@@ -74,6 +79,9 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES) void mn_rollout_kern
                                                     PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none, nullptr, nullptr,
                                                     (last && trow) ? trow : nullptr);
         stepped = true;
+#ifdef MN_ABLATION
+        unsigned long long rt_ = __builtin_amdgcn_s_memtime();
+#endif
         if (ln.active && q == 0) {
             const size_t k = (size_t)t * n + e;
             if (T.reward) T.reward[k] = (float)o.reward;
@@ -83,6 +91,9 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES) void mn_rollout_kern
         }
         // in-kernel reset hand-off: the wave resets its finished envs one after the other, all 64 lanes on each
         unsigned long long m = __ballot(ln.active && o.done && q == 0);
+#ifdef MN_ABLATION
+        if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_rollout_phase[6] += t_ - rt_; g_rollout_phase[8] += 1; rt_ = t_; }
+#endif
         if (m) {
             ln.store(A);                       // pose + counters (total_timesteps drives the curriculum lookup)
             while (m) {
@@ -94,6 +105,9 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES) void mn_rollout_kern
             __syncthreads();                   // the reset's global writes are visible to this wave's reload
             ln.load(A, e, q);
             stepped = false;
+#ifdef MN_ABLATION
+            if (tid == 0) { g_rollout_phase[7] += __builtin_amdgcn_s_memtime() - rt_; g_rollout_phase[9] += 1; }
+#endif
         }
     }
     // (an env that was reset by the last step keeps the reset's float64 velocity in the arrays, exactly as after
@@ -129,6 +143,17 @@ void mn_launch_rollout(const MnArrays &A, const MnDev &P, int precision, int lan
     if (precision == MN_PRECISION_F64) launch_rollout<double, true>(lanes, A, P, n_steps, actions_in, seed, step0, env0, obs_out, T, s);
     else launch_rollout<float, false>(lanes, A, P, n_steps, actions_in, seed, step0, env0, obs_out, T, s);
 }
+
+#ifdef MN_ABLATION
+extern "C" int mn_debug_rollout_phases(unsigned long long *out_host, int reset) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_rollout_phase), sizeof(unsigned long long) * 16) != hipSuccess) return MN_ERR_HIP;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rollout_phase), z, sizeof(z)) != hipSuccess) return MN_ERR_HIP;
+    }
+    return MN_OK;
+}
+#endif
 
 void mn_launch_random_actions(uint64_t seed, uint64_t step, uint64_t env0, int n, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(mn_random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, step, env0, n, out);

@@ -30,6 +30,16 @@
 #else
 #define MN_SKIP(bit) false
 #endif
+// Phase stamps of ONE wavefront (workgroup 0), ablation build only and only in a translation unit that defines MN_PHASE_VAR
+// (mn_rollout.hip: scripts/rollout_phase_timing.py): elapsed s_memtime ticks per phase, accumulated over the steps of a launch.
+#if defined(MN_ABLATION) && defined(MN_PHASE_VAR)
+#define MN_TICK_BEGIN() unsigned long long mn_tick_prev = __builtin_amdgcn_s_memtime()
+#define MN_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (blockIdx.x == 0 && threadIdx.x == 0) MN_PHASE_VAR[k] += t_ - mn_tick_prev; mn_tick_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MN_TICK_BEGIN() do { } while (0)
+#define MN_TICK(k) do { } while (0)
+#endif
 
 #ifndef MN_STEP_BLOCK
 #define MN_STEP_BLOCK 64    // threads per workgroup (npad is a multiple of 256, so 64 / 128 / 256 all tile it); measured: same at 65 536 envs, 64 is 4 % faster at 1 M
@@ -166,6 +176,7 @@ struct MnLane {
     __device__ __forceinline__ MnStepOut step(const MnArrays &A, const MnDev &P, int action_raw, float *__restrict__ obs_row,
                                               double *__restrict__ obs_row64, const MnRing &R, const float2 *prev_head,
                                               const float2 *prev_beam, float *__restrict__ obs_row_b = nullptr) {
+        MN_TICK_BEGIN();
         int action = action_raw < 0 ? 0 : (action_raw > 8 ? 8 : action_raw);
 
         // marinenav_env.py:205 dis_before
@@ -189,6 +200,7 @@ struct MnLane {
         double sn = 0.0, cs = 1.0;
         if (!MN_SKIP(4)) sincos(theta, &sn, &cs);
 
+        MN_TICK(0);      // action decode, distance, sincos
         // ---- N kinematic sub-steps (marinenav_env.py:208-212) -------------------------------------
         // The current is the superposition over ALL cores.  Every core's contribution is formed as two
         // rounded products and the eight of them are added in ONE fixed balanced tree -- ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7))
@@ -295,6 +307,7 @@ struct MnLane {
             }
         }
 
+        MN_TICK(1);      // N sub-steps (current field + integration)
         // marinenav_env.py:214 dis_after
         const double dax = gx - x, day = gy - y;
         const double dis_after = sqrt(fma(dax, dax, day * day));
@@ -351,6 +364,7 @@ struct MnLane {
             }
             beam[j].init();
         }
+        MN_TICK(2);      // obstacle rotation, work-list, beam directions
         if (!MN_SKIP(2))
         for (int s_ = 0; __any(s_ < nrel); ++s_) {
             const bool v = s_ < nrel;
@@ -375,6 +389,7 @@ struct MnLane {
             byo[j] = hit ? (M)(td * bdy[j]) : M(0);
         }
 
+        MN_TICK(3);      // sonar scan over the work-list + range re-derivation
         // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
         double reward = P.timestep_penalty;
         reward += dis_before - dis_after;
@@ -390,6 +405,7 @@ struct MnLane {
         ep_t += 1;       // marinenav_env.py:259-260
         tot_t += 1;
 
+        MN_TICK(4);      // reward, termination ladder
         // ---- observation row (+ replay transition) ---------------------------------------------------
         if (active) {
             // replay slot of this env's transition (FIFO ring; only the newest `cap` rows of a launch survive)
@@ -439,6 +455,7 @@ struct MnLane {
                 }
             }
         }
+        MN_TICK(5);      // observation row stores
         MnStepOut o;
         o.reward = reward; o.done = done; o.info = info;
         return o;
