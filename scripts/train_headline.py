@@ -34,8 +34,8 @@ with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "eval
 n = args.envs
 plan = plan_cadence(3_000_000, 10_000, n, args.batch, grad_steps_per_vector_step=max(1, args.grad_steps // args.update_every) if args.grad_steps >= args.update_every else None)
 V = args.vector_steps or (plan["vector_steps"] if args.grad_steps >= args.update_every else int(np.ceil(plan["total_grad_steps"] * args.update_every / args.grad_steps)))
-env = VecMarineNavEnv(n, seed=0, schedule=TRAINING_SCHEDULE, timestep_scale=3_000_000 / V, device="cuda:0")   # whole curriculum over the run
-eval_env = VecMarineNavEnv(30, device="cuda:0")
+env = VecMarineNavEnv(n, seed=0, schedule=TRAINING_SCHEDULE, timestep_scale=3_000_000 / V, device="cuda:0", precision="f64")   # whole curriculum over the run; strict env kernels (the loop default)
+eval_env = VecMarineNavEnv(30, device="cuda:0", precision="f64")
 agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device="cuda:0", seed=args.seed, learning_starts=0,
                  UPDATE_EVERY=args.update_every)
 agent.grad_steps_per_update = args.grad_steps
