@@ -185,9 +185,8 @@ def _load_g3(env, z, lo, hi):
 def test_g3_single_step_golden(torch, precision, atol, rtol, lanes):
     """2048 independent (world, state, action) triples from the Python reference.
     f64: <= 1e-9.  mixed: |err| <= 1e-5 ABSOLUTE on every float32 output (the north-star tolerance; f32 ulp at 50 m is
-    3.8e-6) -- observation, pose, reward -- with at most 2 conditioning outliers (a grazing sonar hit multiplies the
-    float32-velocity pose error by r/h; none observed in this set), discrete outcomes identical except within 1e-5 of a
-    threshold."""
+    3.8e-6) -- observation, pose, reward -- with NO outlier in this set, and identical discrete outcomes (done / info / beam hit
+    or miss): the counts observed on MI355X, asserted as such."""
     z = np.load(os.path.join(G, "g3_single_step.npz"))
     n = len(z["action"])
     env = make_env(n, precision, step_lanes=lanes)   # lanes per env in the step kernel (default 4)
@@ -211,15 +210,16 @@ def test_g3_single_step_golden(torch, precision, atol, rtol, lanes):
         np.testing.assert_allclose(rew, z["reward"], rtol=0, atol=1e-5)  # f32 output
     else:
         mism = np.nonzero(info != z["info"])[0]
-        assert len(mism) <= 2, mism            # razor-edge threshold cases only
+        assert len(mism) == 0, mism            # observed on MI355X (r03): 0 info mismatches, 0 beam flips, 0 outliers, worst error 2.5e-6
         ok = np.ones(n, bool); ok[mism] = False
         # a beam may flip hit/miss when an intersection is within tolerance of the range / tangency
         beam_flip = _miss(obs) != _miss(z["obs"])
-        assert beam_flip.sum() <= 3
+        assert beam_flip.sum() == 0
         keep = np.repeat(~beam_flip, 2, axis=1)
         err = np.abs(obs - z["obs"])
         err[:, 4:][~keep] = 0.0
-        assert (err > atol).sum() <= 2 and err.max() < 1e-4, (int((err > atol).sum()), err.max())
+        print(f"[observed g3 mixed lanes={lanes}] info mismatches {len(mism)}, beam flips {int(beam_flip.sum())}, outliers {int((err > atol).sum())}, worst {err.max():.3e}")
+        assert (err > atol).sum() == 0, (int((err > atol).sum()), err.max())
         np.testing.assert_allclose(st, z["state_out"], rtol=0, atol=1.1e-5)       # velocity near a core edge: |v| ~ 10 m/s in float32
         np.testing.assert_allclose(st[:, :4], z["state_out"][:, :4], rtol=0, atol=atol)
         np.testing.assert_allclose(rew[ok], z["reward"][ok], rtol=0, atol=atol)
@@ -339,8 +339,10 @@ def test_mixed_single_step_vs_oracle_states(torch):
         e64.reset_done()
         # worlds must stay identical: give the mixed env the same resets
         emx.reset(mask=e64.done)
-    assert flips <= 20, flips   # threshold-band cases out of 200*1024*12 decisions
-    assert outliers <= 8 and worst < 1e-4, (outliers, worst)
+    print(f"[observed mixed vs f64] flips {flips}, outliers {outliers}, worst {worst:.3e}")
+    # observed on MI355X (r03): 0 flips, 1 outlier of 1.3e-5 in 5.3 M outputs; the strict float64 kernels (the loop default) have none
+    assert flips == 0, flips
+    assert outliers <= 3 and worst < 5e-5, (outliers, worst)
     w64 = e64.get_worlds(); wmx = emx.get_worlds()
     for a_, b_ in zip(w64, wmx):
         assert_world_equal(a_, b_)
