@@ -84,11 +84,17 @@ class DQNPolicy(nn.Module):
         """QNetwork._predict (dqn/policies.py:69-73): argmax_a Q(obs, a), one int32 per row."""
         return self.q_values(obs).argmax(dim=1).to(torch.int32)
 
+    exploration_rate = 0.05      # sb3 DQN's value after its exploration schedule (exploration_final_eps, dqn/dqn.py:82)
+
     def predict(self, observation, deterministic=True):
-        """sb3 surface used by run_experiments.py:86: `action, _ = agent.predict(obs, deterministic=True)`."""
-        if not deterministic:
-            raise NotImplementedError("only the greedy policy is provided on the batched path")
+        """sb3 surface used by run_experiments.py:86: `action, _ = agent.predict(obs, deterministic=True)`.  With
+        deterministic=False, DQN.predict's epsilon-greedy (dqn/dqn.py:249-257): ONE `np.random.rand()` draw per call decides whether
+        the whole (vector of) observation(s) gets uniformly random actions instead of the greedy ones."""
         obs = torch.as_tensor(np.asarray(observation), dtype=torch.float32)
         single = obs.dim() == 1
+        if not deterministic and np.random.rand() < self.exploration_rate:
+            n = 1 if single else obs.view(-1, self.state_size).shape[0]
+            a = np.array([np.random.randint(self.action_size) for _ in range(n)], dtype=np.int64)
+            return (a[0] if single else a), None
         a = self.act_batch(obs.view(-1, self.state_size)).cpu().numpy().astype(np.int64)
         return (a[0] if single else a), None

@@ -158,10 +158,19 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     return exp_dir
 
 
+def _trial_worker(device, params, n_envs, kw):
+    import torch
+    torch.cuda.set_device(torch.device(device))
+    return run_trial(device, params, n_envs, verbose=False, **kw)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Train IQN model (batched MI355X path)")
     ap.add_argument("-C", "--config-file", dest="config_file", type=open, required=True)
     ap.add_argument("-D", "--device", dest="device", type=str, default=None)
+    ap.add_argument("-P", "--num-procs", dest="num_procs", type=int, default=1,
+                    help="train_IQN_model.py:24-30: run the trials of the config grid (seeds) in this many worker processes at a time; "
+                         "worker i uses GPU i modulo the visible GPUs (several seeds on one MI355X share it).  Not combinable with torch.distributed.run")
     ap.add_argument("--n-envs", type=int, default=65536, help="environments per GPU")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--replay", type=int, default=100_000)
@@ -186,11 +195,26 @@ def main(argv=None):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
     stamp = datetime.now().strftime("%Y-%m-%d-%H-%M-%S")
-    for p in trial_params(params):
+    trials = trial_params(params)
+    for p in trials:
         p["training_time"] = stamp
-        run_trial(device, p, args.n_envs, rank, world, args.shared_learner, args.batch, args.replay,
-                  grad_steps=args.grad_steps, torch_train=args.torch_train, total_grad_steps=args.total_grad_steps,
-                  n_evals=args.n_evals, cvar=args.cvar, precision=args.precision)
+    kw = dict(batch=args.batch, replay=args.replay, grad_steps=args.grad_steps, torch_train=args.torch_train,
+              total_grad_steps=args.total_grad_steps, n_evals=args.n_evals, cvar=args.cvar, precision=args.precision)
+    if args.num_procs > 1:
+        # train_IQN_model.py:173-179: a Pool of workers, one trial each.  `spawn`: every worker gets its own HIP context
+        if world > 1:
+            raise SystemExit("--num-procs runs independent trials; do not combine it with torch.distributed.run")
+        import multiprocessing as mp
+        n_gpu = max(1, torch.cuda.device_count())
+        with mp.get_context("spawn").Pool(processes=args.num_procs) as pool:
+            jobs = [pool.apply_async(_trial_worker, (args.device or f"cuda:{i % n_gpu}", p, args.n_envs, kw)) for i, p in enumerate(trials)]
+            pool.close()
+            for j in jobs:
+                j.get()
+            pool.join()
+        return
+    for p in trials:
+        run_trial(device, p, args.n_envs, rank, world, args.shared_learner, verbose=True, **kw)
     if world > 1:
         dist.destroy_process_group()
 

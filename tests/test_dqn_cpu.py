@@ -27,6 +27,28 @@ def test_q_values_match_reference_network():
     assert a.shape == (7,) and np.array_equal(a, g["action"][:7])
 
 
+def test_stochastic_predict_is_sb3s_epsilon_greedy():
+    """DQN.predict(deterministic=False) (dqn/dqn.py:249-257): one uniform draw per CALL; below exploration_rate every row gets a
+    uniformly random action, otherwise the greedy actions."""
+    g = np.load(os.path.join(G, "g10_dqn.npz"))
+    pol = _policy()
+    np.random.seed(0)
+    greedy = g["action"][:64]
+    explored, hist = 0, np.zeros(9)
+    for _ in range(400):
+        a, state = pol.predict(g["obs"][:64], deterministic=False)
+        assert state is None and a.shape == (64,) and a.min() >= 0 and a.max() < 9
+        if not np.array_equal(a, greedy):
+            explored += 1
+            hist += np.bincount(a, minlength=9)
+    assert 8 <= explored <= 36                     # Binomial(400, 0.05): mean 20
+    assert (hist / hist.sum()).max() < 0.16        # random rows are uniform over the 9 actions
+    pol.exploration_rate = 0.0
+    assert np.array_equal(pol.predict(g["obs"][:64], deterministic=False)[0], greedy)
+    a, _ = pol.predict(g["obs"][0], deterministic=False)
+    assert np.ndim(a) == 0
+
+
 def test_state_dict_names_are_sb3s():
     keys = set(_policy().state_dict().keys())
     z = np.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"))
