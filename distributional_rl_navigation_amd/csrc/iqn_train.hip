@@ -192,6 +192,61 @@ __device__ __forceinline__ void rows_gemm_fixed_a(const float *A, int lda, const
     }
 }
 
+// The same with ONE B tile shared and A column tiles mk0, mk0 + step, ...: st(mk, acc) with acc[r] = C[4 g + r][i] of A tile mk.
+// (Used transposed for the weight gradients: with A = the layer's INPUT tile and B = the output-gradient tile a lane ends up with four
+// consecutive input columns of one output row -- one 16-byte store instead of four scattered 4-byte ones.)
+template <int NT, typename Store>
+__device__ __forceinline__ void rows_gemm_fixed_b(const float *A, int lda, const float *B, int ldb, int mk0, int step, int mk_end,
+                                                  Store st) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float b[4], a[NT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b[s] = B[(4 * g + s) * ldb + i];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int mk = min(mk0 + j * step, mk_end - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[j][s] = A[(4 * g + s) * lda + mk * 16 + i];
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], b[s], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int mk = mk0 + j * step;
+        if (mk < mk_end) st(mk, acc[j]);
+    }
+}
+
+// 16-byte store of a partial-gradient tile row.  MN_PSTORE: 0 = plain (stays dirty in this XCD's L2 until the kernel's end: the
+// 18 MB then drain at the launch boundary), 1 = sc1 (write-through at agent scope), 2 = nt (streaming, the default), 3 = sc0 sc1.
+// Measured per gradient step (scripts/train_variants.py, one GPU, alternating): plain 40.8 us, sc1 39.1, sc0 sc1 39.1, nt 37.0-37.2.
+// All four are ordinary stores as far as visibility goes: the reduction kernel is a later launch.
+#ifndef MN_PSTORE
+#define MN_PSTORE 2
+#endif
+
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc, int float_off, const f32x4 &v) {
+#if MN_PSTORE == 0
+    *reinterpret_cast<f32x4 *>(base + float_off) = v;
+#elif MN_PSTORE == 1
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, 16);
+#elif MN_PSTORE == 2
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, 2);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, 17);
+#endif
+}
+
+// the small rest of a partial row (biases, output layer, encoders: 15 % of it) goes out as plain stores: non-temporal 4-byte
+// stores measured slower (39.4 vs 37.0 us per step), as did non-temporal loads in the reduction (42.8)
+__device__ __forceinline__ void pstore1(float *p, float v) { *p = v; }
+
 // ---- the batch draw ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser (Steele, Lea, Flood 2014)
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
@@ -618,6 +673,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407); every thread evaluates the (cheap) gradient of
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
     float *out = ws + (size_t)part * P_PAD;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int t = tid + THREADS * e, r = t >> 6, k = t & 63, be = r >> 3;
@@ -659,11 +715,11 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             S[S_DH2 + rr * LDC + c] = S[S_H2 + rr * LDC + c] > 0.f ? acc[r] : 0.f;
         }
     } else {
-        // dW3 = dh3^T h2 : 4 x 4 tiles, K = the 16 rows; wave 4 + mo takes the four tiles of output rows 16 mo ..
+        // dW3 = dh3^T h2 : 4 x 4 tiles, K = the 16 rows, computed transposed (h2^T dh3): wave 4 + mo takes output rows 16 mo .. and
+        // ends up with four consecutive input columns per lane and tile
         const int mo = wave - 4;
-        rows_gemm_fixed_a<4>(S + S_DH3 + mo * 16, LDC, S + S_H2, LDC, 0, 1, 4, [&](int nk, const f32x4 &acc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[O_W3 + (mo * 16 + 4 * g + r) * H + nk * 16 + i] = acc[r];
+        rows_gemm_fixed_b<4>(S + S_H2, LDC, S + S_DH3 + mo * 16, LDC, 0, 1, 4, [&](int nk, const f32x4 &acc) {
+            pstore4(out, out_rsrc, O_W3 + (mo * 16 + i) * H + nk * 16 + 4 * g, acc);
         });
     }
     for (int e = tid; e < NA * H + NA + H; e += THREADS) {   // dW4, db4, db3
@@ -672,16 +728,16 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             const int a = e >> 6, k = e & 63;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r] * S[S_H3 + r * LDC + k];
-            out[O_W4 + e] = v;
+            pstore1(out + O_W4 + e, v);
         } else if (e < NA * H + NA) {
             const int a = e - NA * H;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r];
-            out[O_B4 + a] = v;
+            pstore1(out + O_B4 + a, v);
         } else {
             const int k = e - NA * H - NA;
             for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + k];
-            out[O_B3 + k] = v;
+            pstore1(out + O_B3 + k, v);
         }
     }
     __syncthreads();
@@ -698,17 +754,17 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             for (int r = 0; r < 4; ++r) S[S_DX + (4 * g + r) * LDF + (wave + 8) * 16 + i] = acc2[r];
         }
     }
-    {   // ... then dW2 = dh2^T x : 4 x 13 tiles; wave w: output rows 16 (w & 3) .., column tiles (w >> 2), + 2, ...
+    {   // ... then dW2 = dh2^T x : 4 x 13 tiles, computed transposed (x^T dh2; the dh2 tile 16 (w & 3) .. shared by the wave's 6-7 tiles):
+        // acc[r] = dW2[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int mo = wave & 3;
-        rows_gemm_fixed_a<7>(S + S_DH2 + mo * 16, LDC, S + S_X, LDF, wave >> 2, 2, NT1, [&](int nk, const f32x4 &acc) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[O_W2 + (mo * 16 + 4 * g + r) * F + nk * 16 + i] = acc[r];
+        rows_gemm_fixed_b<7>(S + S_X, LDF, S + S_DH2 + mo * 16, LDC, wave >> 2, 2, NT1, [&](int nk, const f32x4 &acc) {
+            pstore4(out, out_rsrc, O_W2 + (mo * 16 + i) * F + nk * 16 + 4 * g, acc);
         });
     }
     if (tid < H) {
         float v = 0.f;
         for (int r = 0; r < ROWS; ++r) v += S[S_DH2 + r * LDC + tid];
-        out[O_B2 + tid] = v;
+        pstore1(out + O_B2 + tid, v);
     }
     __syncthreads();
     PH(11);  /* dx, dW2 */
@@ -732,27 +788,27 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // acc[r] = dW1[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int nk = wave & 3;
         rows_gemm_fixed_a<7>(S + S_C + nk * 16, LDC, S + S_DX, LDF, wave >> 2, 2, NT1, [&](int mo, const f32x4 &acc) {
-            *reinterpret_cast<float4 *>(out + O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            pstore4(out, out_rsrc, O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g, acc);
         });
     }
     if (tid < F) {
         float v = 0.f;
         for (int r = 0; r < ROWS; ++r) v += S[S_DX + r * LDF + tid];
-        out[O_B1 + tid] = v;
+        pstore1(out + O_B1 + tid, v);
     } else if (tid >= 256 && tid < 256 + F) {
         // encoders: dW = df^T obs, db = sum df
         const int o = tid - 256;
         const float d0 = S[S_DF + o], d1 = S[S_DF + F + o];
         const float *x0 = S + S_OBS, *x1 = S + S_OBS + 28;
         if (o < 16) {
-            for (int k = 0; k < 2; ++k) out[O_VW + o * 2 + k] = d0 * x0[k] + d1 * x1[k];
-            out[O_VB + o] = d0 + d1;
+            for (int k = 0; k < 2; ++k) pstore1(out + O_VW + o * 2 + k, d0 * x0[k] + d1 * x1[k]);
+            pstore1(out + O_VB + o, d0 + d1);
         } else if (o < 32) {
-            for (int k = 0; k < 2; ++k) out[O_GW + (o - 16) * 2 + k] = d0 * x0[2 + k] + d1 * x1[2 + k];
-            out[O_GB + o - 16] = d0 + d1;
+            for (int k = 0; k < 2; ++k) pstore1(out + O_GW + (o - 16) * 2 + k, d0 * x0[2 + k] + d1 * x1[2 + k]);
+            pstore1(out + O_GB + o - 16, d0 + d1);
         } else {
-            for (int k = 0; k < 22; ++k) out[O_SW + (o - 32) * 22 + k] = d0 * x0[4 + k] + d1 * x1[4 + k];
-            out[O_SB + o - 32] = d0 + d1;
+            for (int k = 0; k < 22; ++k) pstore1(out + O_SW + (o - 32) * 22 + k, d0 * x0[4 + k] + d1 * x1[4 + k]);
+            pstore1(out + O_SB + o - 32, d0 + d1);
         }
     }
     if (tid < P_PAD - P_TOTAL) out[P_TOTAL + tid] = 0.f;   // row padding: read (as zeros) by the reduction's 16-byte loads
