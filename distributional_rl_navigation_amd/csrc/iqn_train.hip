@@ -309,6 +309,7 @@ struct FwdWeights {
 
 // All loads are unconditional and in one straight line (clamped indices instead of branches): a divergent branch around a load
 // makes hipcc wait for every outstanding load at the join, which would turn the prefetch into a chain of round trips.
+__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const float *__restrict__ P);
 __device__ __forceinline__ void prefetch_forward(FwdWeights &w, const float *__restrict__ P) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
     {   // encoders: thread t < 416 computes feature o = t % 208 of batch element t / 208 (model.py:170-173); a velocity / goal
@@ -327,12 +328,20 @@ __device__ __forceinline__ void prefetch_forward(FwdWeights &w, const float *__r
     }
     // A wave without such a tile requests ONE 16-byte word instead (every lane the same address: a single cache-line request), so that
     // the request stream stays branch-free without fetching the tile twice
-    const int t1b = min(wave + 8, NT1 - 1), t23 = wave & 3;
-    const bool has1b = wave + 8 < NT1, l3 = wave < 4;
+    const int t1b = min(wave + 8, NT1 - 1);
+    const bool has1b = wave + 8 < NT1;
     load_b_kcontig<4>(w.w1a, P + O_W1 + wave * 16 * NC, NC);
     w.b1a = P[O_B1 + wave * 16 + i];
     load_b_kcontig_if<4>(w.w1b, P + O_W1 + t1b * 16 * NC, NC, has1b, P);
     w.b1b = P[has1b ? O_B1 + t1b * 16 + i : 0];
+}
+// ... and the operands of layers 2-4 (60 % of the bytes), requested right AFTER the first barrier: a wave cannot write its
+// transitions to LDS before it has ISSUED every request in front of that write, and issuing 170 KB per CU takes 2.7 us of the load
+// path's time (37.0 -> 36.55 us per step).
+__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const float *__restrict__ P) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
+    const int t23 = wave & 3;
+    const bool l3 = wave < 4;
     load_b_kcontig_if<13>(w.w2, P + O_W2 + t23 * 16 * F, F, l3, P);
     w.b2 = P[l3 ? O_B2 + t23 * 16 + i : 0];
     // waves 0-3: their hidden_layer_2 tile; waves 4-7: the output layer (9 of 16 columns: columns 9..15 read row 8 again and are
@@ -590,6 +599,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
     PH(16);  /* wave 0 has its transitions in LDS */
     __syncthreads();
+    prefetch_forward_late(w, is_target ? PT : PL);
     PH(1);   /* draw + gather + weight requests */
 
     // output-layer row of the action taken, for dh3 (element tid + 512 e of the [16][64] tile: row 8 e + (tid >> 6), column tid & 63,
@@ -660,6 +670,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         }
         FwdWeights wt;
         prefetch_forward(wt, PT);
+        prefetch_forward_late(wt, PT);
         const PassBufs Bt = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
         forward_pass<false>(Bt, wt, S + T_OBS, S + T_TAU, nullptr, nullptr, -2);
         if (tid < ROWS) {
