@@ -17,8 +17,11 @@ __device__ unsigned long long g_rollout_phase[16];
 #include "mn_reset_body.h"
 #include "mn_step_body.h"
 
+// Waves per SIMD the register allocator has to leave room for.  Round 3: with the obstacle tables shared by an env's lane group the
+// 8- and 4-lane kernels need 258-290 registers, i.e. a handful of spills buy a second wave per SIMD: 65 536 envs 2.87 -> 4.07 G env
+// steps/s (4 096 envs, one wave per two SIMDs, unchanged).  The 2-lane kernel (170 registers over) stays at one.
 #ifndef MN_ROLLOUT_MIN_WAVES
-#define MN_ROLLOUT_MIN_WAVES 1
+#define MN_ROLLOUT_MIN_WAVES(L) ((L) >= 4 ? 2 : 1)
 #endif
 
 namespace {
@@ -51,7 +54,7 @@ struct MnTrace {
 };
 
 template <typename M, bool PARITY, int L>
-__global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES) void mn_rollout_kernel(MnArrays A, MnDev P, int n_steps, const int32_t *__restrict__ actions_in,
+__global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES(L)) void mn_rollout_kernel(MnArrays A, MnDev P, int n_steps, const int32_t *__restrict__ actions_in,
                                                              uint64_t seed, uint64_t step0, uint64_t env0,
                                                              float *__restrict__ obs_out, MnTrace T) {
     static_assert(MN_STEP_BLOCK == MN_WAVE, "one wavefront per workgroup: the in-kernel reset is wave-cooperative");

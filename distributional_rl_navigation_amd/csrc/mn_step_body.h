@@ -72,6 +72,30 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {      // the partner lane's value
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+// Nearest obstacle centre of the env over its lane group: minimum of (d2, k) in lexicographic order -- the FIRST obstacle in
+// generation order among equally near ones, as the sequential `d2 < best` scan of check_collision (marinenav_env.py:329-336) --
+// with that obstacle's radius.  Every lane of the group ends up with the group's result.
+template <int CTRL>
+__device__ __forceinline__ void nearest_step(double &d2, double &r2, int &k) {
+    const double od2 = dpp_get<CTRL>(d2), or2 = dpp_get<CTRL>(r2);
+    const int ok = __builtin_amdgcn_update_dpp(0, k, CTRL, 0xF, 0xF, true);
+    const bool take = (od2 < d2) || (od2 == d2 && ok < k);
+    d2 = take ? od2 : d2; r2 = take ? or2 : r2; k = take ? ok : k;
+}
+template <int L>
+__device__ __forceinline__ void group_nearest(double &d2, double &r2, int &k) {
+    if (L >= 2) nearest_step<0xB1>(d2, r2, k);
+    if (L >= 4) nearest_step<0x4E>(d2, r2, k);
+    if (L >= 8) nearest_step<0x141>(d2, r2, k);
+}
+
 // What one step hands back to its caller (all lanes of an env's group hold the same values).
 struct MnStepOut {
     double reward;
@@ -82,26 +106,32 @@ template <typename M, bool PARITY, int L>
 struct MnLane {
     static constexpr int CPL = MN_MAX_CORES / L;            // vortex cores per lane
     static constexpr int BPL = (MN_NUM_BEAMS + L - 1) / L;  // sonar beams per lane
+    static constexpr int OPL = (MN_MAX_OBS + L - 1) / L;    // obstacles per lane: lane q holds obstacles q, q + L, q + 2 L, ...
     static_assert(MN_MAX_CORES % L == 0, "L must divide 8");
+    static_assert(MN_STEP_BLOCK == 64 && L <= 8, "a lane group lives inside one wavefront; the work-list hand-off below relies on it");
 
     int e, q;              // environment, lane within the env's group
     bool active;
     // pose, counters, episode constants
     double x, y, theta, speed, gx, gy;
     M velx, vely;          // velocity of the last sub-step (what the observation reports, App. A K5)
+    double dis_c;          // distance to the goal after the last step of this lane object (= dis_before of the next one: same pose, same
+    bool dis_ok;           // goal, same expression), valid until load(): the rollout loop saves one float64 sqrt per step
     int ep_t, nc, no;
     long long tot_t;
-    // this lane's vortex cores (generation order is irrelevant for a sum) and ALL obstacles (a beam walks the list in
-    // generation order), padded: missing cores are far away with zero circulation, missing obstacles far away with r = 0
+    // this lane's vortex cores (generation order is irrelevant for a sum) and this lane's SHARE of the obstacles (round 3: the
+    // group rotates them into the robot frame together and hands the sonar work-list over in LDS, in generation order), padded:
+    // missing cores are far away with zero circulation, missing obstacles far away with r = 0
     double ccx[CPL], ccy[CPL];
     M cgs[CPL];
-    double obx[MN_MAX_OBS], oby[MN_MAX_OBS], obr[MN_MAX_OBS];
+    double obx[OPL], oby[OPL], obr[OPL];
 
     // Every load is UNCONDITIONAL (rows beyond the placed count hold zeros), so all ~40-70 loads of a lane are in flight
     // together and the kernel pays one memory latency, not a counts -> tables dependent chain.
     __device__ __forceinline__ void load(const MnArrays &A, int env, int lane_in_group) {
         e = env; q = lane_in_group;
         active = e < A.n;
+        dis_c = 0.0; dis_ok = false;
         const int np = A.npad;
         x = A.x[e]; y = A.y[e]; theta = A.theta[e]; speed = A.speed[e];
         velx = (M)A.vx[e]; vely = (M)A.vy[e];
@@ -117,28 +147,30 @@ struct MnLane {
                 ccx[j] = A.cx[k * np + e]; ccy[j] = A.cy[k * np + e]; ccg[j] = A.cg[k * np + e];
             }
 #pragma unroll
-            for (int k = 0; k < MN_MAX_OBS; ++k) {
-                obx[k] = A.ox[k * np + e]; oby[k] = A.oy[k * np + e]; obr[k] = A.orad[k * np + e];
+            for (int j = 0; j < OPL; ++j) {
+                const int k = min(q + L * j, MN_MAX_OBS - 1);
+                obx[j] = A.ox[k * np + e]; oby[j] = A.oy[k * np + e]; obr[j] = A.orad[k * np + e];
             }
         } else {        // compact tables: int32 fixed-point positions (2^-24 m), float32 Gamma / radius
-            int qx[CPL], qy[CPL], px[MN_MAX_OBS], py[MN_MAX_OBS];
-            float qg[CPL], pr[MN_MAX_OBS];
+            int qx[CPL], qy[CPL], px[OPL], py[OPL];
+            float qg[CPL], pr[OPL];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const int k = q * CPL + j;
                 qx[j] = A.qcx[k * np + e]; qy[j] = A.qcy[k * np + e]; qg[j] = A.qcg[k * np + e];
             }
 #pragma unroll
-            for (int k = 0; k < MN_MAX_OBS; ++k) {
-                px[k] = A.qox[k * np + e]; py[k] = A.qoy[k * np + e]; pr[k] = A.qor[k * np + e];
+            for (int j = 0; j < OPL; ++j) {
+                const int k = min(q + L * j, MN_MAX_OBS - 1);
+                px[j] = A.qox[k * np + e]; py[j] = A.qoy[k * np + e]; pr[j] = A.qor[k * np + e];
             }
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 ccx[j] = (double)qx[j] * MN_FIX_INV; ccy[j] = (double)qy[j] * MN_FIX_INV; ccg[j] = (double)qg[j];
             }
 #pragma unroll
-            for (int k = 0; k < MN_MAX_OBS; ++k) {
-                obx[k] = (double)px[k] * MN_FIX_INV; oby[k] = (double)py[k] * MN_FIX_INV; obr[k] = (double)pr[k];
+            for (int j = 0; j < OPL; ++j) {
+                obx[j] = (double)px[j] * MN_FIX_INV; oby[j] = (double)py[j] * MN_FIX_INV; obr[j] = (double)pr[j];
             }
         }
         nc = cnt & 0xff; no = (cnt >> 8) & 0xff;
@@ -150,11 +182,11 @@ struct MnLane {
             cgs[j] = v ? (M)ccg[j] : M(0);
         }
 #pragma unroll
-        for (int k = 0; k < MN_MAX_OBS; ++k) {
-            const bool v = k < no;         // padding: far away, r = 0 -> can never be hit, so the beam
-            obx[k] = v ? obx[k] : 1.0e6;   // loop needs no count test
-            oby[k] = v ? oby[k] : 1.0e6;
-            obr[k] = v ? obr[k] : 0.0;
+        for (int j = 0; j < OPL; ++j) {
+            const bool v = q + L * j < no; // padding: far away, r = 0 -> never relevant, never the nearest
+            obx[j] = v ? obx[j] : 1.0e6;
+            oby[j] = v ? oby[j] : 1.0e6;
+            obr[j] = v ? obr[j] : 0.0;
         }
     }
 
@@ -181,7 +213,8 @@ struct MnLane {
 
         // marinenav_env.py:205 dis_before
         const double dbx = gx - x, dby = gy - y;
-        const double dis_before = sqrt(fma(dbx, dbx, dby * dby));
+        double dis_before = dis_c;
+        if (__any(!dis_ok)) dis_before = sqrt(fma(dbx, dbx, dby * dby));      // (bitwise the cached value where that one is valid)
 
         // robot.py:55-56: actions[i] = (a[i // 3], w[i % 3])
         const int ai = action / 3, wi = action - 3 * ai;
@@ -311,6 +344,7 @@ struct MnLane {
         // marinenav_env.py:214 dis_after
         const double dax = gx - x, day = gy - y;
         const double dis_after = sqrt(fma(dax, dax, day * day));
+        dis_c = dis_after; dis_ok = true;
 
         // ---- observation (marinenav_env.py:273-326) ------------------------------------------------
         // Obstacle centres in the robot frame, m_r = R(theta)^T (c - p) (|m_r| = |c - p|), and at the same
@@ -320,29 +354,44 @@ struct MnLane {
         // hit nor trigger the reference's `break`; the scan over the list is therefore equivalent to the
         // scan over all obstacles (robot.py:147-198).  Typically 0-3 of the 10 obstacles survive, and the
         // beam loop runs to the longest list in the wavefront instead of 10.
-        __shared__ double lst_x[MN_MAX_OBS][MN_STEP_BLOCK], lst_y[MN_MAX_OBS][MN_STEP_BLOCK];
-        __shared__ M lst_r[MN_MAX_OBS][MN_STEP_BLOCK];     // radius: float32 is exact for the compact tables, float64 in parity mode
-        const int tl = threadIdx.x;
+        // Round 3: the lanes of an env's group SHARE this work -- lane q rotates obstacles q, q + L, ... (10 / L of them instead of
+        // all 10: the float64 rotation was 29 % of a rollout step, profiles/r03_rollout_phase_timing.txt) and appends the relevant ones
+        // to ONE list per env; an obstacle's slot is the number of relevant obstacles before it in generation order, counted from the
+        // wavefront's ballots (lane q of iteration j owns obstacle q + L j, so a group's L ballot bits of iteration j are L
+        // consecutive obstacles).  Values are computed by the same expressions whichever lane owns an obstacle, the list order is the
+        // generation order: results do not depend on L, bit for bit (tests).
+        constexpr int NGRP = MN_STEP_BLOCK / L;
+        __shared__ double lst_x[MN_MAX_OBS][NGRP], lst_y[MN_MAX_OBS][NGRP];
+        __shared__ M lst_r[MN_MAX_OBS][NGRP];     // radius: float32 is exact for the compact tables, float64 in parity mode
+        const int tl = threadIdx.x / L;
+        const int gshift = (threadIdx.x & 63) & ~(L - 1);           // first lane of this env's group in the wavefront
         int nrel = 0;
-        double best = 1e300, best_r2 = 0.0;   // check_collision (:329-336): nearest-CENTRE obstacle only
+        double best = 1e300, best_r = 0.0;    // check_collision (:329-336): nearest-CENTRE obstacle only
+        int best_k = 1 << 20;
         const double reach0 = P.sonar_range + 0.05;
         if (!MN_SKIP(8))
 #pragma unroll
-        for (int k = 0; k < MN_MAX_OBS; ++k) {
-            const double mx = obx[k] - x, my = oby[k] - y;
+        for (int j = 0; j < OPL; ++j) {
+            const int k = q + L * j;
+            const double mx = obx[j] - x, my = oby[j] - y;
             const double rx_ = fma(cs, mx, sn * my), ry_ = fma(cs, my, -(sn * mx));
             const double d2 = fma(mx, mx, my * my);
             const bool in = k < no;
-            const bool nearer = in && (d2 < best);
+            const bool nearer = in && (d2 < best);      // within a lane k grows with j: first of equals wins
             best = nearer ? d2 : best;
-            best_r2 = nearer ? obr[k] * obr[k] : best_r2;
-            const double r = obr[k];
+            best_r = nearer ? obr[j] : best_r;
+            best_k = nearer ? k : best_k;
+            const double r = obr[j];
             const double reach = reach0 + r;
             const bool rel = in && (d2 <= reach * reach) &&
                              (!P.fan_filter || (fma(P.fan_sin, rx_, -(P.fan_cos * fabs(ry_))) >= -(r + 0.05)));
-            if (rel) { lst_x[nrel][tl] = rx_; lst_y[nrel][tl] = ry_; lst_r[nrel][tl] = (M)r; }
-            nrel += rel ? 1 : 0;
+            const unsigned gbits = (unsigned)(__ballot(rel) >> gshift) & ((1u << L) - 1u);     // obstacles L j .. L j + L - 1 of this env
+            const int pos = nrel + __popc(gbits & ((1u << q) - 1u));
+            if (rel) { lst_x[pos][tl] = rx_; lst_y[pos][tl] = ry_; lst_r[pos][tl] = (M)r; }
+            nrel += __popc(gbits);
         }
+        group_nearest<L>(best, best_r, best_k);
+        if (L > 1) __syncthreads();      // (one wavefront per workgroup) the list entries other lanes wrote are visible
         const M range = (M)P.sonar_range;
         const double half_pi = 0.5 * 3.141592653589793, three_half_pi = 3 * 3.141592653589793 / 2;
         M bxo[BPL], byo[BPL];   // this lane's beams, hit point in the robot frame
@@ -393,7 +442,13 @@ struct MnLane {
         // ---- reward + termination ladder (marinenav_env.py:220-257) -------------------------------
         double reward = P.timestep_penalty;
         reward += dis_before - dis_after;
-        const bool collide = no > 0 && sqrt(best) <= sqrt(best_r2) + P.robot_r;   // sqrt(r*r) == r exactly
+        // check_collision: sqrt(d2) <= r + robot_r.  sqrt is monotone and rounds within an ulp, so the comparison of the squares
+        // decides it whenever d2 is not within 2^-48 (relative) of the squared threshold; only then is the square root taken
+        // (wave-uniform branch, practically never) -- same truth value in every case, one float64 sqrt less per step.
+        const double thr = best_r + P.robot_r, thr2 = thr * thr;
+        bool near_enough = best <= thr2;
+        if (__any(fabs(best - thr2) <= thr2 * 0x1p-48)) near_enough = sqrt(best) <= thr;
+        const bool collide = no > 0 && near_enough;
         const bool reach = dis_after <= P.goal_dis;  // check_reach_goal (:338-342)
         const bool out = (x < 0.0 || x > P.width) || (y < 0.0 || y > P.height);
         int done, info;
