@@ -40,7 +40,7 @@ ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_m
 # 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
 # fused step + replay append kernel of the training loop, rollout = mn_rollout at 4 096 envs x 100 steps per launch
 # (profiles/r02_full_loop_kernel_stats.txt, profiles/r02_configs1_rollout.txt)
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 85.6e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 61.8e6}
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 84.2e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 61.8e6}
 # mn_step_append also moves the transition into the replay ring: + 104 B (obs_t row read) + 2 x 104 + 8 + 4 + 4 B written
 APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
@@ -279,8 +279,10 @@ def main():
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     ap.add_argument("--halves", type=int, default=1,
                     help="sub-batches of the envs, each with its own act -> step -> reset chain on its own HIP stream (iqn/overlap.py: the env "
-                         "kernels of one half run under the act kernel of the other; timed by the default run as also.two_halves_two_streams); "
-                         "1 (default) = one batch on one stream, which keeps one act launch = one vector step for the roofline figure")
+                         "kernels of one half run under the act kernel of the other; timed by the default run as also.two_halves_two_streams: "
+                         "+5-7 %% env steps/s).  1 (default) = one batch on one stream: one act launch = one vector step, so the launch duration "
+                         "behind `roofline` is that of a kernel that has the GPU to itself (with two streams the two halves' act kernels "
+                         "overlap each other and a per-launch duration no longer measures the kernel)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--act-grid", type=int, default=1024, help="with --halves > 1: workgroups of an act launch (mn_iqn_set_grid)")
     args = ap.parse_args()
@@ -510,7 +512,8 @@ def main():
                 "workload": ((f"step kernel only, random policy, {roll} vector steps per launch (mn_rollout: in-kernel actions + resets, traces: {','.join(trace) or 'none'})"
                               if roll else "step kernel only, random policy, one mn_step + mn_reset_done launch pair per vector step") if agent is None else
                              f"{n} envs/GPU + IQN training (act K=32, 8 quantiles, replay {args.replay}, batch {args.batch}, "
-                             f"{args.grad_steps} grad step(s) every {args.update_every} vector steps)"),
+                             f"{args.grad_steps} grad step(s) every {args.update_every} vector steps)"
+                             + (f"; the envs of a GPU stepped as {H} sub-batches of {n // H} on {H} HIP streams" if H > 1 else "")),
                 "envs_per_gpu": n, "n_cores": args.cores, "n_obstacles": args.obstacles,
                 "learner": "none" if agent is None else ("shared, RCCL grad all-reduce" if args.shared_learner else "independent per GPU"),
                 "cvar": args.cvar,
@@ -531,7 +534,8 @@ def main():
             "also": also,
             "roofline_env_step": {
                 "precision": args.precision,
-                "kernel": "mn_rollout_kernel<float,false,L>" if roll else ("mn_step_kernel<float,false,L,APPEND=true> (step + replay append)" if fused_append else "mn_step_kernel<float,false,L>"),
+                "kernel": (lambda t_: f"mn_rollout_kernel<{t_},L>" if roll else (f"mn_step_kernel<{t_},L,APPEND=true> (step + replay append)" if fused_append else f"mn_step_kernel<{t_},L>"))
+                          ("float,false" if args.precision == "mixed" else "double,true"),
                 "env_steps_per_launch": per_launch,
                 "bound": "hbm",
                 "achieved": achieved,
@@ -552,12 +556,13 @@ def main():
             },
         }
         if fused and act_ms > 0:
-            alg_tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
+            n_act = n // H      # envs per act launch
+            alg_tf = ACT_FLOP_PER_ENV_STEP * n_act / (act_ms * 1e-3) / 1e12
             if args.act_variant in (2, 3):
                 # split-f16 kernel: the matrix pipe executes three f16 MFMAs per float32 product; `achieved` counts the FLOPs it
                 # ISSUES (incl. the 3x and the K padding) against the f16 dense peak, i.e. the fraction of the pipe that is busy
                 issued = ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else 198 * 32768
-                tf = issued * n / (act_ms * 1e-3) / 1e12
+                tf = issued * n_act / (act_ms * 1e-3) / 1e12
                 kern = ("iqn_qvals_split_kernel (3 x v_mfma_f32_16x16x32_f16 per f32 product, f32-class accuracy)" if args.act_variant == 2 else
                         "iqn_qvals_split32_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, f32-class accuracy)")
                 peak = F16_MFMA_PEAK_TFLOPS
@@ -572,13 +577,13 @@ def main():
                 # `frac_algorithmic` is SURVEY 8d's figure: the network's 2 002 944 FLOP per env-step over the same peak
                 "frac_algorithmic": alg_tf / peak,
                 "traffic": None,      # HBM bytes are not counted live; the rocprofv3 PMC figure of the same kernel is next to it
-                "traffic_from_profile": {"bytes_per_launch": PMC_TRAFFIC_BYTES["act_split" if args.act_variant in (2, 3) else "act"] if n == 65536 else None,
+                "traffic_from_profile": {"bytes_per_launch": PMC_TRAFFIC_BYTES["act_split" if args.act_variant in (2, 3) else "act"] if n_act == 65536 else None,
                                          "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch: observations + taus in, actions out), "
                                                    + ("profiles/r03_full_loop_kernel_stats.txt" if args.act_variant in (2, 3) else "profiles/r01_full_loop_kernel_stats.txt")},
                 "issued_mfma_flop_per_env_step": ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP if args.act_variant == 2 else (198 * 32768 if args.act_variant == 3 else ACT_FLOP_PER_ENV_STEP),
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
                 "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,
-                "launch_ms": act_ms, "launches_timed": act_launches,
+                "launch_ms": act_ms, "launches_timed": act_launches, "env_steps_per_launch": n_act,
             }
         else:
             out["roofline"] = out["roofline_env_step"]

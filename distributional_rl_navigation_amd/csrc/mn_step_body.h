@@ -41,6 +41,10 @@
 #define MN_TICK(k) do { } while (0)
 #endif
 
+// Put inside a wave-uniform `if`: keeps hipcc from if-converting it (it would evaluate the guarded float64 square root on every
+// step and select afterwards, which is exactly what the guard is there to avoid).
+#define MN_REAL_BRANCH() asm volatile("" ::: "memory")
+
 #ifndef MN_STEP_BLOCK
 #define MN_STEP_BLOCK 64    // threads per workgroup (npad is a multiple of 256, so 64 / 128 / 256 all tile it); measured: same at 65 536 envs, 64 is 4 % faster at 1 M
 #endif
@@ -214,7 +218,10 @@ struct MnLane {
         // marinenav_env.py:205 dis_before
         const double dbx = gx - x, dby = gy - y;
         double dis_before = dis_c;
-        if (__any(!dis_ok)) dis_before = sqrt(fma(dbx, dbx, dby * dby));      // (bitwise the cached value where that one is valid)
+        if (__any(!dis_ok)) {      // (bitwise the cached value where that one is valid)
+            MN_REAL_BRANCH();
+            dis_before = sqrt(fma(dbx, dbx, dby * dby));
+        }
 
         // robot.py:55-56: actions[i] = (a[i // 3], w[i % 3])
         const int ai = action / 3, wi = action - 3 * ai;
@@ -447,16 +454,20 @@ struct MnLane {
         // (wave-uniform branch, practically never) -- same truth value in every case, one float64 sqrt less per step.
         const double thr = best_r + P.robot_r, thr2 = thr * thr;
         bool near_enough = best <= thr2;
-        if (__any(fabs(best - thr2) <= thr2 * 0x1p-48)) near_enough = sqrt(best) <= thr;
+        if (__any(fabs(best - thr2) <= thr2 * 0x1p-48)) {
+            MN_REAL_BRANCH();
+            near_enough = sqrt(best) <= thr;
+        }
         const bool collide = no > 0 && near_enough;
         const bool reach = dis_after <= P.goal_dis;  // check_reach_goal (:338-342)
         const bool out = (x < 0.0 || x > P.width) || (y < 0.0 || y > P.height);
-        int done, info;
-        if (P.set_boundary && out) { done = 1; info = MN_INFO_OUT_OF_BOUNDARY; }
-        else if (ep_t >= P.max_episode_steps) { done = 1; info = MN_INFO_TOO_LONG; }
-        else if (collide) { reward += P.collision_penalty; done = 1; info = MN_INFO_COLLISION; }
-        else if (reach) { reward += P.goal_reward; done = 1; info = MN_INFO_REACH_GOAL; }
-        else { done = 0; info = MN_INFO_NORMAL; }
+        // the ladder as selects, lowest priority first (a chain of divergent branches costs more than its five selects)
+        int info = reach ? MN_INFO_REACH_GOAL : MN_INFO_NORMAL;
+        info = collide ? MN_INFO_COLLISION : info;
+        info = ep_t >= P.max_episode_steps ? MN_INFO_TOO_LONG : info;
+        info = (P.set_boundary && out) ? MN_INFO_OUT_OF_BOUNDARY : info;
+        const int done = info != MN_INFO_NORMAL;
+        reward = info == MN_INFO_COLLISION ? reward + P.collision_penalty : (info == MN_INFO_REACH_GOAL ? reward + P.goal_reward : reward);
         ep_t += 1;       // marinenav_env.py:259-260
         tot_t += 1;
 

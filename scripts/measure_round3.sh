@@ -7,15 +7,22 @@ python bench.py --halves 2 --cpu-steps 0 --no-also --no-learner-only > $O/bench_
 python scripts/train_headline.py --update-every 1 --grad-steps 16 --seconds 40 > $O/train_g16.txt 2>&1
 python scripts/learner_bench.py 3000 > $O/learner_bench.txt 2>&1
 python scripts/train_phase_timing.py 256 300 > $O/train_phases.txt 2>&1
+# configs[1]: where a rollout step goes (ablation build, s_memtime stamps) and the rollout / single-launch rates against the batch size
+for a in "4096 0" "4096 4" "4096 2" "65536 0"; do python scripts/rollout_phase_timing.py $a 2>&1 | grep -v amdgpu.ids; done > $O/rollout_phases.txt
+for n in 4096 16384 65536 262144; do
+  python bench.py --no-learner --envs $n --steps 500 --warmup 100 --rollout 100 --cpu-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('mn_rollout T=100, $n envs:', round(d['value']/1e6,1), 'M env steps/s, frac of HBM roofline', round(d['roofline']['frac'],4))"
+  python bench.py --no-learner --envs $n --steps 300 --warmup 50 --cpu-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('mn_step + mn_reset_done per launch pair, $n envs:', round(d['value']/1e6,1), 'M env steps/s,', round(d['ms_per_step']*1e3,1), 'us per vector step')"
+done > $O/rollout_scaling.txt 2>&1
+python bench.py --no-learner --envs 4096 --steps 1000 --warmup 250 --rollout 250 --cpu-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('mn_rollout T=250, 4096 envs:', round(d['value']/1e6,1), 'M env steps/s')" >> $O/rollout_scaling.txt
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_loop -- python $R/bench.py --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also > $O/prof_loop.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_loop -- python $R/bench.py --halves 1 --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also > $O/prof_loop.log 2>&1
 python $R/scripts/prof_summary.py $(find $O/prof_loop -name "*kernel_stats.csv" | head -1) 14 > $O/prof_loop_summary.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_g16 -- python $R/bench.py --steps 60 --warmup 10 --cpu-steps 0 --no-learner-only --no-also --update-every 1 --grad-steps 16 --eps 0.05 > $O/prof_g16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_g16 -- python $R/bench.py --halves 1 --steps 60 --warmup 10 --cpu-steps 0 --no-learner-only --no-also --update-every 1 --grad-steps 16 --eps 0.05 > $O/prof_g16.log 2>&1
 python $R/scripts/prof_summary.py $(find $O/prof_g16 -name "*kernel_stats.csv" | head -1) 14 > $O/prof_g16_summary.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_h2 -- python $R/bench.py --halves 2 --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also > $O/prof_h2.log 2>&1
 python $R/scripts/prof_summary.py $(find $O/prof_h2 -name "*kernel_stats.csv" | head -1) 14 > $O/prof_h2_summary.txt
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 24 --warmup 8 --cpu-steps 0 --no-learner-only --no-also --update-every 1 --grad-steps 4 > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --halves 1 --steps 24 --warmup 8 --cpu-steps 0 --no-learner-only --no-also --update-every 1 --grad-steps 4 > $O/pmc_$c.log 2>&1
   python $R/scripts/pmc_agg.py $(find $O/pmc_$c -name "*counter_collection.csv" | head -1) >> $O/pmc_summary.txt
 done
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete; du -sh $O
