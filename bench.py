@@ -326,7 +326,7 @@ def main():
     n = args.envs
     min_dis = {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0)
     H = args.halves if (not args.no_learner and not args.torch_act and not args.separate_append and n % max(1, args.halves) == 0) else 1
-    envs = [VecMarineNavEnv(n // H, seed=0, first_index=rank * n + h * (n // H), device=device, precision=args.precision, step_lanes=args.lanes,
+    envs = [VecMarineNavEnv(n // H, seed=0, first_index=rank * n + h * (n // H), device=device, precision=args.precision, step_lanes=args.lanes if args.lanes in (1, 2, 4, 8) else 0,
                             rollout_lanes=args.lanes if args.lanes != 1 else 0) for h in range(H)]
     for e_ in envs:
         e_.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis=min_dis, N=args.robot_n)

@@ -87,7 +87,7 @@ static int derive(mn_handle *h, const mn_params &p) {
     if (p.N < 1 || p.N > 1000) return fail(h, MN_ERR_INVALID, "robot N out of range");
     if (p.precision != MN_PRECISION_F64 && p.precision != MN_PRECISION_MIXED) return fail(h, MN_ERR_INVALID, "bad precision");
     if (p.step_lanes != 0 && p.step_lanes != 1 && p.step_lanes != 2 && p.step_lanes != 4 && p.step_lanes != 8) return fail(h, MN_ERR_INVALID, "step_lanes must be 0 (default), 1, 2, 4 or 8");
-    if (p.rollout_lanes != 0 && p.rollout_lanes != 2 && p.rollout_lanes != 4 && p.rollout_lanes != 8) return fail(h, MN_ERR_INVALID, "rollout_lanes must be 0 (default), 2, 4 or 8");
+    if (p.rollout_lanes != 0 && p.rollout_lanes != 2 && p.rollout_lanes != 4 && p.rollout_lanes != 8 && p.rollout_lanes != 16) return fail(h, MN_ERR_INVALID, "rollout_lanes must be 0 (default), 2, 4, 8 or 16");
     MnDev &d = h->P;
     const int32_t keep_n = d.n_stages;
     d.width = p.width; d.height = p.height; d.core_r = p.core_r; d.v_rel_max = p.v_rel_max; d.p = p.p;

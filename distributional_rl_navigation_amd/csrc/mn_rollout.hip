@@ -21,7 +21,7 @@ __device__ unsigned long long g_rollout_phase[16];
 // 8- and 4-lane kernels need 258-290 registers, i.e. a handful of spills buy a second wave per SIMD: 65 536 envs 2.87 -> 4.07 G env
 // steps/s (4 096 envs, one wave per two SIMDs, unchanged).  The 2-lane kernel (170 registers over) stays at one.
 #ifndef MN_ROLLOUT_MIN_WAVES
-#define MN_ROLLOUT_MIN_WAVES(L) ((L) >= 4 ? 2 : 1)
+#define MN_ROLLOUT_MIN_WAVES(L) ((L) == 4 || (L) == 8 ? 2 : 1)
 #endif
 
 namespace {
@@ -125,13 +125,17 @@ void launch_rollout(int lanes, const MnArrays &A, const MnDev &P, int n_steps, c
     hipLaunchKernelGGL((mn_rollout_kernel<M, PARITY, LL>), dim3((unsigned)((size_t)A.npad * LL / MN_WAVE)), dim3(MN_WAVE), 0, s, \
                        A, P, n_steps, actions_in, seed, step0, env0, obs_out, T)
     // Default: a rollout launch is latency-bound per wave (T dependent steps), so small batches want many lanes per env
-    // -- 8 lanes up to 16 K envs (4 096 envs = 512 waves on 1024 SIMDs) -- and large ones less total work.  There is no
+    // -- 16 lanes up to 4 096 envs, 8 up to 16 K -- and large ones less total work.  There is no
     // 1-lane variant: with 64 envs' tables resident per wave next to the reset code it needs more than the 512 registers
     // a lane can have (the compiler spills to scratch), and batches that large are better served by mn_step launches.
-    if (lanes == 0) lanes = A.n <= 16384 ? 8 : (A.n <= 65536 ? 4 : 2);
+    // Round 3: 16 lanes per env while that still leaves at most one wave per SIMD (4 096 envs = 1 024 waves): four envs per wave, so half
+    // the in-kernel resets a wave has to sit through, one obstacle and one beam per lane (4 096 envs: 794 -> 897 M env steps/s; at 8 192
+    // envs 8 lanes are faster again, 1 542 vs 1 482 M).
+    if (lanes == 0) lanes = A.n <= 4096 ? 16 : (A.n <= 16384 ? 8 : (A.n <= 65536 ? 4 : 2));
     switch (lanes) {
         case 2: MN_LAUNCH(2); break;
         case 4: MN_LAUNCH(4); break;
+        case 16: MN_LAUNCH(16); break;
         default: MN_LAUNCH(8); break;
     }
 #undef MN_LAUNCH

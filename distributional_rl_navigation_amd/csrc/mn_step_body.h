@@ -55,10 +55,18 @@ __device__ __forceinline__ float group_sum(float v) {
     if (L >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
     if (L >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     if (L >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    if (L >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+    // 16 lanes per env: lanes 8-15 of a group hold the SAME eight cores as lanes 0-7 (MnLane::load), so each half forms the identical sum
+    // by the identical tree and no fourth stage exists -- the value is bit-identical to L <= 8 and the sub-step chain is no longer
     return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {      // the partner lane's value
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
 template <int L, int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
     const long long b = __builtin_bit_cast(long long, v);
@@ -72,17 +80,9 @@ __device__ __forceinline__ double group_sum(double v) {
     if (L >= 2) v = dpp_add<L, 0xB1>(v);
     if (L >= 4) v = dpp_add<L, 0x4E>(v);
     if (L >= 8) v = dpp_add<L, 0x141>(v);
-    if (L >= 16) v = dpp_add<L, 0x140>(v);
-    return v;
+    return v;      // (L = 16: see the float overload)
 }
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_get(double v) {      // the partner lane's value
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
-}
 // Nearest obstacle centre of the env over its lane group: minimum of (d2, k) in lexicographic order -- the FIRST obstacle in
 // generation order among equally near ones, as the sequential `d2 < best` scan of check_collision (marinenav_env.py:329-336) --
 // with that obstacle's radius.  Every lane of the group ends up with the group's result.
@@ -98,6 +98,7 @@ __device__ __forceinline__ void group_nearest(double &d2, double &r2, int &k) {
     if (L >= 2) nearest_step<0xB1>(d2, r2, k);
     if (L >= 4) nearest_step<0x4E>(d2, r2, k);
     if (L >= 8) nearest_step<0x141>(d2, r2, k);
+    if (L >= 16) nearest_step<0x140>(d2, r2, k);
 }
 
 // What one step hands back to its caller (all lanes of an env's group hold the same values).
@@ -108,11 +109,11 @@ struct MnStepOut {
 
 template <typename M, bool PARITY, int L>
 struct MnLane {
-    static constexpr int CPL = MN_MAX_CORES / L;            // vortex cores per lane
+    static constexpr int CPL = L <= MN_MAX_CORES ? MN_MAX_CORES / L : 1;   // vortex cores per lane (L = 16: lanes 8-15 of a group repeat lanes 0-7's)
     static constexpr int BPL = (MN_NUM_BEAMS + L - 1) / L;  // sonar beams per lane
     static constexpr int OPL = (MN_MAX_OBS + L - 1) / L;    // obstacles per lane: lane q holds obstacles q, q + L, q + 2 L, ...
-    static_assert(MN_MAX_CORES % L == 0, "L must divide 8");
-    static_assert(MN_STEP_BLOCK == 64 && L <= 8, "a lane group lives inside one wavefront; the work-list hand-off below relies on it");
+    static_assert(MN_MAX_CORES % L == 0 || L == 16, "L must divide 8, or be 16");
+    static_assert(MN_STEP_BLOCK == 64 && L <= 16, "a lane group lives inside one wavefront (and one DPP row); the work-list hand-off below relies on it");
 
     int e, q;              // environment, lane within the env's group
     bool active;
@@ -147,7 +148,7 @@ struct MnLane {
         if (PARITY) {   // float64 master tables
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
-                const int k = q * CPL + j;
+                const int k = (q & (MN_MAX_CORES - 1)) * CPL + j;
                 ccx[j] = A.cx[k * np + e]; ccy[j] = A.cy[k * np + e]; ccg[j] = A.cg[k * np + e];
             }
 #pragma unroll
@@ -160,7 +161,7 @@ struct MnLane {
             float qg[CPL], pr[OPL];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
-                const int k = q * CPL + j;
+                const int k = (q & (MN_MAX_CORES - 1)) * CPL + j;
                 qx[j] = A.qcx[k * np + e]; qy[j] = A.qcy[k * np + e]; qg[j] = A.qcg[k * np + e];
             }
 #pragma unroll
@@ -180,7 +181,7 @@ struct MnLane {
         nc = cnt & 0xff; no = (cnt >> 8) & 0xff;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            const bool v = q * CPL + j < nc;
+            const bool v = (q & (MN_MAX_CORES - 1)) * CPL + j < nc;
             ccx[j] = v ? ccx[j] : 1.0e6;   // padding: far away, zero circulation
             ccy[j] = v ? ccy[j] : 1.0e6;
             cgs[j] = v ? (M)ccg[j] : M(0);

@@ -45,7 +45,7 @@ def _same_state(a, b):
 
 
 @pytest.mark.parametrize("precision", ["f64", "mixed"])
-@pytest.mark.parametrize("n,T,rl,sl", [(700, 120, 0, 0), (700, 120, 2, 8), (700, 120, 4, 1), (700, 120, 8, 2), (64, 300, 8, 4), (5000, 40, 0, 0), (20000, 12, 0, 0)])
+@pytest.mark.parametrize("n,T,rl,sl", [(700, 120, 0, 0), (700, 120, 2, 8), (700, 120, 4, 1), (700, 120, 8, 2), (700, 120, 16, 2), (64, 300, 16, 4), (64, 300, 8, 4), (5000, 40, 0, 0), (20000, 12, 0, 0)])
 def test_rollout_equals_single_launches(torch, precision, n, T, rl, sl):
     a_env = _make(n, precision, rollout_lanes=rl, step_lanes=sl)      # one launch
     b_env = _make(n, precision, rollout_lanes=rl, step_lanes=sl)      # T x (actions, step, reset_done)
