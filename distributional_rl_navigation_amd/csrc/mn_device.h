@@ -17,7 +17,14 @@ struct MnMath;
 template <>
 struct MnMath<double> {
     static __device__ __forceinline__ double sqrt_(double v) { return sqrt(v); }
-    static __device__ __forceinline__ double rcp(double v) { return 1.0 / v; }
+    // 1 / v for the current field (v = squared distance to a vortex core): v_rcp_f64 + two Newton steps, i.e. within an ulp of the IEEE
+    // quotient in 5 instructions instead of the ~25 of a float64 division (40 of them per env and step).  v = 0 -> NaN here, which the
+    // `f < cap ? f : cap` of mn_core_velocity turns into the cap exactly as it does the division's +inf.
+    static __device__ __forceinline__ double rcp(double v) {
+        double r = __builtin_amdgcn_rcp(v);
+        r = fma(fma(-v, r, 1.0), r, r);
+        return fma(fma(-v, r, 1.0), r, r);
+    }
     static __device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
 };
 
