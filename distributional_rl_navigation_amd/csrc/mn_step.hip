@@ -68,7 +68,11 @@ void launch_l(int lanes, const MnArrays &A, const MnDev &P, const int32_t *actio
     // Default (lanes == 0), measured on MI355X: up to ~128 K envs the launch is latency-bound and two lanes per env
     // win (19.6 vs 20.5 us at 65 536); beyond that several rounds of waves hide latency by themselves and the
     // mapping with the least total work wins (1 M envs: 121 us at L = 1 -> 44 % of the HBM roofline, 165 us at L = 2).
-    if (lanes == 0) lanes = A.n <= 131072 ? 2 : 1;
+    // Round 3: the kernel that also appends the transition (the training loop's) wants four -- with the obstacle rotation shared by the
+    // lane group more lanes no longer repeat it, and the transition's loads / stores spread over the group: 65 536 envs, float64, in the
+    // loop 27.9 -> 25.2 us per launch (mixed 22.1 -> 21.0; 16 384 / 32 768 / 131 072 envs likewise); the plain step kernel stays at two
+    // (24.6 vs 25.9 us).
+    if (lanes == 0) lanes = A.n <= 131072 ? (APPEND ? 4 : 2) : 1;
     switch (lanes) {
         case 1: MN_LAUNCH(1); break;
         case 4: MN_LAUNCH(4); break;

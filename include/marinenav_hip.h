@@ -87,7 +87,7 @@ typedef struct mn_params {
     int32_t N;                       /* robot.py:29 sub-steps per action */
     int32_t num_beams;               /* robot.py:9, must equal MN_NUM_BEAMS */
     int32_t precision;               /* MN_PRECISION_* */
-    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = auto (2 up to 128 K envs, else 1), or 1, 2, 4, 8.
+    int32_t step_lanes;              /* lanes per env in the step kernel: 0 = auto (up to 128 K envs 2, or 4 in mn_step_append; else 1), or 1, 2, 4, 8.
                                         Results do not depend on it (fixed summation tree): a performance knob only */
     int32_t rollout_lanes;           /* the same for mn_rollout: 0 = auto (16 up to 4 096 envs, 8 up to 16 K, 4 up to 64 K, else 2), or 2, 4, 8, 16 */
 } mn_params;
