@@ -40,7 +40,7 @@ ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_m
 # 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
 # fused step + replay append kernel of the training loop, rollout = mn_rollout at 4 096 envs x 100 steps per launch
 # (profiles/r02_full_loop_kernel_stats.txt, profiles/r02_configs1_rollout.txt)
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 79.8e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 61.8e6}
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 79.8e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 69.2e6}
 # mn_step_append also moves the transition into the replay ring: + 104 B (obs_t row read) + 2 x 104 + 8 + 4 + 4 B written
 APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
@@ -546,7 +546,7 @@ def main():
                 "traffic_from_profile": {"bytes_per_launch": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
                                          (PMC_TRAFFIC_BYTES["step_append_f64"] if (fused_append and (n // H, args.cores, args.obstacles, args.precision) == (65536, 8, 10, "f64")) else
                                           (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n // H, args.cores, args.obstacles, args.precision) == (65536, 8, 10, "mixed") else None)),
-                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch): float64 kernels profiles/r03_full_loop_kernel_stats.txt, mixed-precision kernels profiles/r02_full_loop_kernel_stats_split_act.txt / r02_configs1_rollout.txt"},
+                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch): float64 kernels profiles/r03_full_loop_kernel_stats.txt, mixed-precision kernels profiles/r02_full_loop_kernel_stats_split_act.txt, mn_rollout profiles/r03_rollout_phase_timing.txt"},
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "algorithmic_bytes_step_only": bytes_step,
                 "frac_step_bytes_only": (bytes_step * per_launch / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_kernel_ms > 0 else None,
