@@ -791,7 +791,8 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipMalloc(reinterpret_cast<void **>(&c->packed32), v32::OFF_FB * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp32), sp32::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST * sizeof(float)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
+        hipMemset(c->consts_sp, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(c->packed);
         (void)hipFree(c->packed32);
         (void)hipFree(c->packed_sp);
@@ -895,7 +896,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         const bool slot = use_sp && c->sel_slot >= 0;      // explicitly managed image (mn_iqn_pack_slot / mn_iqn_select_slot): never packed here
         if (slot) image = c->slot_sp[c->sel_slot];
         const int pack_blocks = (dirty_s && !slot) ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
-        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
+        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
             int rng_blocks = (int)((groups + 255) / 256);
@@ -963,12 +964,13 @@ extern "C" int mn_iqn_pack_slot(mn_iqn_ctx *c, const float *const *weights, int3
     for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MN_ERR_INVALID;
-    if (!c->slot_consts && hipMalloc(reinterpret_cast<void **>(&c->slot_consts), sp::N_CONST * sizeof(float)) != hipSuccess) return MN_ERR_ALLOC;
+    if (!c->slot_consts && (hipMalloc(reinterpret_cast<void **>(&c->slot_consts), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
+                            hipMemset(c->slot_consts, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return MN_ERR_ALLOC;
     if (!c->slot_sp[slot] && hipMalloc(reinterpret_cast<void **>(&c->slot_sp[slot]), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
     const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
                           weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->slot_consts);
+    hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->slot_consts);
     hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->slot_consts, c->slot_sp[slot]);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
@@ -991,7 +993,7 @@ extern "C" int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *
         const bool use_sp32 = c->variant == 3;
         bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
         if (dirty_s) {
-            hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(1), dim3(1024), 0, s, w, c->consts_sp);
+            hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
             if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp32);
             else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
             dirty_s = false;

@@ -92,40 +92,65 @@ __device__ __forceinline__ float pow2_to_2p15(float amax) {
 
 // consts[0..2] = 2^k_l (weight scales), [3..5] = 2^-k_l, [6] = R2, [7] = beta2, [8] = R3 R2, [9] = R3 beta2 + beta3,
 // [10], [11] = 2^k4, 2^-k4 (output layer)
-// (bounds inflated by 2^-10 relative against the rounding of the sums).  One block of 1024 threads: coalesced max-reductions
-// over the three weight matrices; the 64 row sums of W2 / W3 by 16 threads per row (a thread per row walking its row serially
-// took 28 us -- 208 dependent L2 round trips -- and this kernel runs after every optimizer step); one combined reduction.
-__global__ __launch_bounds__(1024) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
-    __shared__ float red[16][8];
-    const int tid = threadIdx.x;
-    // v[0..2] = max |W1|, |W2|, |W3|;  v[3], v[4] = row sums of W2, W3 (row = tid / 16, 16 threads per row);  v[5], v[6] = |b2|, |b3|
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // v[7] = max |W4| (the 32x32 kernel runs the output layer on the matrix pipe)
-    for (int i = tid; i < F * N_COS; i += 1024) v[0] = fmaxf(v[0], fabsf(w.W1[i]));
-    for (int i = tid; i < H * F; i += 1024) v[1] = fmaxf(v[1], fabsf(w.W2[i]));
-    for (int i = tid; i < H * H; i += 1024) v[2] = fmaxf(v[2], fabsf(w.W3[i]));
-    const int row = tid >> 4, k = tid & 15;
-    for (int j = k; j < F; j += 16) v[3] += fabsf(w.W2[row * F + j]);
-    for (int j = k; j < H; j += 16) v[4] += fabsf(w.W3[row * H + j]);
-    if (tid < H) { v[5] = fabsf(w.b2[tid]); v[6] = fabsf(w.b3[tid]); }
-    if (tid < A_OUT * H) v[7] = fabsf(w.W4[tid]);
-    // the row sums first (within 16 lanes), then all seven maxima through the same shuffle rounds and ONE pass through LDS
+// (bounds inflated by 2^-10 relative against the rounding of the sums).  Runs after every optimizer step, in front of the act kernel.
+// Round 3: CONST_BLOCKS workgroups instead of one of 1 024 threads (14.4 us: a single CU pulling 30 000 weights other CUs just wrote) --
+// block b takes a 1 / 16 slice of every matrix for the maxima and rows 4 b .. 4 b + 3 of W2 and W3 for the row sums (one wavefront
+// per row, fixed xor tree); its eight partial results go to consts[N_CONST + 8 b ..], and the block that finishes LAST (ticket at
+// consts[N_CONST + 8 CONST_BLOCKS]; maxima, so the order of arrival cannot matter) combines them.  The buffer is N_CONST_BUF floats,
+// zero-filled once.
+constexpr int CONST_BLOCKS = 16;
+constexpr int N_CONST_BUF = N_CONST + 8 * CONST_BLOCKS + 4;
+__global__ __launch_bounds__(256) void iqn_split_consts_kernel(IqnWeights w, float *__restrict__ consts) {
+    __shared__ float red[4][8];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wv = tid >> 6;
+    // v[0..2] = max |W1|, |W2|, |W3| over this block's slices;  v[3], v[4] = row sums of W2, W3 (row = 4 b + wave);  v[5], v[6] = |b2|, |b3|;
+    // v[7] = max |W4| (the 32x32 kernel runs the output layer on the matrix pipe)
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int S12 = F * N_COS / CONST_BLOCKS, S3 = H * H / CONST_BLOCKS;      // 832, 256
+    static_assert(F * N_COS % CONST_BLOCKS == 0 && H * F == F * N_COS && H * H % CONST_BLOCKS == 0 && H == 4 * CONST_BLOCKS, "slices");
+    for (int i = tid; i < S12; i += 256) { v[0] = fmaxf(v[0], fabsf(w.W1[b * S12 + i])); v[1] = fmaxf(v[1], fabsf(w.W2[b * S12 + i])); }
+    if (tid < S3) v[2] = fabsf(w.W3[b * S3 + tid]);
+    const int row = 4 * b + wv;
+    for (int j = lane; j < F; j += 64) v[3] += fabsf(w.W2[row * F + j]);
+    v[4] = fabsf(w.W3[row * H + lane]);
+    if (b == 0 && tid < H) { v[5] = fabsf(w.b2[tid]); v[6] = fabsf(w.b3[tid]); }
+    for (int i = b * 256 + tid; i < A_OUT * H; i += 256 * CONST_BLOCKS) v[7] = fmaxf(v[7], fabsf(w.W4[i]));
+    // the row sums first (within the wavefront), then all eight as maxima through the same shuffle rounds and one pass through LDS
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { v[3] += __shfl_xor(v[3], off); v[4] += __shfl_xor(v[4], off); }
+    for (int off = 32; off > 0; off >>= 1) { v[3] += __shfl_xor(v[3], off); v[4] += __shfl_xor(v[4], off); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], __shfl_xor(v[q], off));
-    if ((tid & 63) == 0)
+        for (int q = 0; q < 8; ++q)
+            if (q != 3 && q != 4) v[q] = fmaxf(v[q], __shfl_xor(v[q], off));
+    if (lane == 0)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) red[tid >> 6][q] = v[q];
+        for (int q = 0; q < 8; ++q) red[wv][q] = v[q];
+    __syncthreads();
+    float *part = consts + N_CONST;
+    unsigned *ticket = reinterpret_cast<unsigned *>(consts + N_CONST + 8 * CONST_BLOCKS);
+    if (tid < 8) {
+        const float r = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+        __hip_atomic_store(part + 8 * b + tid, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // agent scope: read by another block below
+        __threadfence();
+    }
     __syncthreads();
     if (tid == 0) {
-        float r[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            r[q] = red[0][q];
-            for (int i = 1; i < 16; ++i) r[q] = fmaxf(r[q], red[i][q]);
-        }
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == CONST_BLOCKS - 1;
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 8) {
+        float r = 0.f;
+        for (int k = 0; k < CONST_BLOCKS; ++k) r = fmaxf(r, __hip_atomic_load(part + 8 * k + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        red[0][tid] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float *r = red[0];
         const float s1 = pow2_to_2p15(r[0]), s2 = pow2_to_2p15(r[1]), s3 = pow2_to_2p15(r[2]), infl = 1.0009765625f;
         const float r2 = r[3], r3 = r[4], b2m = r[5], b3m = r[6];
         consts[0] = s1; consts[1] = s2; consts[2] = s3;
