@@ -45,6 +45,9 @@
 //
 // act_eval's per-tau quantile output (QUANT = true) runs the output layer on the matrix pipe as well.
 
+#ifndef SP_COSJOB
+#define SP_COSJOB 1      // the next environment's cos embedding inside stage 5 / the tail (CosJob)
+#endif
 #ifndef SP_ABL
 #define SP_ABL 0      // measurement builds only (scripts/act_split_ablation.sh): 1 no operand split, 2 no weight LDS reads, 4 no ReLU / Hadamard, 8 no cos, 16 only the hi.hi products, 64 s_memtime phase timing (printf)
 #endif
@@ -368,6 +371,50 @@ __device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &
     asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(ry) : "v"(y), "v"(hb));
 }
 
+// The NEXT environment's cos embedding (layer-1 B operands: 32 values per lane -> 16 register pairs, each split into a hi and a lo pair)
+// as 80 pieces of 1-3 plain VALU instructions that stage 5 and the tail of the CURRENT environment issue between their matrix instructions
+// (round 3).  Those two have spare slots -- stage 5 has no layer-1 work, the tail's last 24 slots have no epilogue -- and the cos operands of
+// the current environment are dead after stage 4, so the results need no second set of registers.  Beside the matrix pipe a plain VALU
+// instruction costs ~1.6 cycles and a v_cos_f32 ~5 (profiles/r03_valu_cost_probe.txt); as a phase of their own, in front of the encoders,
+// the same 176 instructions took ~830 of an environment's ~13 600 clock ticks.
+struct CosJob {
+    float tau[NT];          // the next environment's taus of this lane
+    float hk0;
+    float x0, x1, r0, r1;
+    f16x2 hc;
+    f16x2 H[16], L[16];     // unit u = (kb NT + nt) 4 + p: cos(tau[nt] (hk0 + 16 kb + p)), cos(tau[nt] (hk0 + 16 kb + p + 0.5))
+    template <int P>
+    __device__ __forceinline__ void piece() {
+        if constexpr (P >= 0 && P < 80) {
+            constexpr int u = P / 5, part = P % 5, kb = u / (4 * NT), nt = (u / 4) % NT, p4 = u % 4;
+            if constexpr (part == 0) {
+                x0 = tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p4)));
+                x1 = tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p4 + 1)));
+            } else if constexpr (part == 1) {
+                x0 = __builtin_amdgcn_cosf(x0);
+            } else if constexpr (part == 2) {
+                x1 = __builtin_amdgcn_cosf(x1);
+            } else if constexpr (part == 3) {
+                hc = cvt_pair(x0, x1);
+                residual_pair(x0, x1, hc, r0, r1);
+                H[u] = hc;
+            } else {
+                L[u] = cvt_pair(r0, r1);
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(f16x8 (&cbh)[2][NT], f16x8 (&cbl)[2][NT]) const {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int u = (kb * NT + nt) * 4;
+                cbh[kb][nt] = cat4(H[u], H[u + 1], H[u + 2], H[u + 3]);
+                cbl[kb][nt] = cat4(L[u], L[u + 1], L[u + 2], L[u + 3]);
+            }
+    }
+};
+
 // One pipeline stage of the fused layers 1 + 2.  Stage B issues, as ONE hand-interleaved instruction stream,
 //   * the 24 layer-2 MFMAs of K block B            (inputs: bh / bl, the split activations of block B),
 //   * the layer-1 MFMAs of block B + 2             (into accW),
@@ -381,7 +428,8 @@ __device__ __forceinline__ void residual_pair(float x, float y, f16x2 h, float &
 template <int B>
 __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
                                       const f16x8 (&cbh)[2][NT], const f16x8 (&cbl)[2][NT], const f16x8 (&bh)[NT], const f16x8 (&bl)[NT],
-                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT]) {
+                                      f32x4 (&acc2)[4][NT], f32x4 (&accW)[2][NT], const f32x4 (&accR)[2][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT],
+                                      CosJob &cj) {
     constexpr int NTI_W = (B + 2 < KB2) ? ntiles_of(B + 2) : 0;                  // layer-1 tiles written (block B + 2)
     constexpr int NTI_R = (B + 1 >= 0 && B + 1 < KB2) ? ntiles_of(B + 1) : 0;    // layer-1 tiles read by the epilogue (block B + 1)
     constexpr bool HAS_L2 = B >= 0;
@@ -461,6 +509,7 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
                 }
             }
         }
+        if constexpr (B == 5 && SP_COSJOB) cj.template piece<m>();      // pieces 0..23 of the next environment's cos embedding
         __builtin_amdgcn_sched_barrier(0);
     });
     if (N_UNIT > 0) {
@@ -546,7 +595,7 @@ __device__ __forceinline__ void store_features(float *__restrict__ lds, int fb_f
 //   slots 48..71  layer-3 MFMAs of K block 1 (output tiles 0, 1 first)
 // S2 h2 = relu(acc2 c2 + S b2) with c2 = 2^-k2 S2 / S1 and S = S2 passed by the caller; the layer-3 accumulators are left in acc3.
 __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float S,
-                                     const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f32x4 (&acc3)[4][NT]) {
+                                     const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f32x4 (&acc3)[4][NT], CosJob &cj) {
     f16x8 a2h[4], a2l[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -615,6 +664,11 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
                 }
             }
         }
+        if constexpr (SP_COSJOB) {      // pieces 24..79 of the next environment's cos embedding: two per slot where the tail has no epilogue work of its own
+            if constexpr (m < 12) { cj.template piece<24 + 2 * m>(); cj.template piece<25 + 2 * m>(); }
+            else if constexpr (m >= 48 && m < 56) { cj.template piece<48 + 2 * (m - 48)>(); cj.template piece<49 + 2 * (m - 48)>(); }
+            else if constexpr (m >= 56) cj.template piece<64 + (m - 56)>();
+        }
         __builtin_amdgcn_sched_barrier(0);
     });
 }
@@ -661,16 +715,16 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     // registers cost spills.  Requesting ONLY the next environment's taus and observation row one iteration ahead (2 VGPRs,
     // 28 SGPRs) changes nothing either (338 vs 337 us, alternating runs on one GPU): that latency is covered by the partner wave.
     [[maybe_unused]] int sp_iter = 0;
-    for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
-        [[maybe_unused]] unsigned long long tk[16];
-#define SP_TICK(i) do { if (SP_ABL & 64) { __builtin_amdgcn_sched_barrier(0); tk[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-        SP_TICK(0);
-        const float u_explore = (explore_u && eps > 0.f) ? explore_u[__builtin_amdgcn_readfirstlane(e)] : 2.0f;     // used ~10 us later
+    // layer-1 B operands: the cos embedding (model.py:155), unscaled, split.  Computed here for a wave's FIRST environment only; for every
+    // later one by the CosJob pieces inside stage 5 / the tail of the environment before it (same expressions, same bits).
+    f16x8 cbh[2][NT], cbl[2][NT];
+    CosJob cj;
+    cj.hk0 = hk0;
+    const int e_first = blockIdx.x * waves_per_block + wave, e_stride = gridDim.x * waves_per_block;
+    if (e_first < n) {
         float tau[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e * K_TAUS + 16 * nt + col];
-        // layer-1 B operands: the cos embedding (model.py:155), unscaled, split
-        f16x8 cbh[2][NT], cbl[2][NT];
+        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e_first * K_TAUS + 16 * nt + col];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -685,6 +739,17 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
                 cbh[kb][nt] = cat4(h[0], h[1], h[2], h[3]);
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
+    }
+    for (int e = e_first; e < n; e += e_stride) {
+        [[maybe_unused]] unsigned long long tk[16];
+#define SP_TICK(i) do { if (SP_ABL & 64) { __builtin_amdgcn_sched_barrier(0); tk[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+        SP_TICK(0);
+        const float u_explore = (explore_u && eps > 0.f) ? explore_u[__builtin_amdgcn_readfirstlane(e)] : 2.0f;     // used ~10 us later
+        {   // the next environment's taus (the last iteration re-reads its own: straight-line code); consumed from stage 5 on
+            const int e_nx = e + e_stride < n ? e + e_stride : e;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) cj.tau[nt] = taus[(size_t)e_nx * K_TAUS + 16 * nt + col];
+        }
         SP_TICK(1);
         // observation encoders, per-environment scale S, S 2^-k1 features -> this wave's LDS buffer
         EnvScale sc;
@@ -712,24 +777,25 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         // Stage b = layer-2 MFMAs of block b + layer-1 MFMAs of block b + 2 + VALU epilogue of block b + 1, see stage()
         f32x4 accA[2][NT], accB[2][NT];
         f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
-        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB);      // layer-1 block 0
+        stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB, cj);      // layer-1 block 0
         SP_TICK(3);
-        stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);      // layer-1 block 1, epilogue of block 0
+        stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);      // layer-1 block 1, epilogue of block 0
         SP_TICK(4);
-        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<0>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, cj);
         SP_TICK(5);
-        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);
         SP_TICK(6);
-        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<2>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, cj);
         SP_TICK(7);
-        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<3>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);
         SP_TICK(8);
-        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB);
+        stage<4>(lds4, ldsv, lb, cbh, cbl, bhA, blA, acc2, accA, accB, bhB, blB, cj);
         SP_TICK(9);
-        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA);
+        stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);
         SP_TICK(10);
         f32x4 acc3[4][NT];
-        tail(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3);
+        tail(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3, cj);
+        if (SP_COSJOB) cj.finish(cbh, cbl);      // (register renaming: the operands of the next environment)
         SP_TICK(11);
         const float c3e = c3 * sc.r32;      // layer-3 accumulators carry S2 2^k3: to S3
         float qv;
