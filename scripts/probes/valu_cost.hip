@@ -87,6 +87,11 @@ int main() {
     {
         const float t = run<13, 1>(512, iters, dout);      // MFMA after every v_mov: ~ MFMA-bound
         printf("MFMA + 1 v_mov, W=2: %6.2f ns per MFMA of the SIMD\n", t * 1e6 / n_inst / 2);
+        // one wave per SIMD: how fast does a wave's own stream of MFMA + K plain instructions run without a partner?
+        const float a1 = run<13, 1>(256, iters, dout), a2 = run<1, 2>(256, iters, dout), a3 = run<1, 3>(256, iters, dout), a4 = run<1, 4>(256, iters, dout);
+        const float b2 = run<1, 2>(512, iters, dout), b4 = run<1, 4>(512, iters, dout);
+        printf("ONE wave per SIMD, MFMA + K x v_max_i32: K=1 %6.2f  K=2 %6.2f  K=3 %6.2f  K=4 %6.2f ns per MFMA;   two waves: K=2 %6.2f  K=4 %6.2f ns per MFMA of the SIMD\n",
+               a1 * 1e6 / n_inst, a2 * 1e6 / (n_inst / 2), a3 * 1e6 / (n_inst / 3), a4 * 1e6 / (n_inst / 4), b2 * 1e6 / (n_inst / 2) / 2, b4 * 1e6 / (n_inst / 4) / 2);
     }
     return 0;
 }
