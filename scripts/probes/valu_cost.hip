@@ -23,7 +23,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     X(10, "v_cvt_pkrtz_f16_f32", "v_cvt_pkrtz_f16_f32 %0, %1, %2", "=v")                                                      \
     X(11, "v_pk_max_f16", "v_pk_max_f16 %0, %1, %2", "=v")                                                                     \
     X(12, "v_readlane_b32 (to sgpr)", "v_readlane_b32 s20, %1, 3", "=v")                                                      \
-    X(13, "v_mov_b32", "v_mov_b32 %0, %1", "=v")
+    X(13, "v_mov_b32", "v_mov_b32 %0, %1", "=v")                                                                              \
+    X(14, "s_nop 0", "s_nop 0 ; %0 %1 %2", "+v")                                                                               \
+    X(15, "s_waitcnt lgkmcnt(0)", "s_waitcnt lgkmcnt(0) ; %0 %1 %2", "+v")                                                     \
+    X(16, "s_mov_b32", "s_mov_b32 s20, 7 ; %0 %1 %2", "+v")
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
