@@ -415,6 +415,22 @@ struct CosJob {
     }
 };
 
+// the two halves of residual_pair as separate instructions (the epilogue is issued in pieces of two instructions, see stage())
+__device__ __forceinline__ float residual_lo32(float x, f16x2 h) {      // x - h.x, exact
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    float r;
+    if (SP_ABL & 1) return x;
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(hb));
+    return r;
+}
+__device__ __forceinline__ float residual_hi32(float y, f16x2 h) {      // y - h.y, exact
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    float r;
+    if (SP_ABL & 1) return y;
+    asm("v_fma_mix_f32 %0, 1.0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(y), "v"(hb));
+    return r;
+}
+
 // One pipeline stage of the fused layers 1 + 2.  Stage B issues, as ONE hand-interleaved instruction stream,
 //   * the 24 layer-2 MFMAs of K block B            (inputs: bh / bl, the split activations of block B),
 //   * the layer-1 MFMAs of block B + 2             (into accW),
@@ -434,7 +450,10 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
     constexpr int NTI_R = (B + 1 >= 0 && B + 1 < KB2) ? ntiles_of(B + 1) : 0;    // layer-1 tiles read by the epilogue (block B + 1)
     constexpr bool HAS_L2 = B >= 0;
     constexpr int N_L2 = HAS_L2 ? 3 * 4 * NT : 0, PER_KB = 3 * NTI_W * NT, NM = N_L2 + 2 * PER_KB;
-    constexpr int N_UNIT = NTI_R * NT * 2, N_SUB = 3 * N_UNIT;
+    // The epilogue of a register pair is 8 plain VALU instructions, issued as FOUR pieces of two (round 3; before: pieces of 4 / 3 / 1 after
+    // every second MFMA).  Beside the matrix pipe the cost of K interleaved instructions is convex in K (+0.3 / +0.9 / +2.0 / +3.9 ns for
+    // K = 1 .. 4, profiles/r03_valu_cost_probe.txt), so the same instructions are cheaper spread two by two over more slots.
+    constexpr int N_UNIT = NTI_R * NT * 2, N_SUB = 4 * N_UNIT;
 
     // Operands are loaded by the stage itself (layer-2 weights, features, bias up front; layer-1 weights 12 slots ahead of
     // their use).  Having the predecessor stage prefetch them (measured) changes nothing: the LDS latency is already covered
@@ -493,18 +512,18 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
 #pragma unroll
         for (int sub = 0; sub < N_SUB; ++sub) {
             if ((sub + 1) * NM / (N_SUB + 1) == m) {
-                const int u = sub / 3, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2;
-                if (sub % 3 == 0) {                    // ReLU + Hadamard: 2 v_max_i32, v_pk_mul_f32
-                    if (SP_ABL & 4) { x0 = accR[ti][nt][2 * pr]; x1 = accR[ti][nt][2 * pr + 1]; }
-                    else {
-                        x0 = relu1(accR[ti][nt][2 * pr]) * fv[ti][2 * pr];
-                        x1 = relu1(accR[ti][nt][2 * pr + 1]) * fv[ti][2 * pr + 1];
-                    }
-                } else if (sub % 3 == 1) {             // hi pair, residuals: v_cvt_pk_f16_f32, 2 v_fma_mix_f32
+                const int u = sub / 4, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2;
+                if (sub % 4 == 0) {                    // ReLU: 2 v_max_i32
+                    x0 = (SP_ABL & 4) ? accR[ti][nt][2 * pr] : relu1(accR[ti][nt][2 * pr]);
+                    x1 = (SP_ABL & 4) ? accR[ti][nt][2 * pr + 1] : relu1(accR[ti][nt][2 * pr + 1]);
+                } else if (sub % 4 == 1) {             // Hadamard: 2 v_mul_f32
+                    if (!(SP_ABL & 4)) { x0 *= fv[ti][2 * pr]; x1 *= fv[ti][2 * pr + 1]; }
+                } else if (sub % 4 == 2) {             // hi pair, first residual: v_cvt_pk_f16_f32, v_fma_mix_f32
                     hcur = cvt_pair(x0, x1);
-                    residual_pair(x0, x1, hcur, r0, r1);
+                    r0 = residual_lo32(x0, hcur);
                     hP[nt][2 * ti + pr] = hcur;
-                } else {                               // lo pair: v_cvt_pk_f16_f32
+                } else {                               // second residual, lo pair: v_fma_mix_f32, v_cvt_pk_f16_f32
+                    r1 = residual_hi32(x1, hcur);
                     lP[nt][2 * ti + pr] = cvt_pair(r0, r1);
                 }
             }
