@@ -391,9 +391,9 @@ struct CosJob {
                 x0 = tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p4)));
                 x1 = tau[nt] * (hk0 + (16.0f * kb + 0.5f * (2 * p4 + 1)));
             } else if constexpr (part == 1) {
-                x0 = __builtin_amdgcn_cosf(x0);
+                if (!(SP_ABL & 8)) x0 = __builtin_amdgcn_cosf(x0);
             } else if constexpr (part == 2) {
-                x1 = __builtin_amdgcn_cosf(x1);
+                if (!(SP_ABL & 8)) x1 = __builtin_amdgcn_cosf(x1);
             } else if constexpr (part == 3) {
                 hc = cvt_pair(x0, x1);
                 residual_pair(x0, x1, hc, r0, r1);
