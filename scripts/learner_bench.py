@@ -30,3 +30,17 @@ for mode in (0, 1, 0):
     dt = time.perf_counter() - t0
     print(f"mode {mode}: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
 _capi.lib().mn_iqn_train_set_mode(0)
+# the same gradient steps as captured hipGraphs of G steps each (IQNAgent.use_fused_graph)
+for G in (16, 64):
+    ag.use_fused_graph = True
+    for _ in range(3):
+        ag.train_steps_from_memory(G)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = max(1, reps // G)
+    for _ in range(k):
+        ag.train_steps_from_memory(G)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"hipGraph of {G:3d} steps: {k * G / dt:9.0f} grad-steps/s  ({1e6 * dt / (k * G):6.2f} us per step)", flush=True)
+ag.use_fused_graph = False
