@@ -34,6 +34,9 @@ HBM_PEAK_GBS = 8000.0
 ACT_FLOP_PER_ENV_STEP = 2 * 32 * (64 * 208 + 208 * 64 + 64 * 64 + 64 * 9)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md (micro-benchmark ceiling 2382; profiles/r02_f16_split_probe.txt: 2057 sustained by one instruction stream)
+# launch-shared taus (mn_iqn_set_tau_mode 1): layer 1 is a constant of the launch; what remains per env-step is the Hadamard product, layers 2-3, output
+ACT_SHARED_FLOP_PER_ENV_STEP = 2 * 32 * (208 * 64 + 64 * 64 + 64 * 9)
+ACT_SHARED_MFMA_FLOP_PER_ENV_STEP = 216 * 16384
 ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_mfma_f32_16x16x32_f16 per environment (3 per f32 product, layer-2 K padded 208 -> 224)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured at
 # 65 536 envs, 8 cores / 10 obstacles: profiles/r01_full_loop_kernel_stats.txt.  Not measured live.
@@ -163,6 +166,26 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
     out["act_exact_f32"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                             "act_kernel": "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "act_launch_ms": act_ms,
                             "roofline_frac_f32_mfma": alg_tf / F32_MFMA_PEAK_TFLOPS if alg_tf else None}
+    # (a') launch-shared taus: one set of 32 quantile fractions per act launch instead of per env (opt-in, IQNAgent.shared_taus)
+    def shared_leg(fn, steps, warm):
+        nonlocal obs
+        agent.shared_taus = True
+        try:
+            dt, obs = _timed(device, fn, steps, warm, obs, lambda: ctx.profile_begin(min(steps, 50)))
+            ms, _ = ctx.profile_end()
+        finally:
+            agent.shared_taus = False
+        return dt, ms
+    steps = max(20, args.steps // 2)
+    dt, act_ms = shared_leg(loop_step, steps, 10)
+    rate = n / (act_ms * 1e-3) / 1e12 if act_ms > 0 else None
+    out["act_shared_taus"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                              "act_kernel": "iqn_qvals_split_kernel<false, SHARED=true> (layer 1 = a [32 x 208] constant of the launch; 216 v_mfma_f32_16x16x32_f16 per env)",
+                              "launch_ms": act_ms, "tau_draw": "32 taus ~ U[0,1) x cvar per LAUNCH, shared by its envs (default: per env)",
+                              "frac_algorithmic_remaining_flops": ACT_SHARED_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
+                              "frac_algorithmic_full_network_flops": ACT_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
+                              "frac_issued_mfma": ACT_SHARED_MFMA_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
+                              "remaining_flop_per_env_step": ACT_SHARED_FLOP_PER_ENV_STEP, "full_network_flop_per_env_step": ACT_FLOP_PER_ENV_STEP}
     # (b) the cadence that trains
     ue, gs = agent.UPDATE_EVERY, agent.grad_steps_per_update
     agent.UPDATE_EVERY, agent.grad_steps_per_update = 1, 16
@@ -173,6 +196,9 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
     out["train_cadence"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                             "grad_steps_per_vector_step": 16, "eps": 0.05,
                             "grad_steps_per_sec": 16 * steps / dt, "grad_steps_counted": agent.grad_steps - g0 - 16 * 10}
+    dt, act_ms = shared_leg(lambda o: agent.vec_step(env, o, 0.05, args.cvar, train_every=1, per_iter=n)[0], steps, 10)
+    out["train_cadence_shared_taus"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                                        "grad_steps_per_vector_step": 16, "eps": 0.05, "grad_steps_per_sec": 16 * steps / dt, "act_launch_ms": act_ms}
     agent.UPDATE_EVERY, agent.grad_steps_per_update = ue, gs
     # (c) configs[1]
     n1 = 4096
@@ -284,6 +310,8 @@ def main():
                          "behind `roofline` is that of a kernel that has the GPU to itself (with two streams the two halves' act kernels "
                          "overlap each other and a per-launch duration no longer measures the kernel)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
+    ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
+                                                               "timed by the default run as also.act_shared_taus)")
     ap.add_argument("--act-grid", type=int, default=1024, help="with --halves > 1: workgroups of an act launch (mn_iqn_set_grid)")
     args = ap.parse_args()
     if args.precision is None:
@@ -340,6 +368,7 @@ def main():
                          UPDATE_EVERY=args.update_every, rank=rank if args.shared_learner else 0)
         agent.grad_steps_per_update = args.grad_steps
         agent.use_fused_graph = args.graph_train
+        agent.shared_taus = args.shared_taus
     if agent is not None and args.torch_act:
         agent.use_fused_act = False
     if agent is not None and args.no_train_graph:
@@ -508,6 +537,7 @@ def main():
                                                                                       "tests/test_env_gpu.py::test_loop_default_precision_is_strict_1e5_with_zero_outliers)"),
             "data": "synthetic (seeded random worlds, random-init IQN)",
             "act_kernel_variant": args.act_variant,
+            "act_tau_mode": "shared per launch (opt-in)" if args.shared_taus else "per env (default)",
             "config": {
                 "workload": ((f"step kernel only, random policy, {roll} vector steps per launch (mn_rollout: in-kernel actions + resets, traces: {','.join(trace) or 'none'})"
                               if roll else "step kernel only, random policy, one mn_step + mn_reset_done launch pair per vector step") if agent is None else
@@ -566,6 +596,9 @@ def main():
                 kern = ("iqn_qvals_split_kernel (3 x v_mfma_f32_16x16x32_f16 per f32 product, f32-class accuracy)" if args.act_variant == 2 else
                         "iqn_qvals_split32_kernel (3 x v_mfma_f32_32x32x16_f16 per f32 product, f32-class accuracy)")
                 peak = F16_MFMA_PEAK_TFLOPS
+                if args.shared_taus and args.act_variant == 2:
+                    tf = ACT_SHARED_MFMA_FLOP_PER_ENV_STEP * n_act / (act_ms * 1e-3) / 1e12
+                    kern = "iqn_qvals_split_kernel<false, SHARED=true> (launch-shared taus: layer 1 is a constant of the launch, 216 MFMAs per env)"
             else:
                 tf = alg_tf
                 kern = "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)"

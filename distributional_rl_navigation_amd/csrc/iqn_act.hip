@@ -748,6 +748,8 @@ struct mn_iqn_ctx {
     uint32_t *packed_sp = nullptr; // weight image of the split-f16 kernel (iqn_act_split.h)
     uint32_t *packed_sp32 = nullptr;   // ... and of its 32x32x16 form (iqn_act_split32.h)
     float *consts_sp = nullptr;    // its scale / bound constants
+    float *h1_sp = nullptr;        // the launch's layer-1 constant [32 taus x 208] of the shared-tau kernel (mn_iqn_set_tau_mode)
+    int tau_mode = 0;              // 0 = every environment its own 32 taus (the reference's per-call draw), 1 = one set of 32 per launch
     bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
@@ -781,6 +783,10 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp32::iqn_qvals_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
         return MN_ERR_HIP;
@@ -792,11 +798,14 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp32), sp32::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->h1_sp), sp::H1_FLOATS * sizeof(float)) != hipSuccess ||
         hipMemset(c->consts_sp, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(c->packed);
         (void)hipFree(c->packed32);
         (void)hipFree(c->packed_sp);
         (void)hipFree(c->packed_sp32);
+        (void)hipFree(c->consts_sp);
+        (void)hipFree(c->h1_sp);
         delete c;
         return MN_ERR_ALLOC;
     }
@@ -815,6 +824,7 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->packed_sp);
     (void)hipFree(c->packed_sp32);
     (void)hipFree(c->consts_sp);
+    (void)hipFree(c->h1_sp);
     (void)hipFree(c->slot_sp[0]);
     (void)hipFree(c->slot_sp[1]);
     (void)hipFree(c->slot_consts);
@@ -835,6 +845,12 @@ extern "C" int mn_iqn_weights_changed(mn_iqn_ctx *c) {
 extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
     if (!c || variant < 0 || variant > 3) return MN_ERR_INVALID;
     c->variant = variant;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode) {
+    if (!c || mode < 0 || mode > 1) return MN_ERR_INVALID;
+    c->tau_mode = mode;
     return MN_OK;
 }
 
@@ -890,6 +906,31 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     // quantile capture (act_eval): the split-f16 kernel's QUANT form for variants 2 and 3, the exact 16x16x4 kernel's for 0 and 1
     const bool use_sp = c->variant == 2 || (quantiles_dev && c->variant == 3), use_sp32 = !quantiles_dev && c->variant == 3;
     const bool use32 = !quantiles_dev && c->variant == 1;
+    if (c->tau_mode == 1) {
+        // Launch-shared taus: ONE set of 32 quantile fractions for every environment of the launch (iqn_act_split.h, stage_sh).  Only the
+        // split-f16 kernel has this form; per-row CVaR (adaptive policies) needs per-environment taus; the explicitly managed image slots
+        // of the two-stream loop would pair a lagging image with a layer-1 constant of the live weights.
+        if (c->variant != 2 || cvar_row_dev || c->sel_slot >= 0) return MN_ERR_INVALID;
+        const int pack_blocks = c->dirty_sp ? sp::PACK_BLOCKS : 0;
+        if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
+        int rng_blocks = 0;
+        if (rng_state_dev) {
+            rng_blocks = (int)(((long)n + K_TAUS + 255) / 256);
+            if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
+        }
+        hipLaunchKernelGGL(sp::iqn_shared_prep_kernel, dim3(pack_blocks + sp::H1_BLOCKS + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                           c->packed_sp, (const uint64_t *)rng_state_dev, draws_dev, n, rng_state_dev ? nullptr : taus_dev, cvar, pack_blocks, c->h1_sp);
+        if (rng_state_dev) explore_u_dev = eps > 0.f ? draws_dev + K_TAUS : nullptr;
+        c->dirty_sp = false;
+        if (quantiles_dev)
+            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<true, true>), dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, (const float *)nullptr,
+                               (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)c->h1_sp);
+        else
+            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<false, true>), dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, (const float *)nullptr,
+                               (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)c->h1_sp);
+        if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
+        return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+    }
     if (use_sp || use_sp32) {
         bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
         uint32_t *image = use_sp32 ? c->packed_sp32 : c->packed_sp;
@@ -919,10 +960,10 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
         else if (quantiles_dev)
             hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<true>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev);
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)nullptr);
         else
             hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<false>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)nullptr);
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }

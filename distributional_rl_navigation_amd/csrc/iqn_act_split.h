@@ -540,6 +540,130 @@ __device__ __forceinline__ void stage(const u32x4 *__restrict__ lds4, const f32x
     }
 }
 
+// ---- launch-shared taus (mn_iqn_set_tau_mode(ctx, 1); round 4) ---------------------------------------------------------------------
+// When every environment of a launch sees the SAME 32 quantile fractions, layer 1 -- relu(W1 cos(pi k tau) + b1), model.py:141-157,
+// 176-178 -- does not depend on the environment: it is a [32 tau x 208 feature] constant of the launch, computed once by the preparation
+// launch (iqn_shared_prep_kernel, exact float32 FMA chains on accurate cosines) and parked in the LDS region the layer-1 weights would
+// occupy, as [13 tiles][2 tau tiles][64 lanes] float4 = the C-tile registers the per-env kernel's layer-1 accumulators hold.  Per
+// environment what remains is the Hadamard product with the (scaled) encoder features and the operand split: six plain VALU instructions
+// per register pair in three pieces of two, no ReLU, no v_cos, no layer-1 matrix instructions -- 216 MFMAs per environment instead of 372.
+constexpr int H1_FLOATS = T1 * NT * 64 * 4;      // 6 656 = 32 taus x 208 features
+static_assert(H1_FLOATS / 4 <= W2_U4, "the layer-1 constant fits into the W1 region of the image");
+
+// Stage B of the shared-tau pipeline: the 24 layer-2 MFMAs of K block B (B >= 0) || Hadamard + split of block B + 1 (-> bhN / blN).
+template <int B>
+__device__ __forceinline__ void stage_sh(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb,
+                                         const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f16x8 (&bhN)[NT], f16x8 (&blN)[NT]) {
+    constexpr int NTI_R = ntiles_of(B + 1);
+    constexpr bool HAS_L2 = B >= 0;
+    constexpr int N_L2 = HAS_L2 ? 3 * 4 * NT : 0;
+    constexpr int N_UNIT = NTI_R * NT * 2, N_SUB = 3 * N_UNIT;
+    constexpr int NM = HAS_L2 ? N_L2 : N_SUB;          // stage -1 has no matrix instructions: one slot per piece
+    f16x8 a2h[4], a2l[4];
+    if (HAS_L2) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int c = W2_U4 + ((mt * KB2 + (HAS_L2 ? B : 0)) * 2) * 64;
+            a2h[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c));
+            a2l[mt] = __builtin_bit_cast(f16x8, ld_w(lds4, lb, c + 64));
+        }
+    }
+    f32x4 fv[2], h1v[2][NT];
+#pragma unroll
+    for (int ti = 0; ti < NTI_R; ++ti) {
+        fv[ti] = ldsv[lb.fb + 4 * (2 * (B + 1) + ti)];                                           // S1 features[16t + 4g + r]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h1v[ti][nt] = ldsv[lb.w_lo + ((2 * (B + 1) + ti) * NT + nt) * 64];     // relu(layer 1)[16t + 4g + r][tau 16nt + col]
+    }
+    f16x2 hP[NT][4], lP[NT][4];
+    const f16x2 zero2 = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hP[nt][q] = zero2; lP[nt][q] = zero2; }
+    float x0 = 0.f, x1 = 0.f, r0 = 0.f, r1 = 0.f;
+    f16x2 hcur = zero2;
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NM>([&](auto M_) {
+        constexpr int m = decltype(M_)::value;
+        if constexpr (m < N_L2) {
+            constexpr int p = m / (4 * NT), mt = (m % (4 * NT)) / NT, nt = m % NT;
+            acc2[mt][nt] = mf(p == 0 ? a2l[mt] : a2h[mt], p == 1 ? bl[nt] : bh[nt], acc2[mt][nt]);
+        }
+#pragma unroll
+        for (int sub = 0; sub < N_SUB; ++sub) {
+            if ((HAS_L2 ? (sub + 1) * NM / (N_SUB + 1) : sub) == m) {
+                const int u = sub / 3, ti = u / (NT * 2), nt = (u / 2) % NT, pr = u % 2;
+                if (sub % 3 == 0) {                    // Hadamard: 2 v_mul_f32
+                    x0 = h1v[ti][nt][2 * pr] * fv[ti][2 * pr];
+                    x1 = h1v[ti][nt][2 * pr + 1] * fv[ti][2 * pr + 1];
+                } else if (sub % 3 == 1) {             // hi pair, first residual
+                    hcur = cvt_pair(x0, x1);
+                    r0 = residual_lo32(x0, hcur);
+                    hP[nt][2 * ti + pr] = hcur;
+                } else {                               // second residual, lo pair
+                    r1 = residual_hi32(x1, hcur);
+                    lP[nt][2 * ti + pr] = cvt_pair(r0, r1);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bhN[nt] = cat4(hP[nt][0], hP[nt][1], hP[nt][2], hP[nt][3]);
+        blN[nt] = cat4(lP[nt][0], lP[nt][1], lP[nt][2], lP[nt][3]);
+    }
+}
+
+// The launch's layer-1 constant + its random numbers (+ the weight image when stale), one launch in front of the shared-tau act kernel:
+//   blocks [0, pack_blocks)                       weight image (as iqn_split_prep_kernel)
+//   blocks [pack_blocks, pack_blocks + H1_BLOCKS) h1[((t NT + nt) 64 + lane) 4 + r] = relu(b1[j] + sum_k W1[j][k] cos(tau pi k)), j = 16 t + 4 (lane >> 4) + r,
+//                                                 tau = taus[16 nt + (lane & 15)]: the float32 product tau * (float)(pi k) and an accurate cosine, as
+//                                                 model.py:149-155 forms them; k ascending float32 FMA chain
+//   the rest                                      draws[0 .. 32) = the launch's taus = U[0,1) cvar, draws[32 .. 32 + n) = exploration uniforms
+// taus_in != nullptr: injected taus (mn_iqn_act), no draws.  Every H1 block re-derives the 32 taus itself (counter-based: same values).
+constexpr int H1_BLOCKS = H1_FLOATS / 256;      // 26
+__global__ __launch_bounds__(256) void iqn_shared_prep_kernel(IqnWeights w, const float *__restrict__ consts, uint32_t *__restrict__ packed,
+                                                              const uint64_t *__restrict__ rng_state, float *__restrict__ draws, int n,
+                                                              const float *__restrict__ taus_in, float cvar, int pack_blocks, float *__restrict__ h1) {
+    __shared__ float cs[K_TAUS][N_COS + 1];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < pack_blocks) {
+        const int i = blockIdx.x * blockDim.x + tid;
+        if (i < OFF_FB) packed[i] = pack_word(w, consts, i);
+        return;
+    }
+    uint32_t k0 = 0, k1 = 0;
+    if (!taus_in) {
+        const uint64_t base = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 1));
+        k0 = (uint32_t)base; k1 = (uint32_t)(base >> 32);
+    }
+    const int hb = (int)blockIdx.x - pack_blocks;
+    if (hb < H1_BLOCKS) {
+        for (int i = tid; i < K_TAUS * N_COS; i += 256) {
+            const int ti = i / N_COS, k = i % N_COS;
+            const float tau = taus_in ? taus_in[ti] : u01((uint32_t)ti, k0, k1) * cvar;
+            cs[ti][k] = cosf(tau * (float)(3.14159265358979323846 * k));
+        }
+        __syncthreads();
+        const int o = hb * 256 + tid, r = o & 3, lane = (o >> 2) & 63, nt = (o >> 8) % NT, t = o / (256 * NT);
+        const int j = 16 * t + 4 * (lane >> 4) + r, ti = 16 * nt + (lane & 15);
+        float a = w.b1[j];
+        for (int k = 0; k < N_COS; ++k) a = fmaf(w.W1[j * N_COS + k], cs[ti][k], a);
+        h1[o] = fmaxf(a, 0.f);
+        return;
+    }
+    if (taus_in) return;
+    const long total = (long)n + K_TAUS;
+    const long stride = (long)((int)gridDim.x - pack_blocks - H1_BLOCKS) * 256;
+    for (long idx = (long)(hb - H1_BLOCKS) * 256 + tid; idx < total; idx += stride) {
+        float u = u01((uint32_t)idx, k0, k1);
+        if (idx < K_TAUS) u *= cvar;
+        draws[idx] = u;
+    }
+}
+
 // ---- observation encoders (model.py:170-173) in schedulable pieces.  Lane l computes sensor features l, l + 64, l + 128 (22
 // inputs each) and velocity / goal feature l (2 inputs; lanes < 32), then its share of the activation bound.  25 sub-steps of
 // 1 LDS read + 2-4 VALU.
@@ -613,6 +737,7 @@ __device__ __forceinline__ void store_features(float *__restrict__ lds, int fb_f
 //   slots 24..47  layer-3 MFMAs of K block 0         || layer-2 epilogue of tiles 2, 3
 //   slots 48..71  layer-3 MFMAs of K block 1 (output tiles 0, 1 first)
 // S2 h2 = relu(acc2 c2 + S b2) with c2 = 2^-k2 S2 / S1 and S = S2 passed by the caller; the layer-3 accumulators are left in acc3.
+template <bool COS = true>
 __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4 *__restrict__ ldsv, const LdsBase &lb, float c2, float S,
                                      const f16x8 (&bh)[NT], const f16x8 (&bl)[NT], f32x4 (&acc2)[4][NT], f32x4 (&acc3)[4][NT], CosJob &cj) {
     f16x8 a2h[4], a2l[4];
@@ -683,7 +808,7 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
                 }
             }
         }
-        if constexpr (SP_COSJOB) {      // pieces 24..79 of the next environment's cos embedding: two per slot where the tail has no epilogue work of its own
+        if constexpr (SP_COSJOB && COS) {      // pieces 24..79 of the next environment's cos embedding: two per slot where the tail has no epilogue work of its own
             if constexpr (m < 12) { cj.template piece<24 + 2 * m>(); cj.template piece<25 + 2 * m>(); }
             else if constexpr (m >= 48 && m < 56) { cj.template piece<48 + 2 * (m - 48)>(); cj.template piece<49 + 2 * (m - 48)>(); }
             else if constexpr (m >= 56) cj.template piece<64 + (m - 56)>();
@@ -695,19 +820,26 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
 // QUANT = false: acting / training (tau mean before the linear output layer, f32 VALU mat-vec).
 // QUANT = true : IQNAgent.act_eval (agent.py:217-236): the output layer runs per tau on the matrix pipe (12 more MFMAs on a padded
 //                16-row tile), the [n][32][9] quantile values are written out and Q is their mean.
-template <bool QUANT>
+// SHARED = true : launch-shared taus (see stage_sh): `taus` is unused, `h1` is the launch's layer-1 constant (iqn_shared_prep_kernel).
+template <bool QUANT, bool SHARED = false>
 __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                                  const uint32_t *__restrict__ packed, float *__restrict__ qvals,
                                                                  const float *__restrict__ explore_u, float eps,
                                                                  int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state,
-                                                                 float *__restrict__ quantiles) {
+                                                                 float *__restrict__ quantiles, const float *__restrict__ h1 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by the prep kernel
     {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(packed);
         u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
-        for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+        if constexpr (SHARED) {      // the layer-1 constant takes the place of the layer-1 weights
+            const u32x4 *hsrc = reinterpret_cast<const u32x4 *>(h1);
+            for (int i = tid; i < H1_FLOATS / 4; i += blockDim.x) dst[i] = hsrc[i];
+            for (int i = W2_U4 + tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+        } else {
+            for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+        }
     }
     __syncthreads();
 
@@ -740,7 +872,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     CosJob cj;
     cj.hk0 = hk0;
     const int e_first = blockIdx.x * waves_per_block + wave, e_stride = gridDim.x * waves_per_block;
-    if (e_first < n) {
+    if (!SHARED && e_first < n) {
         float tau[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e_first * K_TAUS + 16 * nt + col];
@@ -764,7 +896,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
 #define SP_TICK(i) do { if (SP_ABL & 64) { __builtin_amdgcn_sched_barrier(0); tk[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
         SP_TICK(0);
         const float u_explore = (explore_u && eps > 0.f) ? explore_u[__builtin_amdgcn_readfirstlane(e)] : 2.0f;     // used ~10 us later
-        {   // the next environment's taus (the last iteration re-reads its own: straight-line code); consumed from stage 5 on
+        if constexpr (!SHARED) {   // the next environment's taus (the last iteration re-reads its own: straight-line code); consumed from stage 5 on
             const int e_nx = e + e_stride < n ? e + e_stride : e;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) cj.tau[nt] = taus[(size_t)e_nx * K_TAUS + 16 * nt + col];
@@ -780,7 +912,7 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
             EncState st;
             static_for<N_ENC_SUB>([&](auto I_) { enc_substep<decltype(I_)::value>(lds, ldsv, enc_w, enc_f, lane, ov, st); });
             sc = env_scale(st.bnd, a2, d2, a3, d3);
-            store_features(lds, fb_f, lane, st, sc.S1 * c1);
+            store_features(lds, fb_f, lane, st, SHARED ? sc.S1 : sc.S1 * c1);      // (the shared layer-1 constant carries no 2^k1)
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -794,8 +926,26 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // Stage b = layer-2 MFMAs of block b + layer-1 MFMAs of block b + 2 + VALU epilogue of block b + 1, see stage()
-        f32x4 accA[2][NT], accB[2][NT];
         f16x8 bhA[NT], blA[NT], bhB[NT], blB[NT];
+        f32x4 acc3[4][NT];
+        if constexpr (SHARED) {
+            stage_sh<-1>(lds4, ldsv, lb, bhB, blB, acc2, bhA, blA);      // Hadamard + split of block 0
+            SP_TICK(3); SP_TICK(4);
+            stage_sh<0>(lds4, ldsv, lb, bhA, blA, acc2, bhB, blB);
+            SP_TICK(5);
+            stage_sh<1>(lds4, ldsv, lb, bhB, blB, acc2, bhA, blA);
+            SP_TICK(6);
+            stage_sh<2>(lds4, ldsv, lb, bhA, blA, acc2, bhB, blB);
+            SP_TICK(7);
+            stage_sh<3>(lds4, ldsv, lb, bhB, blB, acc2, bhA, blA);
+            SP_TICK(8);
+            stage_sh<4>(lds4, ldsv, lb, bhA, blA, acc2, bhB, blB);
+            SP_TICK(9);
+            stage_sh<5>(lds4, ldsv, lb, bhB, blB, acc2, bhA, blA);
+            SP_TICK(10);
+            tail<false>(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3, cj);
+        } else {
+        f32x4 accA[2][NT], accB[2][NT];
         stage<-2>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accA, accB, bhB, blB, cj);      // layer-1 block 0
         SP_TICK(3);
         stage<-1>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);      // layer-1 block 1, epilogue of block 0
@@ -812,9 +962,9 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
         SP_TICK(9);
         stage<5>(lds4, ldsv, lb, cbh, cbl, bhB, blB, acc2, accB, accA, bhA, blA, cj);
         SP_TICK(10);
-        f32x4 acc3[4][NT];
         tail(lds4, ldsv, lb, c2 * sc.r21, sc.S2, bhA, blA, acc2, acc3, cj);
         if (SP_COSJOB) cj.finish(cbh, cbl);      // (register renaming: the operands of the next environment)
+        }
         SP_TICK(11);
         const float c3e = c3 * sc.r32;      // layer-3 accumulators carry S2 2^k3: to S3
         float qv;

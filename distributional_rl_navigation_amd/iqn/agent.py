@@ -48,6 +48,7 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_fused_act = True                    # GPU tensors: fused HIP act kernel (csrc/iqn_act.hip)
         self._act_rng = None                         # the act path's own counter-based tau / exploration draws (fused_act.ActRng)
         self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
+        self.shared_taus = False                     # opt-in: one set of 32 taus per act LAUNCH instead of per row (fused_act(shared_taus=True))
         self.use_fused_graph = False                 # opt-in: the fused gradient steps of one training event as one captured hipGraph (train_steps_from_memory)
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
@@ -117,9 +118,10 @@ class IQNAgent(ReferenceLoopMixin):
             if taus is None and self.use_library_rng:
                 if self._act_rng is None:
                     self._act_rng = ActRng(self.gen.initial_seed(), states.device)
-                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, want_quantiles=True)
+                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, want_quantiles=True,
+                                 shared_taus=self.shared_taus)
             return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, taus=taus, generator=self.gen,
-                             want_quantiles=True)
+                             want_quantiles=True, shared_taus=self.shared_taus and (taus is None or taus.numel() == self.qnetwork_local.K))
         quantiles, t = self.qnetwork_local.forward(states, self.qnetwork_local.K, cvar, taus=taus)
         greedy = quantiles.mean(dim=1).argmax(dim=1).to(torch.int32)
         if eps > 0.0:
@@ -155,11 +157,11 @@ class IQNAgent(ReferenceLoopMixin):
         if states.is_cuda and self.use_fused_act:
             from .fused_act import fused_act
             if not self.use_library_rng:
-                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen)
+                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen, shared_taus=self.shared_taus)
             if self._act_rng is None:
                 from .fused_act import ActRng
                 self._act_rng = ActRng(self.gen.initial_seed(), states.device)
-            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng)
+            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, shared_taus=self.shared_taus)
         q = self.qvals_batch(states, cvar)
         greedy = q.argmax(dim=1).to(torch.int32)
         if eps <= 0.0:

@@ -36,6 +36,7 @@ class ActContext:
         self.h = h
         self._sig = None
         self.variant = self.DEFAULT_VARIANT
+        self.tau_mode = 0
         self._ptrs = (C.c_void_p * 14)()
         self._fin = weakref.finalize(self, _capi.lib().mn_iqn_destroy, h)
 
@@ -70,6 +71,16 @@ class ActContext:
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")
         self.variant = int(variant)
+
+    def set_tau_mode(self, mode):
+        """0 = every observation row its own 32 taus (default, the reference's per-call draw); 1 = one set of 32 taus per launch:
+        layer 1 of the network becomes a constant of the launch (C-ABI mn_iqn_set_tau_mode; split-f16 kernel only)."""
+        if int(mode) == self.tau_mode:
+            return
+        rc = _capi.lib().mn_iqn_set_tau_mode(self.h, int(mode))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_set_tau_mode failed ({rc})")
+        self.tau_mode = int(mode)
 
     def set_grid(self, max_workgroups):
         """0 = one persistent workgroup per CU (default); > 0 = up to that many shorter workgroups, so that other streams'
@@ -156,17 +167,23 @@ class ActRng:
 
 
 @torch.no_grad()
-def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None, want_quantiles=False):
+def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None, want_quantiles=False,
+              shared_taus=False):
     """IQNAgent.act for states [n, 26] on the GPU in ONE kernel: encoders, cosine embedding, Hadamard
     product, hidden layers, mean over K = 32 taus, argmax and epsilon-greedy.
     Returns actions [n] int32; with want_qvals (actions, Q [n, 9]); with want_quantiles -- the batched
     IQNAgent.act_eval (agent.py:217-236) -- (actions, quantiles [n, 32, 9], taus [n, 32, 1]) (+ Q if want_qvals).
     `taus` [n, 32] may be injected; otherwise, with `rng` (an ActRng) the library draws taus and exploration uniforms
-    in its own preparation launch (no torch.rand kernels), and without it they come from torch.rand on `generator`."""
+    in its own preparation launch (no torch.rand kernels), and without it they come from torch.rand on `generator`.
+    `shared_taus` (opt-in): ONE set of 32 taus (x the scalar `cvar`) for all n rows of the call instead of 32 per row -- layer 1 of
+    the network becomes a constant of the launch (mn_iqn_set_tau_mode; 216 instead of 372 matrix instructions per row).  Injected
+    `taus` are then [32]; a per-row `cvar` tensor (adaptive policies) needs per-row taus and keeps the default mode."""
     assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous()
     n = states.shape[0]
     dev = states.device
     ctx = act_context(net)
+    shared = bool(shared_taus) and not torch.is_tensor(cvar) and ctx.variant == 2
+    ctx.set_tau_mode(1 if shared else 0)
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
     quant = torch.empty(n, net.K, net.action_size, dtype=torch.float32, device=dev) if want_quantiles else None
@@ -179,7 +196,17 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
                                         _p(actions), _p(q), _p(quant), n, net.K, stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_act_rng failed ({rc})")
-        t = draws[:n * net.K].view(n, net.K)
+        t = draws[:net.K].view(1, net.K).expand(n, net.K) if shared else draws[:n * net.K].view(n, net.K)
+    elif shared:
+        t1 = (torch.rand(net.K, device=dev, generator=generator) if taus is None else taus.to(device=dev, dtype=torch.float32).reshape(-1))
+        assert t1.numel() == net.K, "shared_taus: one row of K taus"
+        t1 = (t1 * cvar if cvar != 1.0 else t1).contiguous()
+        u = torch.rand(n, device=dev, generator=generator) if eps > 0.0 else None
+        rc = _capi.lib().mn_iqn_act(ctx.h, _p(states), _p(t1), ctx.weights(net), _p(q), _p(u), C.c_float(float(eps)),
+                                    _p(actions), _p(quant), n, net.K, stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
+        t = t1.view(1, net.K).expand(n, net.K)
     else:
         if taus is None and eps > 0.0:      # one RNG launch for the n x K taus and the n exploration uniforms
             buf = torch.rand(n * (net.K + 1), device=dev, generator=generator)
@@ -194,7 +221,7 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
             raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
     out = (actions,)
     if want_quantiles:
-        out += (quant, t.clone().view(n, net.K, 1))
+        out += (quant, t.clone().view(n, net.K, 1))       # (.clone(): the library's draw buffer is reused by the next call)
     if want_qvals:
         out += (q,)
     return out if len(out) > 1 else actions
@@ -207,6 +234,7 @@ def fused_qvals(net, states, cvar=1.0, taus=None, generator=None):
     states = states.contiguous()
     n = states.shape[0]
     ctx = act_context(net)
+    ctx.set_tau_mode(0)
     t = _taus(net, n, states.device, cvar, taus, generator)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=states.device)
     stream = C.c_void_p(torch.cuda.current_stream(states.device).cuda_stream)

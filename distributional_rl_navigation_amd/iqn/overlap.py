@@ -36,6 +36,9 @@ class SplitBatchLoop:
         self.agent, self.envs = agent, list(envs)
         self.device = envs[0].device
         assert self.device.type == "cuda" and agent.use_fused_act, "SplitBatchLoop drives the fused HIP act kernel"
+        assert not getattr(agent, "shared_taus", False), "launch-shared taus read the live layer-1 weights: not with the double-buffered weight image"
+        # step_append writes 1-step transitions; the learner would discount them with GAMMA ** n_step
+        assert agent.n_step == 1, "SplitBatchLoop appends 1-step transitions (mn_step_append): n_step must be 1"
         self.n_envs = sum(e.n_envs for e in envs)
         H = len(envs)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(H)]

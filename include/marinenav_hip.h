@@ -251,6 +251,18 @@ int mn_iqn_weights_changed(mn_iqn_ctx *c);
  *      of 2; measured 4 % slower on MI355X, kept for comparison; quantile output is served by kernel 2).
  * Same network in all four; they differ by float32 rounding only. */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
+/* How an act launch's quantile fractions are drawn (round 4).
+ *   0 (default): every observation row gets its own 32 taus -- what a batch of independent calls of the reference's batch-1
+ *      IQNAgent.act (agent.py:186-205 -> model.py:149-153) would draw.  mn_iqn_act takes taus [n][32]; mn_iqn_act_rng writes
+ *      draws[0 .. 32 n) = taus, draws[32 n .. 33 n) = exploration uniforms.
+ *   1: ONE set of 32 taus (x the launch's cvar) for all n rows of the launch.  Every row still sees 32 i.i.d. U(0,1) cvar fractions per
+ *      call (the reference's act is batch-1, so independence ACROSS environments is not a reference property), but layer 1 of the
+ *      network -- relu(W1 cos(pi k tau) + b1), model.py:141-157,176-178 -- becomes a [32 x 208] constant of the launch that the
+ *      preparation launch computes once (exact float32): 216 instead of 372 matrix instructions per row, no per-row cosines.
+ *      mn_iqn_act then reads taus [32]; mn_iqn_act_rng writes draws[0 .. 32) = the taus, draws[32 .. 32 + n) = exploration uniforms.
+ *      Only with variant 2, without per-row cvar (cvar_row_dev == NULL) and without a selected image slot: else MN_ERR_INVALID.
+ * A row's result for GIVEN taus is the same function in both modes up to float32 rounding (tests). */
+int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
 /* Grid of the act kernel.  0 (default): at most one PERSISTENT workgroup per CU, each looping over its share of the observations --
  * the weight image is staged into LDS once per CU, the fastest form when nothing else runs.  max_workgroups > 0: up to that many
  * workgroups (more than CUs = several rounds of shorter workgroups, e.g. 2048 for 65 536 observations = 4 per wavefront, ~3 % more
