@@ -70,6 +70,7 @@ SIGNATURES = [
     ("mn_get_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd]),
     ("mn_get_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
     ("mn_set_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
+    ("mn_enable_obs64", C.c_int, [_vp, _i32]),
     ("mn_get_obs64", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_get_reward64", C.c_int, [_vp, _i32, _i32, _pd]),
     ("mn_enable_trajectory", C.c_int, [_vp, _i32]),

@@ -783,10 +783,10 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::OFF_FB * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::OFF_FB * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp32::iqn_qvals_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
         return MN_ERR_HIP;
@@ -923,10 +923,10 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         if (rng_state_dev) explore_u_dev = eps > 0.f ? draws_dev + K_TAUS : nullptr;
         c->dirty_sp = false;
         if (quantiles_dev)
-            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<true, true>), dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, (const float *)nullptr,
+            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<true, true, 8>), dim3(blocks), dim3(512), sp::OFF_FB * sizeof(float), s, obs_dev, (const float *)nullptr,
                                (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)c->h1_sp);
-        else
-            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<false, true>), dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, (const float *)nullptr,
+        else      // (12 waves per workgroup -- three per SIMD, the kernel needs 153 registers -- measured: 202-204 us against 203, no gain)
+            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<false, true, 8>), dim3(blocks), dim3(512), sp::OFF_FB * sizeof(float), s, obs_dev, (const float *)nullptr,
                                (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)c->h1_sp);
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;

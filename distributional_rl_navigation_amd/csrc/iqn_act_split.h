@@ -821,8 +821,9 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
 // QUANT = true : IQNAgent.act_eval (agent.py:217-236): the output layer runs per tau on the matrix pipe (12 more MFMAs on a padded
 //                16-row tile), the [n][32][9] quantile values are written out and Q is their mean.
 // SHARED = true : launch-shared taus (see stage_sh): `taus` is unused, `h1` is the launch's layer-1 constant (iqn_shared_prep_kernel).
-template <bool QUANT, bool SHARED = false>
-__global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
+// NW = wavefronts per workgroup (one workgroup per CU): 8 = two per SIMD; the shared-tau form needs ~155 registers and also runs three per SIMD.
+template <bool QUANT, bool SHARED = false, int NW = WAVES>
+__global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                                  const uint32_t *__restrict__ packed, float *__restrict__ qvals,
                                                                  const float *__restrict__ explore_u, float eps,
                                                                  int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state,
@@ -848,10 +849,14 @@ __global__ __launch_bounds__(64 * WAVES) void iqn_qvals_split_kernel(const float
     const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
     const u32x4 *lds4 = reinterpret_cast<const u32x4 *>(lds);
     LdsBase lb;
-    lb.w_lo = lane; lb.w_hi = lane + 4096; lb.fl = (OFF_B1 >> 2) + g; lb.fb = ((OFF_FB + wave * F) >> 2) + g;
+    // per-wave feature buffer: behind the image; shared-tau form: in the rest of the W1 region, behind the layer-1 constant
+    constexpr int FB0 = SHARED ? H1_FLOATS : OFF_FB;
+    static_assert(!SHARED || H1_FLOATS + NW * F <= W2_U4 * 4, "feature buffers of the shared-tau kernel fit into the W1 region");
+    static_assert(SHARED || NW <= WAVES, "feature buffers behind the image: WAVES of them");
+    lb.w_lo = lane; lb.w_hi = lane + 4096; lb.fl = (OFF_B1 >> 2) + g; lb.fb = ((FB0 + wave * F) >> 2) + g;
     int enc_w = (OFF_WS >> 2) + lane;       // sensor encoder weights (16-byte units)
     int enc_f = OFF_BND + lane;             // bounds / encoder biases (floats)
-    int fb_f = OFF_FB + wave * F + lane;    // this wave's feature buffer (floats)
+    int fb_f = FB0 + wave * F + lane;       // this wave's feature buffer (floats)
     asm volatile("" : "+v"(lb.w_lo), "+v"(lb.w_hi), "+v"(lb.fl), "+v"(lb.fb), "+v"(enc_w), "+v"(enc_f), "+v"(fb_f));
     const float c1 = lds[OFF_CST + 0], c2 = lds[OFF_CST + 1], c3 = lds[OFF_CST + 2];
     const float a2 = lds[OFF_CST + 3], d2 = lds[OFF_CST + 4], a3 = lds[OFF_CST + 5], d3 = lds[OFF_CST + 6];

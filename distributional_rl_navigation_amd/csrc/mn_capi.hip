@@ -21,6 +21,7 @@ struct mn_handle {
     uint32_t *mask_count = nullptr;
     int32_t *list_scratch = nullptr;
     double *peek_scratch = nullptr;
+    double *obs64_buf = nullptr, *rew64_buf = nullptr;      // mn_enable_obs64: A.obs64 / A.rew64 point here while enabled
     int device = -1;      // HIP device the handle's memory lives on (the caller's current device at mn_create)
     // profiling
     std::vector<hipEvent_t> ev;
@@ -185,7 +186,7 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     ALLOC(qox, np * MN_MAX_OBS) ALLOC(qoy, np * MN_MAX_OBS) ALLOC(qor, np * MN_MAX_OBS)
     ALLOC(mt, np * 624) ALLOC(mt_pos, np)
     ALLOC(queue_count, 2) ALLOC(queue, np)
-    if (p->precision == MN_PRECISION_F64) { ALLOC(obs64, np * MN_OBS_DIM) ALLOC(rew64, np) }
+    // (obs64 / rew64 -- float64 copies of the last observation rows / rewards -- are allocated and written only after mn_enable_obs64)
 #undef ALLOC
     if ((rc = dev_alloc(h, &h->seeds_dev, np)) || (rc = dev_alloc(h, &h->mask_count, 1)) ||
         (rc = dev_alloc(h, &h->list_scratch, np)) || (rc = dev_alloc(h, &h->peek_scratch, np))) {
@@ -527,7 +528,7 @@ extern "C" int mn_get_obs64(mn_handle *h, int32_t first, int32_t count, double *
     if (rc) return rc;
     if (count == 0) return MN_OK;
     if (!out) return MN_ERR_INVALID;
-    if (!h->A.obs64) return fail(h, MN_ERR_INVALID, "float64 observations are kept only with MN_PRECISION_F64");
+    if (!h->A.obs64) return fail(h, MN_ERR_INVALID, "float64 observations are kept only with MN_PRECISION_F64 after mn_enable_obs64(h, 1)");
     MN_HIP(h, hipDeviceSynchronize());
     MN_HIP(h, hipMemcpy(out, h->A.obs64 + (size_t)first * MN_OBS_DIM, (size_t)count * MN_OBS_DIM * 8, hipMemcpyDeviceToHost));
     return MN_OK;
@@ -538,9 +539,24 @@ extern "C" int mn_get_reward64(mn_handle *h, int32_t first, int32_t count, doubl
     if (rc) return rc;
     if (count == 0) return MN_OK;
     if (!out) return MN_ERR_INVALID;
-    if (!h->A.rew64) return fail(h, MN_ERR_INVALID, "float64 rewards are kept only with MN_PRECISION_F64");
+    if (!h->A.rew64) return fail(h, MN_ERR_INVALID, "float64 rewards are kept only with MN_PRECISION_F64 after mn_enable_obs64(h, 1)");
     MN_HIP(h, hipDeviceSynchronize());
     MN_HIP(h, hipMemcpy(out, h->A.rew64 + first, (size_t)count * 8, hipMemcpyDeviceToHost));
+    return MN_OK;
+}
+
+extern "C" int mn_enable_obs64(mn_handle *h, int32_t on) {
+    if (!h || on < 0 || on > 1) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
+    if (h->params.precision != MN_PRECISION_F64) return fail(h, MN_ERR_INVALID, "float64 observation copies exist only with MN_PRECISION_F64");
+    MN_HIP(h, hipDeviceSynchronize());
+    if (!on) { h->A.obs64 = nullptr; h->A.rew64 = nullptr; return MN_OK; }      // the buffers stay owned by the handle
+    if (!h->obs64_buf) {
+        int rc = dev_alloc(h, &h->obs64_buf, (size_t)h->A.npad * MN_OBS_DIM);
+        if (rc == MN_OK) rc = dev_alloc(h, &h->rew64_buf, (size_t)h->A.npad);
+        if (rc) return rc;
+    }
+    h->A.obs64 = h->obs64_buf; h->A.rew64 = h->rew64_buf;
     return MN_OK;
 }
 

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES(L)) void mn_rollout_k
         float *trow = T.obs ? T.obs + ((size_t)t * n + e) * MN_OBS_DIM : nullptr;
         float *orow = obs_out + (size_t)e * MN_OBS_DIM;
         const MnStepOut o = ln.template step<false>(A, P, action, (last || !trow) ? orow : trow,
-                                                    PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none, nullptr, nullptr,
+                                                    (PARITY && A.obs64) ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none, nullptr, nullptr,
                                                     (last && trow) ? trow : nullptr);
         stepped = true;
 #ifdef MN_ABLATION

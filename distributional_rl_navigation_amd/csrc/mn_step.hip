@@ -36,7 +36,7 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     }
 
     const MnStepOut o = ln.template step<APPEND>(A, P, action, obs_out + (size_t)e * MN_OBS_DIM,
-                                                 PARITY ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, R, prev_head, prev_beam);
+                                                 (PARITY && A.obs64) ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, R, prev_head, prev_beam);
     ln.store(A);
     if (ln.active && q == 0) {
         reward_out[e] = (float)o.reward;

@@ -503,7 +503,7 @@ struct MnLane {
                         R.dones[slot] = done ? 1.0f : 0.0f;
                     }
                 }
-                if (PARITY) {
+                if (PARITY && obs_row64) {      // float64 copies for parity checks: only after mn_enable_obs64 (wave-uniform)
                     A.rew64[e] = reward;
                     obs_row64[0] = (double)o0; obs_row64[1] = (double)o1; obs_row64[2] = (double)o2; obs_row64[3] = (double)o3;
                 }
@@ -518,7 +518,7 @@ struct MnLane {
                     if constexpr (APPEND) {
                         if (rs) { rs[2 + b] = prev_beam[j]; rn[2 + b] = make_float2((float)bxo[j], (float)byo[j]); }
                     }
-                    if (PARITY) { obs_row64[4 + 2 * b] = (double)bxo[j]; obs_row64[5 + 2 * b] = (double)byo[j]; }
+                    if (PARITY && obs_row64) { obs_row64[4 + 2 * b] = (double)bxo[j]; obs_row64[5 + 2 * b] = (double)byo[j]; }
                 }
             }
         }

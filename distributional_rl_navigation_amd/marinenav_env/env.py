@@ -137,7 +137,7 @@ _SCALAR_ATTRS = ("width", "height", "r", "v_rel_max", "p", "clear_r", "goal_dis"
 class MarineNavEnv(_Base):
     def __init__(self, seed: int = 0, schedule: dict = None, device="cuda:0"):
         object.__setattr__(self, "_ready", False)
-        self._venv = VecMarineNavEnv(1, seeds=[seed], schedule=schedule, device=device, precision="f64")
+        self._venv = VecMarineNavEnv(1, seeds=[seed], schedule=schedule, device=device, precision="f64", obs64=True)
         self.sd = seed
         self.robot = _RobotView(self)
         self.action_space = _Discrete(9) if _gym is None else _gym.spaces.Discrete(9)

@@ -50,7 +50,7 @@ class VecMarineNavEnv:
     """
 
     def __init__(self, n_envs, seed=0, seeds=None, schedule=None, device="cuda:0", precision="mixed",
-                 timestep_scale=1.0, first_index=0, params=None, step_lanes=0, rollout_lanes=0):
+                 timestep_scale=1.0, first_index=0, params=None, step_lanes=0, rollout_lanes=0, obs64=False):
         if not torch.cuda.is_available():
             raise _capi.MarineNavHipError("VecMarineNavEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.L = _capi.lib()
@@ -68,6 +68,9 @@ class VecMarineNavEnv:
             raise _capi.MarineNavHipError(f"mn_create failed ({rc}): {self.L.mn_last_error(None).decode()}")
         self.h = h
         self.first_index = int(first_index)
+        self.obs64_enabled = False
+        if obs64:      # float64 copies of observations / rewards (parity checks, the n = 1 facade); off in the training loop
+            self.enable_obs64(True)
         if seeds is None:
             seeds = shard_seeds(self.n_envs, seed, first_index)
         self.seed(seeds)
@@ -335,6 +338,13 @@ class VecMarineNavEnv:
                                         _np_ptr(s, C.c_double) if s is not None else None,
                                         _np_ptr(ep, C.c_int32) if ep is not None else None,
                                         _np_ptr(tot, C.c_int64) if tot is not None else None))
+
+    def enable_obs64(self, on=True):
+        """Keep float64 copies of every later step's / reset's observation rows and rewards (`get_obs64`, `get_reward64`; f64 handles).
+        Off by default: the training loop never reads them (C-ABI mn_enable_obs64)."""
+        torch.cuda.synchronize(self.device)
+        self._check(self.L.mn_enable_obs64(self.h, 1 if on else 0))
+        self.obs64_enabled = bool(on)
 
     def get_obs64(self, first_env=0, count=None):
         cnt = self.n_envs - first_env if count is None else count

@@ -206,6 +206,12 @@ int mn_set_state(mn_handle *h, int32_t first_env, int32_t count, const double *s
 
 /* Float64 copy of the last observation each env produced (the reference returns float64,
  * marinenav_env.py:326).  Only kept when precision == MN_PRECISION_F64; out[count][26]. */
+/* Float64 copies of the last observation rows / rewards (what the reference's float64 step returns before the agent's .float()),
+ * for parity checks and the n = 1 gym-shaped facade.  OFF by default since round 4 -- the training loop does not read them and they
+ * were 14 MB of the step kernel's 39 MB of writes per 65 536-env launch: mn_enable_obs64(h, 1) (MN_PRECISION_F64 handles only) makes
+ * every later mn_step / mn_step_append / mn_reset* / mn_rollout write them; (h, 0) stops again.  mn_get_obs64 / mn_get_reward64 return
+ * MN_ERR_INVALID while disabled.  Enabling does not change any other output (bit-identity tests). */
+int mn_enable_obs64(mn_handle *h, int32_t on);
 int mn_get_obs64(mn_handle *h, int32_t first_env, int32_t count, double *out);
 /* Float64 copy of the last reward (marinenav_env.py:220-255 computes it in float64); same rule. */
 int mn_get_reward64(mn_handle *h, int32_t first_env, int32_t count, double *out);

@@ -318,6 +318,12 @@ int mn_set_state(mn_handle *h, int32_t first, int32_t count, const double *state
     return MN_OK;
 }
 
+/* the twin always computes in float64 and always keeps the copies: the switch only has to exist */
+int mn_enable_obs64(mn_handle *h, int32_t on) {
+    if (!h || on < 0 || on > 1) return MN_ERR_INVALID;
+    return MN_OK;
+}
+
 int mn_get_obs64(mn_handle *h, int32_t first, int32_t count, double *out) {
     int rc = range_ok(h, first, count);
     if (rc) return rc;

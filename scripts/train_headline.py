@@ -27,6 +27,7 @@ ap.add_argument("--vector-steps", type=int, default=0, help="length of the run t
 ap.add_argument("--evals", type=int, default=10)
 ap.add_argument("--seed", type=int, default=100)
 ap.add_argument("--cvar", type=float, default=1.0)
+ap.add_argument("--shared-taus", action="store_true", help="acting: one set of 32 taus per launch instead of per env (IQNAgent.shared_taus); the learner is unchanged")
 args = ap.parse_args()
 
 with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "eval_config_seed3.json")) as f:
@@ -39,8 +40,9 @@ eval_env = VecMarineNavEnv(30, device="cuda:0", precision="f64")
 agent = IQNAgent(26, 9, BATCH_SIZE=args.batch, BUFFER_SIZE=args.replay, device="cuda:0", seed=args.seed, learning_starts=0,
                  UPDATE_EVERY=args.update_every)
 agent.grad_steps_per_update = args.grad_steps
+agent.shared_taus = args.shared_taus
 agent.target_sync_grad_steps = plan["target_sync_grad_steps"]
-print(f"# {n} envs, replay {args.replay}, batch {args.batch}: {args.grad_steps} grad step(s) every {args.update_every} vector step(s); "
+print(f"# seed {args.seed}, act taus {'shared per launch' if args.shared_taus else 'per env'}; {n} envs, replay {args.replay}, batch {args.batch}: {args.grad_steps} grad step(s) every {args.update_every} vector step(s); "
       f"eps ramp / curriculum over {V} vector steps ({V * n:.3g} env steps); target copy every {agent.target_sync_grad_steps} grad steps; "
       f"replay ratio {args.grad_steps * args.batch / (args.update_every * n):.4f} sampled / generated transition", flush=True)
 

@@ -177,19 +177,19 @@ def test_library_draw_path(torch):
     obs, _ = _inputs(torch, 20000, 5.0)
     n = obs.shape[0]
     rng = ActRng(123, DEV)
-    a, z, t, q = fused_act(net, obs, 0.0, 0.5, rng=rng, want_quantiles=True, want_qvals=True, shared_taus=True)
+    a, q = fused_act(net, obs, 0.0, 0.5, rng=rng, want_qvals=True, shared_taus=True)
     assert int(rng.state[1]) == 1
-    row = t[0, :, 0].clone()
-    assert bool((t[:, :, 0] == row.view(1, 32)).all()) and float(row.min()) >= 0.0 and float(row.max()) < 0.5
+    row = rng.draws(n, 32)[:32].clone()
+    assert float(row.min()) >= 0.0 and float(row.max()) < 0.5 and float(row.max()) > 0.25
     # the same taus injected (cvar already applied) give the same Q-values bit for bit
     _, q_inj = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
     assert torch.equal(q, q_inj) and bool((a.long() == q.argmax(1)).all())
     # next call: other taus; a fresh generator with the same seed reproduces the first call
     _, _, t2 = fused_act(net, obs, 0.0, 0.5, rng=rng, want_quantiles=True, shared_taus=True)
-    assert int(rng.state[1]) == 2 and not torch.equal(t2, t)
+    assert int(rng.state[1]) == 2 and t2.shape == (n, 32, 1) and bool((t2 == t2[0:1]).all()) and not torch.equal(t2[0, :, 0], row)
     rng_b = ActRng(123, DEV)
-    a_b, _, t_b = fused_act(net, obs, 0.0, 0.5, rng=rng_b, want_quantiles=True, shared_taus=True)
-    assert torch.equal(t_b, t) and torch.equal(a_b, a)
+    a_b, _, t_b = fused_act(net, obs, 0.0, 0.5, rng=rng_b, want_quantiles=True, shared_taus=True)      # (act_eval's kernel: the same draws)
+    assert torch.equal(t_b[0, :, 0], row) and float((a_b != a).float().mean()) < 1e-3
     # exploration
     a_e = fused_act(net, obs, 1.0, 1.0, rng=rng, shared_taus=True)
     cnt = torch.bincount(a_e.long(), minlength=9).float() / n

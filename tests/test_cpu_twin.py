@@ -15,7 +15,7 @@ G = os.path.join(ROOT, "tests", "golden")
 TWIN = os.path.join(ROOT, "oracle", "libmarinenav_cpu.so")
 ENV_SYMBOLS = ("mn_default_params", "mn_create", "mn_destroy", "mn_last_error", "mn_num_envs", "mn_set_params", "mn_get_params",
                "mn_seed", "mn_set_schedule", "mn_set_start_goal", "mn_reset", "mn_step", "mn_step_append", "mn_build_info",
-               "mn_reset_done", "mn_load_worlds", "mn_get_worlds", "mn_get_state", "mn_set_state", "mn_get_obs64",
+               "mn_reset_done", "mn_load_worlds", "mn_get_worlds", "mn_get_state", "mn_set_state", "mn_enable_obs64", "mn_get_obs64",
                "mn_get_reward64", "mn_peek_next_double", "mn_last_done_count", "mn_profile_begin", "mn_profile_end")
 
 
@@ -40,6 +40,8 @@ class Driver:
         self.p.precision = precision
         self.h = C.c_void_p()
         assert L.mn_create(n, C.byref(self.p), C.byref(self.h)) == 0, L.mn_last_error(None)
+        if precision == _capi.PRECISION_F64:
+            assert L.mn_enable_obs64(self.h, 1) == 0      # float64 observation / reward copies are opt-in
         s = np.ascontiguousarray(np.arange(n) if seeds is None else seeds, dtype=np.uint32)
         assert L.mn_seed(self.h, s.ctypes.data_as(C.POINTER(C.c_uint32)), None) == 0
         self.obs = [alloc((n, 26), np.float32), alloc((n, 26), np.float32)]

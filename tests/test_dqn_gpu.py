@@ -41,7 +41,7 @@ def test_dqn_closed_loop_on_hip_env(torch):
     with open(os.path.join(G, "eval_config_seed3.json")) as f:
         cfg = json.load(f)
     pol = DQNPolicy.load(os.path.join(G, "pretrained_DQN_seed3", "q_net.npz"), device="cuda:0")
-    env = VecMarineNavEnv(30, device="cuda:0", precision="f64")
+    env = VecMarineNavEnv(30, device="cuda:0", precision="f64", obs64=True)
     obs = env.load_worlds([VecMarineNavEnv.world_from_eval_config(c) for c in cfg.values()]).clone()
     rec, lens = g["eval_actions"].astype(np.int64), g["eval_len"]
     following = np.ones(30, dtype=bool)            # still on the recorded trajectory

@@ -122,14 +122,16 @@ def test_fused_step_two_ranks_equals_big_batch(torch, tmp_path):
     np.testing.assert_allclose(res["params"].numpy(), ref._fused.local.cpu().numpy(), rtol=0, atol=2e-6)
 
 
-def test_shards_equal_slices_at_config3_size(torch):
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+def test_shards_equal_slices_at_config3_size(torch, precision):
     """BASELINE configs[3]: 524 288 envs as 8 shards of 65 536 (rank r: first_index = r * 65 536).  One 524 288-env
     handle vs the eight shard handles, same actions: worlds, observations, rewards, done flags and counters of shard
-    r are bitwise rows [r n, (r+1) n) of the big run, through resets (mixed precision = what the bench runs)."""
+    r are bitwise rows [r n, (r+1) n) of the big run, through resets -- in float64 (what `bench.py --gpus N` runs with a learner
+    in the loop, `bench.default_precision`) and in the kernel-only configs' mixed precision."""
     from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
     n, world, T = 65536, 8, 6
     dev = "cuda:0"
-    big = VecMarineNavEnv(n * world, seed=0, device=dev, precision="mixed")
+    big = VecMarineNavEnv(n * world, seed=0, device=dev, precision=precision)
     big.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
     ob = big.reset().clone()
     g = torch.Generator(device=dev); g.manual_seed(0)
@@ -145,7 +147,7 @@ def test_shards_equal_slices_at_config3_size(torch):
     big.close()
     total_done = 0
     for r_ in range(world):
-        sh = VecMarineNavEnv(n, seed=0, first_index=r_ * n, device=dev, precision="mixed")
+        sh = VecMarineNavEnv(n, seed=0, first_index=r_ * n, device=dev, precision=precision)
         sh.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
         sl = slice(r_ * n, (r_ + 1) * n)
         assert torch.equal(sh.reset(), ob[sl])

@@ -18,7 +18,7 @@ def torch():
 
 def _make(n, precision, **kw):
     from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
-    env = VecMarineNavEnv(n, seed=5, device="cuda:0", precision=precision, **kw)
+    env = VecMarineNavEnv(n, seed=5, device="cuda:0", precision=precision, obs64=precision == "f64", **kw)
     env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
     return env
 
