@@ -91,6 +91,35 @@ def cpu_baseline_all_cores(n_steps_each, world, threads):
     return threads * n_steps_each / dt, dt
 
 
+def gpu_clock_probe(device, target_ms=50.0):
+    """The clock this GPU holds under f16 matrix load (C-ABI mn_probe_mfma_clock: a pure stream of the act kernel's matrix instruction on
+    every CU for ~50 ms).  The same act binary runs 10-12 % slower on some boxes of the pool; with this in the line a reader can tell a
+    slow box from a slow kernel (launch time x clock = the kernel's cycles, which do not depend on the box)."""
+    import ctypes as C
+    import torch
+    from distributional_rl_navigation_amd import _capi
+    out = (C.c_double * 5)()
+    with torch.cuda.device(device):
+        rc = _capi.lib().mn_probe_mfma_clock(C.c_double(target_ms), out, C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    if rc:
+        return {"error": rc}
+    return {"probe_ms": out[0], "mfma_clock_ghz": out[1], "wave_counter_clock_ghz": out[2], "f16_mfma_tflops_sustained": out[3], "n_cu": int(out[4]),
+            "how": "pure v_mfma_f32_16x16x32_f16 stream, 2 waves per SIMD on every CU; clock = 16 cycles x instructions per SIMD / elapsed"}
+
+
+def rocm_smi_power():
+    """Power cap / average power / clocks as rocm-smi reports them, if it is there and answers (never fails the run)."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout[r.stdout.index("{"):])
+        card = j.get("card0", next(iter(j.values())))
+        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("power", "sclk", "mclk"))}
+        return keep or None
+    except Exception as e:
+        return {"unavailable": repr(e)[:120]}
+
+
 def _timed(device, fn, steps, warmup, state, before_timed=None):
     """W untimed + K timed calls of fn(state) -> state, bracketed by device synchronisation.  Returns (seconds, state)."""
     import torch
@@ -202,31 +231,48 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
     agent.UPDATE_EVERY, agent.grad_steps_per_update = ue, gs
     # (c) configs[1]
     n1 = 4096
-    e1 = VecMarineNavEnv(n1, seed=0, device=device, precision="mixed")
-    e1.set_attrs(num_cores=args.cores, num_obs=args.obstacles, min_start_goal_dis={4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0))
-    e1.reset()
-    gen = torch.Generator(device=device); gen.manual_seed(0)
-    bytes_step = BYTES_PER_ENV_STEP.get((args.cores, args.obstacles), 190 + 12 * (args.cores + args.obstacles))
 
-    def pair(_):
-        e1.step(torch.randint(0, 9, (n1,), device=device, dtype=torch.int32, generator=gen))
-        return e1.reset_done()
-    dt, _ = _timed(device, pair, 1000, 100, None, lambda: e1.profile_begin(50))
-    k_ms, _ = e1.profile_end()
-    single = {"value": n1 * 1000 / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / 1000, "steps": 1000,
-              "step_kernel_ms": k_ms, "hbm_frac_406B": bytes_step * n1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
-              "hbm_frac_406B_wall": bytes_step * n1 * 1000 / dt / 1e9 / HBM_PEAK_GBS}
-    T, ctr = 100, [0]
+    def config1(cores, obstacles, min_dis, precision, single_steps=1000):
+        """4 096 envs, random policy, step kernel only: (single launch pairs, mn_rollout T = 100) for one world size and arithmetic."""
+        e1 = VecMarineNavEnv(n1, seed=0, device=device, precision=precision)
+        e1.set_attrs(num_cores=cores, num_obs=obstacles, min_start_goal_dis=min_dis)
+        e1.reset()
+        gen = torch.Generator(device=device); gen.manual_seed(0)
+        bytes_step = BYTES_PER_ENV_STEP.get((cores, obstacles), 190 + 12 * (cores + obstacles))
 
-    def roll_launch(_):
-        e1.rollout(T, action_seed=0, first_step=ctr[0], trace=("obs", "reward", "done"))
-        ctr[0] += T
-    dt, _ = _timed(device, roll_launch, 10, 2, None, lambda: e1.profile_begin(10))
-    k_ms, _ = e1.profile_end()
-    rollout = {"value": n1 * T * 10 / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / (T * 10), "steps": T * 10, "steps_per_launch": T,
-               "launch_ms": k_ms, "hbm_frac_406B": bytes_step * n1 * T / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
-    e1.close()
-    out["config1"] = {"envs": n1, "precision": "mixed", "single_launch_pair": single, "mn_rollout": rollout}
+        def pair(_):
+            e1.step(torch.randint(0, 9, (n1,), device=device, dtype=torch.int32, generator=gen))
+            return e1.reset_done()
+        dt, _ = _timed(device, pair, single_steps, 100, None, lambda: e1.profile_begin(50))
+        k_ms, _ = e1.profile_end()
+        single = {"value": n1 * single_steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / single_steps, "steps": single_steps,
+                  "step_kernel_ms": k_ms, "algorithmic_bytes_per_env_step": bytes_step,
+                  "hbm_frac": bytes_step * n1 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+                  "hbm_frac_wall": bytes_step * n1 * single_steps / dt / 1e9 / HBM_PEAK_GBS}
+        T, ctr = 100, [0]
+
+        def roll_launch(_):
+            e1.rollout(T, action_seed=0, first_step=ctr[0], trace=("obs", "reward", "done"))
+            ctr[0] += T
+        dt, _ = _timed(device, roll_launch, 10, 2, None, lambda: e1.profile_begin(10))
+        k_ms, _ = e1.profile_end()
+        rollout = {"value": n1 * T * 10 / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / (T * 10), "steps": T * 10, "steps_per_launch": T,
+                   "launch_ms": k_ms, "algorithmic_bytes_per_env_step": bytes_step,
+                   "hbm_frac": bytes_step * n1 * T / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
+        e1.close()
+        return single, rollout
+    single, rollout = config1(args.cores, args.obstacles, {4: 30.0, 6: 35.0, 8: 40.0}.get(args.cores, 25.0), "mixed")
+    # SURVEY 8(d) C2: stage 2 (8 cores / 10 obstacles, the headline world), the reference's default world (8 / 5, marinenav_env.py:62-63) and
+    # curriculum stage 0 (4 / 6, train_IQN_model.py:85-88); in the float64 kernels (north-star tolerance with zero outliers) and in mixed precision
+    worlds = {}
+    for (nc, no, md) in ((8, 10, 40.0), (8, 5, 25.0), (4, 6, 30.0)):
+        for prec in ("f64", "mixed"):
+            if (nc, no, prec) == (args.cores, args.obstacles, "mixed"):
+                s_, r_ = single, rollout
+            else:
+                s_, r_ = config1(nc, no, md, prec, single_steps=500)
+            worlds.setdefault(f"{nc}_cores_{no}_obstacles", {})[prec] = {"single_launch_pair": s_, "mn_rollout": r_}
+    out["config1"] = {"envs": n1, "precision": "mixed", "single_launch_pair": single, "mn_rollout": rollout, "worlds": worlds}
     # (d) learner alone, without / with a single-rank RCCL group
     def learner_rate(reps=400):
         for _ in range(10):
@@ -437,6 +483,7 @@ def main():
         act_context(agent.qnetwork_local).set_variant(args.act_variant)
     obs = run_steps(args.warmup, obs)
     g0 = agent.grad_steps if agent else 0
+    clock_before = gpu_clock_probe(device) if rank == 0 else None      # ~50 ms of matrix load, outside the timed region
     fence()
     # HIP-event pairs are recorded around the first n_prof act / step launches of the timed region; not around all of
     # them, because the four event records per vector step cost ~18 us of stream time (measured: 1.079 ms/step with
@@ -456,6 +503,7 @@ def main():
     if fused:
         act_ms, act_launches = act_context(agent.qnetwork_local).profile_end()
     grad_steps = (agent.grad_steps - g0) if agent else 0
+    clock_after = gpu_clock_probe(device) if rank == 0 else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -562,6 +610,8 @@ def main():
             "learner_only_grad_steps_per_sec_per_gpu": learner_only,   # sample + train back to back, outside the timed region
             # further configurations timed by THIS run, after the main timed region (N = 1 only): see also_legs()
             "also": also,
+            # which clock this box sustains under f16 matrix load, probed right before and right after the timed region, + rocm-smi's view
+            "gpu_clock_probe": {"before_timed_region": clock_before, "after_timed_region": clock_after, "rocm_smi": rocm_smi_power()},
             "roofline_env_step": {
                 "precision": args.precision,
                 "kernel": (lambda t_: f"mn_rollout_kernel<{t_},L>" if roll else (f"mn_step_kernel<{t_},L,APPEND=true> (step + replay append)" if fused_append else f"mn_step_kernel<{t_},L>"))
@@ -617,7 +667,11 @@ def main():
                 "algorithmic_flop_per_env_step": ACT_FLOP_PER_ENV_STEP, "algorithmic_tflops": alg_tf,
                 "algorithmic_tflops_over_f32_mfma_peak": alg_tf / F32_MFMA_PEAK_TFLOPS,
                 "launch_ms": act_ms, "launches_timed": act_launches, "env_steps_per_launch": n_act,
+                # box-independent form of launch_ms: the launch's duration in cycles of the clock the probe measured (mean of before / after)
+                "act_effective_clock_ghz": (lambda cs: sum(cs) / len(cs) if cs else None)([c["mfma_clock_ghz"] for c in (clock_before, clock_after) if c and "mfma_clock_ghz" in c]),
             }
+            ghz = out["roofline"]["act_effective_clock_ghz"]
+            out["roofline"]["launch_kilocycles_at_that_clock"] = act_ms * 1e-3 * ghz * 1e9 / 1e3 if ghz else None
         else:
             out["roofline"] = out["roofline_env_step"]
         if args.cpu_steps > 0 and world == 1:      # reported baseline: rank 0 at N = 1 only
@@ -627,6 +681,10 @@ def main():
                 "sample": f"{args.cpu_steps} steps of one env (oracle/marinenav_oracle.c, float64 scalar), "
                           f"{args.cores} cores / {args.obstacles} obstacles, random actions, resets included, {dt:.1f} s",
                 "host_cpus": os.cpu_count(),
+                # the reference's own Python step() cannot travel to the GPU box; its rate was measured where the reference can be imported
+                "reference_python": {"value": 293, "unit": "env steps/s", "cores": 1, "where": "build container, 8 vCPU Xeon 2.1 GHz",
+                                     "what": "the reference's MarineNavEnv.step (marinenav_env.py:199), 8 cores / 10 obstacles, 1 process, random actions, resets included "
+                                             "(default world 8 / 5: 275; stage 0, 4 / 6: 604; 8 processes: ~1 800 aggregate)", "source": "BASELINE.md section 2"},
             }
             nth = min(64, len(os.sched_getaffinity(0))) if args.cpu_threads < 0 else args.cpu_threads
             if nth > 1:

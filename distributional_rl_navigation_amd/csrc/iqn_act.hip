@@ -732,10 +732,83 @@ __global__ __launch_bounds__(256) void iqn_prep32_kernel(IqnWeights w, float *__
 #include "iqn_act_split.h"
 #include "iqn_act_split32.h"
 
+// ---- what clock does THIS GPU sustain under f16 matrix load?  (mn_probe_mfma_clock; round 4)
+// The same act binary runs 10-12 % slower on some boxes of the pool (304-318 us vs 352-367 us per 65 536-env launch) while the
+// exact-f32 kernel does not move.  This probe separates a slow box from a slow kernel: a pure stream of v_mfma_f32_16x16x32_f16 -- the act
+// kernel's matrix instruction -- from two waves per SIMD on every CU.  The instruction occupies the SIMD's matrix pipe for 16 cycles
+// (4 passes), so with the pipe saturated   effective clock = 16 x (matrix instructions per SIMD) / elapsed time.
+// Wave 0 of every workgroup also brackets its loop with s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz).
+__global__ __launch_bounds__(512) void mfma_clock_probe_kernel(int iters, unsigned long long *__restrict__ stamps, float *__restrict__ sink) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    h8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (lane + i)); b[i] = (_Float16)(0.002f * (lane - i)); }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (s == 12345.678f) sink[0] = s;      // keeps the accumulators alive
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 }  // namespace
 
 // C-ABI ----------------------------------------------------------------------------------------------
 #include <vector>
+
+extern "C" int mn_probe_mfma_clock(double target_ms, double *out, void *stream) {
+    if (!out || !(target_ms > 0.0) || target_ms > 2000.0) return MN_ERR_INVALID;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_NO_DEVICE;
+    const int n_cu = prop.multiProcessorCount;
+    unsigned long long *stamps = nullptr;
+    float *sink = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&stamps), 2 * n_cu * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&sink), sizeof(float)) != hipSuccess) { (void)hipFree(stamps); return MN_ERR_ALLOC; }
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    int rc = MN_OK;
+    int iters = 2000;
+    float ms = 0.f;
+    for (int pass = 0; pass < 2 && rc == MN_OK; ++pass) {      // pass 0 calibrates the loop count, pass 1 is the measurement
+        (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(mfma_clock_probe_kernel, dim3(n_cu), dim3(512), 0, s, iters, stamps, sink);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) { rc = MN_ERR_HIP; break; }
+        if (pass == 0) {
+            double scaled = iters * target_ms / ms;
+            iters = scaled > 5e7 ? 50000000 : (scaled < 100 ? 100 : (int)scaled);
+        }
+    }
+    if (rc == MN_OK) {
+        std::vector<unsigned long long> h(2 * n_cu);
+        if (hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = MN_ERR_HIP;
+        else {
+            double ct = 0, rt = 0;
+            for (int i = 0; i < n_cu; ++i) { ct += (double)h[2 * i]; rt += (double)h[2 * i + 1]; }
+            const double per_simd = 2.0 * iters * 16.0;      // two waves per SIMD, 16 matrix instructions per loop iteration
+            out[0] = ms;
+            out[1] = 16.0 * per_simd / (ms * 1e-3) / 1e9;     // GHz the matrix pipe ran at, if saturated
+            out[2] = rt > 0 ? ct / rt * 0.1 : 0.0;            // GHz by the wave's own counters: shader ticks per 100 MHz tick
+            out[3] = per_simd * 4.0 * n_cu * 16384.0 / (ms * 1e-3) / 1e12;      // sustained f16 TFLOP/s of the whole chip (2 x 16 x 16 x 32 FLOP each)
+            out[4] = (double)n_cu;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(stamps); (void)hipFree(sink);
+    return rc;
+}
 
 // Per-caller state of the act path: the permuted LDS weight image (cached between calls until the caller says the
 // weights changed), the profiling events.  One context per agent / per stream: two contexts never share a buffer, so

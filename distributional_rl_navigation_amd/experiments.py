@@ -75,7 +75,10 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     out_of_area, reward, actions)} with one entry per world.  With `capture` each policy also gets the reference's `ep_data`
     list (run_experiments.py:26-69,262-282): per episode the episode_data() dict incl. the sub-step trajectory, and for the
     IQN policies the per-action CVaR level, quantile values [1,32,9] and taus [1,32,1] of IQNAgent.act_eval -- the whole
-    `exp_data` JSON the reference dumps, minus wall-clock `computation_times` (batched: meaningless per env)."""
+    `exp_data` JSON the reference dumps.  `computation_times` (run_experiments.py:30,37-44,254-255: the wall-clock seconds of every
+    act call, flattened over a policy's episodes) is the batched equivalent: the device time of the step's act launch(es) for that
+    policy group (HIP events) divided by the rows the launch served, one entry per step of every episode -- the amortised cost of one
+    action, which is what `avg_compute_t` (run_experiments.py:274) averages."""
     worlds = generate_worlds(num, n_obs, n_cores, seed, device)
     n = num * len(policies)
     env = VecMarineNavEnv(n, device=device, precision="f64")
@@ -107,27 +110,41 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     last_info = torch.zeros(n, dtype=torch.uint8, device=dev)
     acts = torch.full((max_steps, n), -1, dtype=torch.int32, device=dev)
     cap_cv, cap_q, cap_t, cap_traj = [], [], [], []
+    act_events = {}                                                # group -> [(start, end)] per step; groups: "IQN" (one launch for all IQN policies), planners
+    alive_hist = []                                                # per step: live envs per policy (before the step)
+
+    def timed(group, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        act_events.setdefault(group, []).append((e0, e1))
+        return r
     if capture:
         env.enable_trajectory()
     if agent is not None:
         agent.qnetwork_local.eval()
     for t in range(max_steps):
         a = torch.zeros(n, dtype=torch.int32, device=dev)
+        alive_hist.append(alive.view(len(policies), num).sum(dim=1))
         if iqn_idx.numel():
-            o = obs[iqn_idx]
-            cv = torch.where(adaptive[iqn_idx], agent.adjust_cvar_batch(o), fixed[iqn_idx])   # agent.py:249-267 per row
-            if capture:      # act_eval / act_adaptive_eval (agent.py:217-247): the action AND what it was chosen from
-                a_iqn, quant, taus = agent.act_eval_batch(o.contiguous(), 0.0, cv)
-                a[iqn_idx] = a_iqn
+            o = obs[iqn_idx].contiguous()
+
+            def iqn_act():      # what the reference times (run_experiments.py:35-44): adjust_cvar + act_eval / act
+                cv_ = torch.where(adaptive[iqn_idx], agent.adjust_cvar_batch(o), fixed[iqn_idx])   # agent.py:249-267 per row
+                if capture:      # act_eval / act_adaptive_eval (agent.py:217-247): the action AND what it was chosen from
+                    return (cv_,) + tuple(agent.act_eval_batch(o, 0.0, cv_))
+                return cv_, agent.act_batch(o, 0.0, cv_), None, None
+            cv, a_iqn, quant, taus = timed("IQN", iqn_act)
+            a[iqn_idx] = a_iqn
+            if capture:
                 cap_cv.append(cv.cpu().numpy()); cap_q.append(quant.cpu().numpy()); cap_t.append(taus.cpu().numpy())
-            else:
-                a[iqn_idx] = agent.act_batch(o, 0.0, cv)
         for name, rows in classical.items():                                 # APF.py:17-78 / BA.py:14-72
             if name == "DQN":                                                # run_experiments.py:86 (greedy predict)
-                a[rows] = dqn.act_batch(obs[rows])
+                a[rows] = timed(name, lambda: dqn.act_batch(obs[rows]))
                 continue
             fn = apf_act_batch if name == "APF" else ba_act_batch
-            a[rows] = fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32)
+            a[rows] = timed(name, lambda: fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32))
         obs, reward, done, info = env.step(a)
         if capture:
             cap_traj.append(env.get_trajectory())
@@ -144,6 +161,10 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     length_h = length.cpu().numpy(); info_h = last_info.cpu().numpy(); acts_h = acts.cpu().numpy()
     ret_h = ret.cpu().numpy(); energy_h = energy.cpu().numpy()
     dtN = env.params.dt * env.params.N
+    torch.cuda.synchronize(dev)
+    group_rows = {"IQN": max(1, int(iqn_idx.numel()))}
+    step_s = {g: [e0.elapsed_time(e1) * 1e-3 / group_rows.get(g, num) for e0, e1 in evs] for g, evs in act_events.items()}
+    alive_h = torch.stack(alive_hist).cpu().numpy() if alive_hist else np.zeros((0, len(policies)), dtype=np.int64)
     out = {}
     for p, name in enumerate(policies):
         sl = slice(p * num, (p + 1) * num)
@@ -151,6 +172,9 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
                          time=[float(dtN * l) for l in length_h[sl]], energy=[float(v) for v in energy_h[sl]],
                          reward=[float(v) for v in ret_h[sl]],
                          actions=[[int(x) for x in acts_h[:length_h[i], i]] for i in range(p * num, (p + 1) * num)])
+        ts = step_s.get(name if name in classical else "IQN", [])
+        # one entry per act call of the reference = per live episode and step: the step's amortised per-row device time
+        out[name]["computation_times"] = [float(ts[t_]) for t_ in range(len(ts)) for _ in range(int(alive_h[t_, p]))]
         if capture:
             iqn_pos = {int(g_): k for k, g_ in enumerate(iqn_idx.cpu().numpy())}     # env row -> row of the IQN captures
             eps_ = []

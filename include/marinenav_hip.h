@@ -269,6 +269,12 @@ int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
  *      Only with variant 2, without per-row cvar (cvar_row_dev == NULL) and without a selected image slot: else MN_ERR_INVALID.
  * A row's result for GIVEN taus is the same function in both modes up to float32 rounding (tests). */
 int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
+/* Measurement aid (bench.py: `gpu_clock_probe`): runs a pure stream of the act kernel's matrix instruction (v_mfma_f32_16x16x32_f16, two
+ * waves per SIMD on every CU) for about target_ms milliseconds on `stream` and returns out[0] = elapsed ms (HIP events), out[1] = the clock
+ * in GHz the matrix pipe sustained (16 cycles per instruction), out[2] = the clock by the waves' own counters (s_memtime ticks per
+ * s_memrealtime tick x 100 MHz), out[3] = sustained f16 TFLOP/s of the chip, out[4] = CUs.  Synchronises the stream.  The boxes of a pool
+ * differ in the clock they hold under matrix load; this tells a slow box from a slow kernel. */
+int mn_probe_mfma_clock(double target_ms, double *out, void *stream);
 /* Grid of the act kernel.  0 (default): at most one PERSISTENT workgroup per CU, each looping over its share of the observations --
  * the weight image is staged into LDS once per CU, the fastest form when nothing else runs.  max_workgroups > 0: up to that many
  * workgroups (more than CUs = several rounds of shorter workgroups, e.g. 2048 for 65 536 observations = 4 per wavefront, ~3 % more

@@ -308,6 +308,11 @@ def test_experiment_capture_schema(torch):
     for name in ("adaptive_IQN", "IQN_0.5", "APF"):
         eps = res[name]["ep_data"]
         assert len(eps) == 6
+        # exp_data[name]["computation_times"] (run_experiments.py:226,254-255): one entry per act call of the reference = per step of
+        # every episode; here the amortised device time of the step's batched act launch
+        ct = res[name]["computation_times"]
+        assert len(ct) == sum(len(a_) for a_ in res[name]["actions"]) and all(0.0 < v < 1.0 for v in ct)
+        assert set(res[name]) >= {"ep_data", "success", "time", "energy", "out_of_area", "computation_times"}      # run_experiments.py:226
         for i, ep in enumerate(eps):
             L = len(res[name]["actions"][i])
             assert sorted(ep["env"].keys()) == keys["env"]
