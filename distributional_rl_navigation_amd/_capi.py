@@ -85,6 +85,7 @@ SIGNATURES = [
     ("mn_iqn_set_variant", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_grid", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_tau_mode", C.c_int, [_vp, _i32]),
+    ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
     ("mn_probe_mfma_clock", C.c_int, [C.c_double, _pd, _vp]),
     ("mn_iqn_refresh", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp]),
     ("mn_iqn_pack_slot", C.c_int, [_vp, C.POINTER(C.c_void_p), _i32, _vp]),

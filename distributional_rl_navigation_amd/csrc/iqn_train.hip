@@ -484,8 +484,10 @@ __host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_pa
 __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
 __host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
 __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
-// epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64)
-__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_epoch(n_part) + 8; }
+// epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
+// [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9..11] unused
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_epoch(n_part) + 12; }
+constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
 
@@ -841,6 +843,12 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     const int col = blockIdx.x * RED_COLS + cx;
     PH2(0, 0);
     constexpr int BT = RED_COLS * RED_SEG;
+    // A workspace that mn_iqn_train_workspace_init never saw holds garbage tickets / epoch / tags: the counters would never advance and the
+    // learner would silently repeat one batch.  Fail loudly instead: NaN loss, gradient untouched, Adam refuses too.
+    if (*reinterpret_cast<const uint32_t *>(ws + ws_epoch(n_part) + 8) != WS_MAGIC) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = __builtin_nanf("");
+        return;
+    }
     float lpart = 0.f;      // block 0 sums the loss: its partials are requested now, summed at the end
     if (blockIdx.x == 0)
         for (int wq = threadIdx.x; wq < n_part; wq += BT) lpart += ws[ws_loss(n_part) + wq];
@@ -986,6 +994,7 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     __shared__ float s_bc[2];
     const int p = blockIdx.x * 256 + threadIdx.x;
     PH2(1, 0);
+    if (ticket[6] != WS_MAGIC) return;      // (ticket = epoch block + 2) workspace not initialised: see iqn_grad_reduce
     // this thread's operands first: their latency overlaps the norm
     float gq = 0.f, mp = 0.f, vp = 0.f, pp = 0.f;
     if (p < P_TOTAL) { gq = grad[p] * grad_scale; mp = m[p]; vp = v[p]; pp = params[p]; }
@@ -1072,6 +1081,16 @@ extern "C" int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_sta
 extern "C" int64_t mn_iqn_train_workspace_floats(int32_t batch) {
     if (batch <= 0 || batch % BE) return -1;
     return ws_total(batch / BE);
+}
+
+extern "C" int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream) {
+    if (!workspace || batch <= 0 || batch % BE) return MN_ERR_INVALID;
+    const int n_part = batch / BE;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, (size_t)ws_total(n_part) * sizeof(float), s) != hipSuccess ||
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(workspace + ws_epoch(n_part) + 8), (int)WS_MAGIC, 1, s) != hipSuccess)
+        return MN_ERR_HIP;
+    return MN_OK;
 }
 
 static int launch_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,

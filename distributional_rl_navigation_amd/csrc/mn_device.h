@@ -92,10 +92,12 @@ struct MnBeam {
 // compare + select, and d = 0 stays finite.  Returns the contribution (ux, uy) as two rounded products: the caller
 // adds the cores up in a FIXED balanced tree (mn_step_body.h), which is what makes the result independent of how
 // many lanes share an environment.
-template <typename M>
+// IEEE_DIV: the quotient as an IEEE division instead of MnMath::rcp (float64: v_rcp_f64 + two Newton steps, within an ulp of it) -- the
+// reset kernel's one evaluation per episode (first observation), which is not on the hot path.
+template <typename M, bool IEEE_DIV = false>
 __device__ __forceinline__ void mn_core_velocity(M dx, M dy, M gs, M inv_two_pi_r2, M inv_two_pi, M &ux, M &uy) {
     const M d2 = MnMath<M>::fma_(dx, dx, dy * dy);
-    M f = inv_two_pi * MnMath<M>::rcp(d2);
+    M f = IEEE_DIV ? inv_two_pi / d2 : inv_two_pi * MnMath<M>::rcp(d2);
     f = f < inv_two_pi_r2 ? f : inv_two_pi_r2;
     f *= gs;
     ux = -dy * f;

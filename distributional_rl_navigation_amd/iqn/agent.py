@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from .cadence import cadence_tick
 from .compat import ReferenceLoopMixin
 from .model import ObsEncoder
 from .replay_buffer import ReplayBuffer
@@ -229,8 +230,10 @@ class IQNAgent(ReferenceLoopMixin):
         forward / backward, reduction, RCCL all-reduce of a shared learner, Adam -- is ONE hipGraph launch (iqn/fused_train.py:
         graphed_steps): the host enqueues one node instead of 3-4 launches per step, which is what a shared learner's 16 steps per
         vector step need to stay ahead of the GPU.  Same arithmetic, same generator stream: bit-identical to the eager calls."""
+        # (while the ring is still filling its row count changes with every vector step and each change would be a re-capture +
+        # device synchronisation: the eager steps -- bit-identical -- run until the ring is full)
         if (self.use_fused_graph and self.use_fused_train and self.device.type == "cuda" and n_steps > 1
-                and len(self.memory) >= self.BATCH_SIZE):
+                and len(self.memory) >= self.BATCH_SIZE and len(self.memory) == self.memory.capacity):
             m = self.memory
             ft = self._fused_trainer()
             self._enter_train_path("hip")
@@ -364,6 +367,11 @@ class IQNAgent(ReferenceLoopMixin):
             for tp, lp in zip(target_model.parameters(), local_model.parameters()):
                 tp.data.copy_(self.TAU * lp.data + (1.0 - self.TAU) * tp.data)
 
+    def _sync_target(self):
+        """Target copy + the gradient-step mark the `target_sync_grad_steps` cadence counts from (iqn/cadence.py)."""
+        self.soft_update(self.qnetwork_local, self.qnetwork_target)
+        self._last_sync_at = self.grad_steps
+
     # ---- batched loop on the HIP vector env ----------------------------------------------------------
     def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,
                   eval_log_path=None, total_timesteps=None, world_size=1, cvar=1.0, verbose=True,
@@ -388,7 +396,7 @@ class IQNAgent(ReferenceLoopMixin):
         stats = dict(episodes=0, successes=0, collisions=0, timeouts=0, loss=None)
         for it in range(total_vector_steps):
             eps = self.linear_eps(total_timesteps)
-            prev_learning = self.learning_timestep
+            evaluate_now = eval_env is not None and cadence_tick(self, train_every, eval_freq).evaluate      # (the state vec_step's own tick sees)
             obs, reward, done, info, loss = self.vec_step(train_env, obs, eps, cvar, train_every, per_iter)
             if loss is not None:
                 stats["loss"] = loss
@@ -401,8 +409,7 @@ class IQNAgent(ReferenceLoopMixin):
                 stats["collisions"] += int((info == 3).sum())
                 stats["timeouts"] += int((info == 2).sum())
                 ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
-            if (eval_env is not None and eval_freq and self.learning_timestep != prev_learning
-                    and prev_learning % eval_freq == 0):
+            if evaluate_now:
                 self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
                 self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
                 if eval_log_path is not None:
@@ -431,16 +438,12 @@ class IQNAgent(ReferenceLoopMixin):
                 self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         obs = train_env.reset_done()                                    # first observations where done
         loss = None
+        due = cadence_tick(self, train_every)      # iqn/cadence.py: agent.py:126-147's rule (+ the target cadence in gradient steps)
+        if due.train:
+            loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
+        if due.sync:
+            self._sync_target()
         if self.current_timestep >= self.learning_starts:
-            if self.learning_timestep % train_every == 0 and len(self.memory) > self.BATCH_SIZE:
-                loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
-            if self.target_sync_grad_steps is None:
-                if self.learning_timestep % self.target_update_interval == 0:
-                    self.soft_update(self.qnetwork_local, self.qnetwork_target)
-            elif self.learning_timestep == 0 or self.grad_steps - self._last_sync_at >= self.target_sync_grad_steps:
-                # cadence in GRADIENT steps (the reference: every 10 000 learning steps = 2 500 grad steps, agent.py:136)
-                self.soft_update(self.qnetwork_local, self.qnetwork_target)
-                self._last_sync_at = self.grad_steps
             self.learning_timestep += 1
         self.current_timestep += per_iter
         return obs, reward, done, info, loss

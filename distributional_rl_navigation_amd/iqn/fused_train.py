@@ -55,7 +55,7 @@ class FusedTrainer:
         self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self._ws, self._ws_batch = None, 0
+        self._ws, self._ws_batch, self._ws_by_batch = None, 0, {}
         self._staged_key = None      # (ring, its version, rows, batch, workspace) the workspace holds a staged next batch for
         self._graph, self._graph_key = None, None
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
@@ -110,12 +110,18 @@ class FusedTrainer:
 
     def _workspace(self, batch):
         if self._ws_batch != batch:
-            n = _capi.lib().mn_iqn_train_workspace_floats(batch)
-            if n < 0:
-                raise ValueError("fused IQN gradient step: the batch size must be even")
-            # zero-filled once: the TD-target hand-off tags, their epoch word and the Adam ticket live in it between calls
-            self._ws = torch.zeros(n, dtype=torch.float32, device=self.device)
-            self._ws_batch = batch
+            ws = self._ws_by_batch.get(batch)
+            if ws is None:
+                n = _capi.lib().mn_iqn_train_workspace_floats(batch)
+                if n < 0:
+                    raise ValueError("fused IQN gradient step: the batch size must be even")
+                # one workspace PER batch size, never re-allocated: a captured hipGraph (graphed_steps) holds its raw pointer, and the
+                # TD-target hand-off tags, their epoch word, the tickets and the staged next batch live in it between calls
+                ws = self._ws_by_batch[batch] = torch.empty(n, dtype=torch.float32, device=self.device)
+                rc = _capi.lib().mn_iqn_train_workspace_init(_p(ws), batch, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                if rc:
+                    raise _capi.MarineNavHipError(f"mn_iqn_train_workspace_init failed ({rc})")
+            self._ws, self._ws_batch = ws, batch
         return self._ws
 
     def sample(self, ring_size, batch):
@@ -170,12 +176,13 @@ class FusedTrainer:
         launch (the ring may have been written since the last call), steps 2.. start from the batch their predecessor staged.
         Returns the loss of the last step.  Bit-identical to the eager sequence (tests)."""
         states = ring[0]
-        key = (states.data_ptr(), int(ring_size), batch, int(n_steps), bool(self.agent.distributed))
+        # everything the captured launches hold a raw pointer to is part of the key
+        key = (states.data_ptr(), int(ring_size), batch, int(n_steps), bool(self.agent.distributed), self._workspace(batch).data_ptr(),
+               self.local.data_ptr(), self.target.data_ptr(), self.grad.data_ptr())
         if self._graph_key != key:
             self._graph = None
             torch.cuda.synchronize(self.device)
             # warm-up outside the capture would advance the training state: everything the steps need is allocated here instead
-            self._workspace(batch)
             if batch not in self._idx:
                 self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
                 self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)

@@ -27,6 +27,7 @@ different row order.
 """
 import torch
 
+from .cadence import cadence_tick
 from .fused_act import ActRng, act_context, fused_act
 
 
@@ -107,15 +108,10 @@ class SplitBatchLoop:
                 outs.append((reward, done, info))
         self._appended_once = True
         loss = None
+        due = cadence_tick(ag, train_every)      # iqn/cadence.py: the one statement of the loop's cadence
+        if due.train or due.sync:
+            loss = self._training_event(due.train, due.sync)
         if ag.current_timestep >= ag.learning_starts:
-            train_now = ag.learning_timestep % train_every == 0 and len(ag.memory) > ag.BATCH_SIZE
-            if ag.target_sync_grad_steps is None:
-                sync_now = ag.learning_timestep % ag.target_update_interval == 0
-            else:
-                sync_now = (ag.learning_timestep == 0 or
-                            ag.grad_steps + (ag.grad_steps_per_update if train_now else 0) - ag._last_sync_at >= ag.target_sync_grad_steps)
-            if train_now or sync_now:
-                loss = self._training_event(train_now, sync_now)
             ag.learning_timestep += 1
         ag.current_timestep += per_iter
         return self.obs, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], loss
@@ -133,8 +129,7 @@ class SplitBatchLoop:
                 if train_now:
                     loss = ag.train_steps_from_memory(ag.grad_steps_per_update)
                 if sync_now:
-                    ag.soft_update(ag.qnetwork_local, ag.qnetwork_target)
-                    ag._last_sync_at = ag.grad_steps
+                    ag._sync_target()
                 new = self.cur_slot ^ 1
                 if train_now:
                     self.ctx.pack_slot(ag.qnetwork_local, new)
@@ -153,8 +148,7 @@ class SplitBatchLoop:
         if train_now:
             loss = ag.train_steps_from_memory(ag.grad_steps_per_update)
         if sync_now:
-            ag.soft_update(ag.qnetwork_local, ag.qnetwork_target)
-            ag._last_sync_at = ag.grad_steps
+            ag._sync_target()
         self.ctx.refresh(ag.qnetwork_local)
         self.fork.record(main)
         for s in self.streams:

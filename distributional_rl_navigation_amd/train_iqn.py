@@ -158,9 +158,19 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     return exp_dir
 
 
+def _worker_device(requested, i, n_gpu):
+    """Device of pool worker i: `-D cuda:K` pins every worker to GPU K; `-D cuda` or no -D spreads them, worker i on GPU i modulo the
+    visible GPUs; anything else (`-D cpu`) is passed through."""
+    if requested is None or requested == "cuda":
+        return f"cuda:{i % max(1, n_gpu)}"
+    return requested
+
+
 def _trial_worker(device, params, n_envs, kw):
     import torch
-    torch.cuda.set_device(torch.device(device))
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is not None:      # (an un-indexed or non-CUDA device has no current-device to set)
+        torch.cuda.set_device(dev)
     return run_trial(device, params, n_envs, verbose=False, **kw)
 
 
@@ -207,7 +217,7 @@ def main(argv=None):
         import multiprocessing as mp
         n_gpu = max(1, torch.cuda.device_count())
         with mp.get_context("spawn").Pool(processes=args.num_procs) as pool:
-            jobs = [pool.apply_async(_trial_worker, (args.device or f"cuda:{i % n_gpu}", p, args.n_envs, kw)) for i, p in enumerate(trials)]
+            jobs = [pool.apply_async(_trial_worker, (_worker_device(args.device, i, n_gpu), p, args.n_envs, kw)) for i, p in enumerate(trials)]
             pool.close()
             for j in jobs:
                 j.get()

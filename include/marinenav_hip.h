@@ -344,8 +344,11 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  *                               sensor_encoder.{[176][22],[176]}, cos_embedding.{[208][64],[208]},
  *                               hidden_layer.{[64][208],[64]}, hidden_layer_2.{[64][64],[64]}, output_layer.{[9][64],[9]}
  *   workspace                 : mn_iqn_train_workspace_floats(batch) floats (per-workgroup partial gradients, norm partials, the
- *                               TD-target hand-off granules with their epoch word, the Adam ticket).  ZERO-FILL it once before the
- *                               first call and then pass the same buffer and batch, untouched, to every call of one learner
+ *                               TD-target hand-off granules with their epoch word, the Adam ticket).  Call
+ *                               mn_iqn_train_workspace_init(workspace, batch, stream) ONCE before the first step and then pass the same
+ *                               buffer and batch, untouched, to every call of one learner: the workspace carries state between calls
+ *                               (hand-off epoch, tickets, the staged next batch).  A workspace that was never initialised is refused
+ *                               on the device: the step returns a NaN loss and leaves gradient, moments and parameters untouched
  *   grad_out [35 785]         : d loss / d params_local (un-clipped); loss_out [1]: the loss
  * mn_iqn_train_grad computes loss and gradient (2 kernels, deterministic: no float atomics).  The forward / backward launch has
  * two workgroup roles -- batch / 2 TARGET workgroups (lower block indices) run the target network and hand their 16 TD targets
@@ -359,6 +362,7 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * norm is recomputed from grad.
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
+int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
  * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).  Slot k reads
  * row perm(k) of a keyed pseudo-random permutation of [0, ring_size) (4-round Feistel network + cycle walking): distinct by

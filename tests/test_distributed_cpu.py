@@ -85,3 +85,12 @@ def test_shard_seeds_tile_the_single_gpu_run():
         shard_seeds(0)
     with pytest.raises(ValueError):
         shard_seeds(4, first_index=-1)
+
+
+def test_pool_worker_device_selection():
+    """train_iqn -P: `-D cuda:K` pins every worker, `-D cuda` / no -D spreads worker i to GPU i modulo the visible GPUs, `-D cpu` passes
+    through (set_device was called unconditionally and every worker landed on one device)."""
+    from distributional_rl_navigation_amd.train_iqn import _worker_device
+    assert [_worker_device(None, i, 4) for i in range(6)] == ["cuda:0", "cuda:1", "cuda:2", "cuda:3", "cuda:0", "cuda:1"]
+    assert [_worker_device("cuda", i, 2) for i in range(3)] == ["cuda:0", "cuda:1", "cuda:0"]
+    assert _worker_device("cuda:3", 5, 8) == "cuda:3" and _worker_device("cpu", 1, 0) == "cpu" and _worker_device(None, 2, 0) == "cuda:0"

@@ -292,8 +292,8 @@ def test_iqn_c_abi_argument_checks(torch):
     from distributional_rl_navigation_amd import _capi
     L = _capi.lib()
     # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
-    # staging tag + the staged next batch (256 slots of 72 floats)
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 8 + 256 * 72
+    # staging tag / magic word + the staged next batch (256 slots of 72 floats)
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 256 * 72
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -316,6 +316,20 @@ def test_iqn_c_abi_argument_checks(torch):
     assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), None, p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, C.c_float(1.0), 0, None) == INVALID
     assert L.mn_iqn_train_adam(p(f), p(f), p(f), p(f), p(st), p(ws), 2, 1e-4, 0.9, 0.999, 1e-8, 0.5, C.c_float(0.0), 0, None) == INVALID   # grad_scale must be positive
     assert L.mn_iqn_train_set_mode(2) == INVALID and L.mn_iqn_train_set_mode(0) == 0
+    assert L.mn_iqn_train_workspace_init(None, 2, None) == INVALID and L.mn_iqn_train_workspace_init(p(ws), 3, None) == INVALID
+    # a workspace that was never initialised is refused on the device: NaN loss, parameters and moments untouched
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    ag = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=256, device=dev, seed=3)
+    ag.memory.add_batch(*_random_batch(torch, 200, torch.Generator(device=dev).manual_seed(4)))
+    ft = ag._fused_trainer()
+    assert np.isfinite(float(ag.train_from_memory()))
+    garbage = torch.full_like(ft._ws, 3.0e9)
+    ft._ws_by_batch[32] = ft._ws = garbage
+    before, m_before, step_before = ft.local.clone(), ft.exp_avg.clone(), int(ft.step_dev)
+    assert np.isnan(float(ag.train_from_memory()))
+    assert torch.equal(ft.local, before) and torch.equal(ft.exp_avg, m_before) and int(ft.step_dev) == step_before
+    assert L.mn_iqn_train_workspace_init(p(garbage), 32, None) == 0
+    assert np.isfinite(float(ag.train_from_memory())) and not torch.equal(ft.local, before)
     assert L.mn_iqn_act(None, p(ring[0]), p(taus), None, None, None, C.c_float(0.0), p(idx), None, 4, 32, None) == INVALID
 
 

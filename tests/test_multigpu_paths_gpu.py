@@ -200,13 +200,13 @@ def test_graphed_fused_steps_equal_eager_steps_bitwise_plain_and_under_nccl(torc
         try:
             runs = []
             for graphed in (False, True):
-                ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=512, device=dev, seed=5, distributed=distributed)
+                ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
                 ag.use_fused_graph = graphed
-                ag.memory.add_batch(*_batch(torch, 7, 300, dev))
+                ag.memory.add_batch(*_batch(torch, 7, 300, dev))      # the ring is full (graphs are used from then on: its row count is constant)
                 losses = []
                 for ev in range(3):
                     if ev == 2:
-                        ag.memory.add_batch(*_batch(torch, 8, 100, dev))      # ring written (and grown): the graph is re-captured
+                        ag.memory.add_batch(*_batch(torch, 8, 100, dev))      # ring written between two replays of the SAME graph
                     losses.append(float(ag.train_steps_from_memory(8)))
                 ft = ag._fused
                 runs.append((losses, ft.local.clone(), ft.exp_avg_sq.clone(), ft.rng_state.clone(), int(ft.step_dev), ag.grad_steps))
