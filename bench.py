@@ -300,6 +300,36 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
         agent.distributed = True
         sl["nccl_ws1_allreduce"] = learner_rate()
         sl["allreduce_overhead_us_per_step"] = 1e6 * (1.0 / sl["nccl_ws1_allreduce"] - 1.0 / sl["no_group"])
+        # the same gradient steps as ONE captured hipGraph per 16-step training event, RCCL all-reduce captured too (--graph-train):
+        # does capture hide any of the collective's cost?
+        def graphed_rate(events=25, G=16):
+            was_g = agent.use_fused_graph
+            agent.use_fused_graph = True
+            try:
+                for _ in range(3):
+                    agent.train_steps_from_memory(G)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(events):
+                    agent.train_steps_from_memory(G)
+                torch.cuda.synchronize(device)
+                return events * G / (time.perf_counter() - t0)
+            finally:
+                agent.use_fused_graph = was_g
+        sl["nccl_ws1_allreduce_graphed_16_step_events"] = graphed_rate()
+        agent.distributed = False
+        sl["no_group_graphed_16_step_events"] = graphed_rate()
+        agent.distributed = True
+        sl["allreduce_overhead_us_per_step_graphed"] = 1e6 * (1.0 / sl["nccl_ws1_allreduce_graphed_16_step_events"] - 1.0 / sl["no_group_graphed_16_step_events"])
+        # the one-shot exchange over IPC-mapped mailboxes instead of the RCCL all-reduce (iqn/mailbox.py; one rank: its own mailbox only)
+        agent.exchange = "mailbox"
+        try:
+            sl["mailbox_ws1_exchange"] = learner_rate()
+            sl["mailbox_overhead_us_per_step"] = 1e6 * (1.0 / sl["mailbox_ws1_exchange"] - 1.0 / sl["no_group"])
+            sl["mailbox_ws1_exchange_graphed_16_step_events"] = graphed_rate()
+            sl["mailbox_timeouts"] = agent._fused._mailbox.timeouts()
+        finally:
+            agent.exchange = "collective"
     except Exception as e:      # the line must still come out if RCCL cannot initialise on this box
         sl["nccl_ws1_error"] = repr(e)
     finally:

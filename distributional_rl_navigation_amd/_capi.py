@@ -86,6 +86,13 @@ SIGNATURES = [
     ("mn_iqn_set_grid", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_tau_mode", C.c_int, [_vp, _i32]),
     ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
+    ("mn_xchg_create", C.c_int, [_i32, _i32, C.POINTER(_vp)]),
+    ("mn_xchg_export", C.c_int, [_vp, _vp]),
+    ("mn_xchg_import", C.c_int, [_vp, _i32, _vp]),
+    ("mn_xchg_attach", C.c_int, [_vp, _vp, _i32, _vp]),
+    ("mn_iqn_train_exchange", C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp]),
+    ("mn_xchg_status", C.c_int, [_vp, _pi32]),
+    ("mn_xchg_destroy", C.c_int, [_vp]),
     ("mn_probe_mfma_clock", C.c_int, [C.c_double, _pd, _vp]),
     ("mn_iqn_refresh", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp]),
     ("mn_iqn_pack_slot", C.c_int, [_vp, C.POINTER(C.c_void_p), _i32, _vp]),

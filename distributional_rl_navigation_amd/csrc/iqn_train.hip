@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <mutex>
 
@@ -485,13 +486,18 @@ __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part)
 __host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
 __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
-// [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9..11] unused
+// [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] unused,
+// [10..11] device pointer (u64) of this rank's gradient mailbox, 0 = none (mn_xchg_attach: the reduction kernel publishes into it)
 __host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_epoch(n_part) + 12; }
 constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
 
 constexpr int MODE_TWO_ROLES = 0, MODE_LOCAL_ONLY = 1;
+
+// tag of the gradient a step publishes: never 0 (mailboxes start zero-filled), consecutive steps differ, equal on every rank of a shared
+// learner (all ranks have completed the same number of steps)
+__host__ __device__ __forceinline__ uint32_t xchg_tag(uint64_t epoch_after_step) { return (uint32_t)(epoch_after_step % 0xFFFFFFFFull) + 1u; }
 
 
 // the caller's copies of a batch drawn in the launch (inspection, tests): by workgroup 0, after its real work
@@ -907,6 +913,17 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
                     if (p + k < P_TOTAL) grad[p + k] = e[k];
             }
             ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
+            // one-shot exchange of a shared learner (mn_xchg_*): the reduced gradient also goes to this rank's mailbox as self-tagged
+            // 8-byte granules {step tag, value}, system scope -- the peers' gather kernels poll them, the data is the flag
+            const uint64_t mb = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 10);
+            if (mb) {
+                const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);     // the epoch this step ends with
+                gu64 *dst = reinterpret_cast<gu64 *>(mb) + (size_t)(tag & 1u) * P_PAD + p;
+                const float e[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_store(dst + k, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(e[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         sq[cx] = ss;
     }
@@ -975,6 +992,60 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restri
     } else {
         for (int k = 0; k < 4; ++k)
             if (q + k < P_TOTAL) e[k] = grad[q + k];
+    }
+    for (int k = 0; k < 4; ++k) e[k] *= grad_scale;
+    sq[threadIdx.x] = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < RED_COLS; ++k) t += sq[k];
+        blocksq[blockIdx.x] = t;
+    }
+}
+
+// One-shot gradient exchange of a shared learner (one 143 KB bucket, latency-bound): every rank's reduction kernel has
+// published its reduced gradient into its own mailbox (above); this kernel reads the mailboxes of ALL ranks -- its own and, through
+// IPC-mapped pointers, the peers' -- and forms grad = sum over ranks IN RANK ORDER (same bits on every rank; for two ranks the same sum
+// an all-reduce gives), plus iqn_grad_sumsq's per-block sums of squares of grad_scale * grad in the same shape and order, so that
+// mn_iqn_train_adam needs no second pass.  No collective launch, no barrier: a granule carries its step tag, a reader polls until the tag
+// is the current step's (bounded: ~2 s of the 100 MHz counter, then the status word is raised and the step continues with what is there --
+// a wait can never hang the device).  Two slots alternate with the step parity: a rank publishes step k + 2 into slot k & 1 only after its
+// gather of step k + 1, which needed every peer's step k + 1, which every peer published after ITS gather of step k.
+constexpr int XCHG_MAX_RANKS = 8;
+struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS]; };
+__global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int world, const float *__restrict__ ws, int n_part,
+                                                            float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale,
+                                                            unsigned *__restrict__ status) {
+    __shared__ float sq[RED_COLS];
+    const int q = (blockIdx.x * RED_COLS + threadIdx.x) * 4;
+    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)));      // (the reduction kernel advanced the epoch)
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q < P_PAD) {
+        bool late = false;
+        for (int r = 0; r < world; ++r) {
+            const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
+            uint64_t x[4];
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = ok && (uint32_t)(x[k] >> 32) == tag;
+                }
+                if (ok) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
+        }
+        if (late) atomicAdd(status, 1u);
+        if (q + 3 < P_TOTAL) *reinterpret_cast<float4 *>(grad + q) = make_float4(e[0], e[1], e[2], e[3]);
+        else
+            for (int k = 0; k < 4; ++k)
+                if (q + k < P_TOTAL) grad[q + k] = e[k];
+                else e[k] = 0.f;
     }
     for (int k = 0; k < 4; ++k) e[k] *= grad_scale;
     sq[threadIdx.x] = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3];
@@ -1163,9 +1234,97 @@ extern "C" int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, flo
     const float *blocksq = workspace + ws_sq(batch / BE);
     unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(batch / BE) + 2);
     float *blocksq_w = workspace + ws_sq(batch / BE);
-    if (grad_rewritten || grad_scale != 1.0f)      // the reduction kernel's partial sums of squares no longer describe grad
+    if ((grad_rewritten || grad_scale != 1.0f) && grad_rewritten != 2)      // the reduction kernel's partial sums of squares no longer describe grad (2: mn_iqn_train_exchange already wrote them for grad_scale * grad)
         hipLaunchKernelGGL(iqn_grad_sumsq, dim3(N_RED), dim3(RED_COLS), 0, s, grad, blocksq_w, grad_scale);
     hipLaunchKernelGGL(iqn_adam, dim3(N_ADAM), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, blocksq, step_dev, ticket, lr, beta1,
                        beta2, eps, max_norm, grad_scale);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+// ---- one-shot gradient exchange of a shared learner over IPC-mapped mailboxes (see iqn_grad_gather) ---------------------------------
+struct mn_xchg {
+    int rank = 0, world = 1, device = -1;
+    gu64 *own = nullptr;                       // [2][P_PAD] granules, this rank's reduced gradient of the last two steps
+    const gu64 *peer[XCHG_MAX_RANKS] = {};     // own + IPC-mapped peers, by rank
+    bool opened[XCHG_MAX_RANKS] = {};
+    unsigned *status = nullptr;                // device word: number of granule groups that timed out
+};
+
+extern "C" int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out) {
+    if (!out || world < 1 || world > XCHG_MAX_RANKS || rank < 0 || rank >= world) return MN_ERR_INVALID;
+    mn_xchg *x = new mn_xchg();
+    x->rank = rank; x->world = world;
+    const size_t bytes = 2 * (size_t)P_PAD * sizeof(uint64_t);
+    void *p = nullptr;
+    // plain device memory: granules are written and polled with system-scope (cache-bypassing) accesses, and hipIpcGetMemHandle exports it
+    if (hipGetDevice(&x->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&x->status), sizeof(unsigned)) != hipSuccess || hipMemset(x->status, 0, sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p); (void)hipFree(x->status); delete x;
+        return MN_ERR_ALLOC;
+    }
+    x->own = (gu64 *)p;
+    x->peer[rank] = x->own;
+    *out = x;
+    return MN_OK;
+}
+
+extern "C" int mn_xchg_export(mn_xchg *x, void *handle_out) {
+    if (!x || !handle_out) return MN_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "mn_xchg_export / _import exchange 64-byte handles");
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, (void *)x->own) != hipSuccess) return MN_ERR_HIP;
+    memcpy(handle_out, &h, sizeof(h));
+    return MN_OK;
+}
+
+extern "C" int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle) {
+    if (!x || !handle || peer_rank < 0 || peer_rank >= x->world || peer_rank == x->rank || x->opened[peer_rank]) return MN_ERR_INVALID;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MN_ERR_HIP;
+    x->peer[peer_rank] = (const gu64 *)p;
+    x->opened[peer_rank] = true;
+    return MN_OK;
+}
+
+extern "C" int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void *stream) {
+    if (!workspace || batch <= 0 || batch % BE) return MN_ERR_INVALID;
+    const uint64_t v = x ? (uint64_t)(uintptr_t)x->own : 0ull;      // x == NULL detaches
+    if (hipMemcpyAsync(workspace + ws_epoch(batch / BE) + 10, &v, sizeof(v), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        return MN_ERR_HIP;
+    return MN_OK;
+}
+
+extern "C" int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t batch, float grad_scale, void *stream) {
+    if (!x || !grad || !workspace || batch <= 0 || batch % BE || !(grad_scale > 0.f)) return MN_ERR_INVALID;
+    XchgPeers peers;
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
+        peers.mb[r] = r < x->world ? x->peer[r] : nullptr;
+        if (r < x->world && !peers.mb[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
+    }
+    const int n_part = batch / BE;
+    hipLaunchKernelGGL(iqn_grad_gather, dim3(N_RED), dim3(RED_COLS), 0, (hipStream_t)stream, peers, x->world, (const float *)workspace, n_part,
+                       grad, workspace + ws_sq(n_part), grad_scale, x->status);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+extern "C" int mn_xchg_status(mn_xchg *x, int32_t *timeouts) {
+    if (!x || !timeouts) return MN_ERR_INVALID;
+    unsigned v = 0;
+    if (hipMemcpy(&v, x->status, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return MN_ERR_HIP;
+    *timeouts = (int32_t)v;
+    return MN_OK;
+}
+
+extern "C" int mn_xchg_destroy(mn_xchg *x) {
+    if (!x) return MN_ERR_INVALID;
+    for (int r = 0; r < x->world; ++r)
+        if (x->opened[r]) (void)hipIpcCloseMemHandle((void *)x->peer[r]);
+    (void)hipFree((void *)x->own);
+    (void)hipFree(x->status);
+    delete x;
+    return MN_OK;
 }

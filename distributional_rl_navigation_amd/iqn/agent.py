@@ -76,6 +76,8 @@ class IQNAgent(ReferenceLoopMixin):
         self.learning_timestep = 0
         self.grad_steps = 0
         self.distributed = bool(distributed)
+        self.exchange = "collective"                 # shared learner: "collective" = RCCL all-reduce of the flat gradient (default); "mailbox" =
+                                                     # one-shot exchange over IPC-mapped mailboxes (iqn/mailbox.py; opt-in)
         self._flat = None
 
         self.eval_timesteps = dict(greedy=[], adaptive=[])

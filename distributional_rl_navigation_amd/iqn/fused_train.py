@@ -56,6 +56,7 @@ class FusedTrainer:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws, self._ws_batch, self._ws_by_batch = None, 0, {}
+        self._mailbox = None         # iqn/mailbox.py: MailboxExchange of a shared learner with agent.exchange == "mailbox"
         self._staged_key = None      # (ring, its version, rows, batch, workspace) the workspace holds a staged next batch for
         self._graph, self._graph_key = None, None
         # {seed, call counter} of the sampling kernel (same seed family as the replay memory's generator)
@@ -122,6 +123,13 @@ class FusedTrainer:
                 if rc:
                     raise _capi.MarineNavHipError(f"mn_iqn_train_workspace_init failed ({rc})")
             self._ws, self._ws_batch = ws, batch
+        if self.agent.distributed and getattr(self.agent, "exchange", "collective") == "mailbox":
+            if self._mailbox is None:
+                from .mailbox import MailboxExchange
+                self._mailbox = MailboxExchange(self.device)
+            self._mailbox.attach(self._ws, batch)      # (no-op once attached) the reduction kernel publishes the gradient itself
+        elif self._mailbox is not None:
+            self._mailbox.detach(self._ws, batch)      # back on the collective / single-learner path: stop publishing
         return self._ws
 
     def sample(self, ring_size, batch):
@@ -235,7 +243,16 @@ class FusedTrainer:
         L = _capi.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         scale, rewritten = 1.0, 0
-        if ag.distributed:
+        if ag.distributed and getattr(ag, "exchange", "collective") == "mailbox":
+            # one-shot exchange (iqn/mailbox.py): the reduction kernel published this rank's gradient already; one gather kernel sums the
+            # ranks' mailboxes in rank order and leaves the norm partials -- no collective launch, no separate norm pass
+            mb = self._mailbox
+            if mb is None:
+                from .mailbox import MailboxExchange
+                mb = self._mailbox = MailboxExchange(self.device)
+            scale, rewritten = 1.0 / mb.world, 2
+            mb.exchange(self.grad, self._workspace(B), B, scale)
+        elif ag.distributed:
             import torch.distributed as dist
             if dist.get_backend() == "gloo":
                 # debugging / single-GPU multi-process tests only: gloo reduces on the host

@@ -358,11 +358,38 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * which applies clip_grad_norm_(max_norm) (agent.py:299) to grad_scale * grad and one torch.optim.Adam update (agent.py:300;
  * exp_avg / exp_avg_sq [35 785], step_dev: i32 step counter on the device, incremented by the call; grad is overwritten with the
  * clipped gradient).  grad_rewritten = 0 promises that grad_out is exactly what the preceding mn_iqn_train_grad* call on the same
- * workspace left there (the norm then comes from partial sums that call stored); with grad_rewritten != 0 or grad_scale != 1 the
+ * workspace left there (the norm then comes from partial sums that call stored); grad_rewritten = 2 that mn_iqn_train_exchange formed
+ * them for grad_scale * grad; with grad_rewritten = 1 or (grad_rewritten = 0 and grad_scale != 1) the
  * norm is recomputed from grad.
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
 int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
+
+/* ---- One-shot gradient exchange of a shared learner (BASELINE configs[4]; SURVEY 8e: one flat 143 KB bucket per gradient step, latency-
+ * bound).  Alternative to an RCCL all-reduce between mn_iqn_train_grad* and mn_iqn_train_adam: every rank owns a MAILBOX in device memory;
+ * once a workspace is attached, the gradient step's reduction kernel also publishes the reduced gradient there as self-tagged 8-byte
+ * granules {step tag, value} (system-scope stores); mn_iqn_train_exchange launches ONE kernel that reads all ranks' mailboxes -- the peers'
+ * through IPC-mapped pointers, i.e. directly over xGMI -- polling each granule until it carries the current step's tag, and leaves
+ *     grad = sum over ranks, in rank order (bit-identical on every rank; equal to an all-reduce(SUM) for two ranks)
+ * plus the norm partials of grad_scale * grad, so that the step continues with mn_iqn_train_adam(..., grad_scale, grad_rewritten = 2).
+ * Four launches per step instead of five (no collective launch, no separate norm pass), no host synchronisation, graph-capturable.
+ *   mn_xchg_create(rank, world <= 8)    this rank's context + mailbox on the current device
+ *   mn_xchg_export(x, handle[64])       hipIpcMemHandle_t of the mailbox, to be sent to every peer (e.g. torch.distributed.all_gather_object)
+ *   mn_xchg_import(x, peer, handle[64]) maps a peer's mailbox (once per peer)
+ *   mn_xchg_attach(x, workspace, batch) the learner that steps on `workspace` publishes into x's mailbox from now on (x = NULL detaches)
+ *   mn_iqn_train_exchange(x, grad, workspace, batch, grad_scale, stream)   after mn_iqn_train_grad* on the same stream
+ *   mn_xchg_status(x, &timeouts)        granule groups that did not arrive within ~2 s (0 in a healthy run; the poll is bounded so that a
+ *                                       missing peer can never hang the device)
+ * All ranks must call the step functions the same number of times (the tag is the workspace's step count).  RCCL stays the default
+ * transport of iqn/fused_train.py; this path is opt-in (IQNAgent.exchange = "mailbox"). */
+typedef struct mn_xchg mn_xchg;
+int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out);
+int mn_xchg_export(mn_xchg *x, void *handle_out);
+int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle);
+int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void *stream);
+int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t batch, float grad_scale, void *stream);
+int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
+int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
  * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).  Slot k reads
  * row perm(k) of a keyed pseudo-random permutation of [0, ring_size) (4-round Feistel network + cycle walking): distinct by

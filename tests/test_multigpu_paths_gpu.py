@@ -81,18 +81,22 @@ sys.path.insert(0, sys.argv[4]); sys.path.insert(0, os.path.join(sys.argv[4], "t
 from test_multigpu_paths_gpu import _batch, _taus
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 rank, port, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+exchange = sys.argv[5] if len(sys.argv) > 5 else "collective"
+n_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
 dev = "cuda:0"
 agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, device=dev, seed=3, distributed=True, rank=rank)
+agent.exchange = exchange      # "collective": the bucket travels over gloo; "mailbox": IPC-mapped mailboxes, gloo only carries the handles
 assert agent.use_fused_train
-for step in range(3):
+for step in range(n_steps):
     tt, tl = _taus(torch, 10 * step + rank, 32, dev)
     agent.train(_batch(torch, 10 * step + rank, 32, dev), taus_target=tt, taus_local=tl)
 flat = agent._fused.local.cpu()
 gathered = [torch.empty_like(flat) for _ in range(2)]
 dist.all_gather(gathered, flat)
+timeouts = agent._fused._mailbox.timeouts() if exchange == "mailbox" else 0
 if rank == 0:
-    torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1]))), out)
+    torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1])), timeouts=timeouts), out)
 dist.destroy_process_group()
 """
 
@@ -120,6 +124,51 @@ def test_fused_step_two_ranks_equals_big_batch(torch, tmp_path):
         (t0, l0), (t1, l1) = _taus(torch, 10 * step, 32, dev), _taus(torch, 10 * step + 1, 32, dev)
         ref.train(tuple(torch.cat([a, b]) for a, b in zip(b0, b1)), taus_target=torch.cat([t0, t1]), taus_local=torch.cat([l0, l1]))
     np.testing.assert_allclose(res["params"].numpy(), ref._fused.local.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def _two_rank_run(torch, tmp_path, tag, exchange, n_steps):
+    out = str(tmp_path / f"{tag}.pt"); port = str(_free_port())
+    script = str(tmp_path / "worker.py")
+    with open(script, "w") as f:
+        f.write(_TWO_RANK_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, script, str(r), port, out, ROOT, exchange, str(n_steps)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return torch.load(out)
+
+
+def test_mailbox_exchange_two_ranks_equals_the_all_reduce_path_bitwise(torch, tmp_path):
+    """The one-shot gradient exchange (`mn_xchg_*`, iqn/mailbox.py): two ranks (two processes on this GPU) publish their reduced
+    gradients into IPC-exported mailboxes from inside the reduction kernel and each sums both mailboxes in rank order with one gather
+    kernel -- no collective.  Same batches through the all-reduce path (bucket over gloo): parameters bit-identical after 12 steps,
+    ranks bit-identical to each other, no granule timed out."""
+    a = _two_rank_run(torch, tmp_path, "collective", "collective", 12)
+    b = _two_rank_run(torch, tmp_path, "mailbox", "mailbox", 12)
+    assert a["same"] and b["same"] and b["timeouts"] == 0
+    assert torch.equal(a["params"], b["params"])
+
+
+def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graphed(torch):
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        runs = []
+        for distributed, graphed in ((False, False), (True, False), (True, True)):
+            ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
+            ag.exchange = "mailbox"
+            ag.use_fused_graph = graphed
+            ag.memory.add_batch(*_batch(torch, 7, 300, dev))
+            losses = [float(ag.train_steps_from_memory(8)) for _ in range(3)]
+            runs.append((losses, ag._fused.local.clone(), ag._fused.exp_avg_sq.clone(), int(ag._fused.step_dev)))
+            if distributed:
+                assert ag._fused._mailbox.timeouts() == 0
+        for r in runs[1:]:
+            assert r[0] == runs[0][0] and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and r[3] == runs[0][3] == 24
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("precision", ["f64", "mixed"])
