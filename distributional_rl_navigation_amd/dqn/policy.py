@@ -75,14 +75,55 @@ class DQNPolicy(nn.Module):
         pol.load_state_dict(sd, strict=True)
         return pol
 
+    use_fused_act = True      # GPU tensors: the whole network + argmax as ONE HIP launch (csrc/dqn_act.hip); False = eager PyTorch
+
+    def _fused(self, obs, want_q, want_a):
+        """C-ABI mn_dqn_act on a contiguous float32 device batch; the permuted weight image is rebuilt when a parameter was written
+        (PyTorch version counters) or re-allocated."""
+        import ctypes as C
+        from .. import _capi
+        L = _capi.lib()
+        ex, qn = self.q_net.features_extractor, self.q_net.q_net
+        mods = (ex.velocity_encoder, ex.goal_encoder, ex.sensor_encoder, ex.hidden_layer, ex.hidden_layer_2, ex.output_layer, qn[0], qn[2], qn[4])
+        ps = [t for m in mods for t in (m.weight, m.bias)]
+        sig = tuple((t.data_ptr(), t._version) for t in ps)
+        st = getattr(self, "_fused_state", None)
+        if st is None or st["image"].device != obs.device:
+            st = dict(image=torch.empty(L.mn_dqn_image_floats(), dtype=torch.float32, device=obs.device), sig=None, ptrs=(C.c_void_p * 18)())
+            object.__setattr__(self, "_fused_state", st)
+        repack = sig != st["sig"]
+        if repack:
+            for i, t in enumerate(ps):
+                assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+                st["ptrs"][i] = t.data_ptr()
+            st["sig"] = sig
+        n = obs.shape[0]
+        q = torch.empty(n, self.action_size, dtype=torch.float32, device=obs.device) if want_q else None
+        a = torch.empty(n, dtype=torch.int32, device=obs.device) if want_a else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        rc = L.mn_dqn_act(p(obs), st["ptrs"], p(st["image"]), int(repack), p(q), p(a), n, C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_dqn_act failed ({rc})")
+        return q, a
+
+    def _fusable(self, obs):
+        return (self.use_fused_act and obs.is_cuda and not torch.is_grad_enabled() and len(self.q_net.q_net) == 5
+                and self.q_net.q_net[0].out_features == 64 and self.q_net.q_net[2].out_features == 64 and obs.shape[0] > 0)
+
     @torch.no_grad()
     def q_values(self, obs):
-        return self.q_net(obs.to(self.device, torch.float32).view(-1, self.state_size))
+        obs = obs.to(self.device, torch.float32).view(-1, self.state_size)
+        if self._fusable(obs):
+            return self._fused(obs.contiguous(), True, False)[0]
+        return self.q_net(obs)
 
     @torch.no_grad()
     def act_batch(self, obs):
         """QNetwork._predict (dqn/policies.py:69-73): argmax_a Q(obs, a), one int32 per row."""
-        return self.q_values(obs).argmax(dim=1).to(torch.int32)
+        obs = obs.to(self.device, torch.float32).view(-1, self.state_size)
+        if self._fusable(obs):
+            return self._fused(obs.contiguous(), False, True)[1]
+        return self.q_net(obs).argmax(dim=1).to(torch.int32)
 
     exploration_rate = 0.05      # sb3 DQN's value after its exploration schedule (exploration_final_eps, dqn/dqn.py:82)
 

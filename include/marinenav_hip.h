@@ -382,6 +382,18 @@ int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
  *                                       missing peer can never hang the device)
  * All ranks must call the step functions the same number of times (the tag is the workspace's step count).  RCCL stays the default
  * transport of iqn/fused_train.py; this path is opt-in (IQNAgent.exchange = "mailbox"). */
+/* ---- DQN baseline, acting: the greedy policy of the reference's sb3 `ObsEncoderPolicy` for n observation rows in ONE
+ * launch -- encoders (no activation) -> hidden_layer -> hidden_layer_2 -> output_layer (thirdparty/stable_baselines3/common/
+ * torch_layers.py:96-135) -> q_net.0 -> q_net.2 -> q_net.4 (dqn/policies.py:48-58, net_arch [64, 64]) -> argmax (:69-73), exact float32 MFMA.
+ *   weights[18]   device pointers, nn.Linear layout: {velocity, goal, sensor}_encoder, hidden_layer, hidden_layer_2, output_layer,
+ *                 q_net.0, q_net.2, q_net.4, each as (weight, bias)
+ *   image_dev     caller-owned scratch of mn_dqn_image_floats() floats: the permuted weight image; repack != 0 rebuilds it from
+ *                 `weights` in front of the launch (first call, and after the weights changed)
+ *   qvals_dev     [n][9] Q-values or NULL; actions_dev [n] greedy actions (first maximum) or NULL */
+int64_t mn_dqn_image_floats(void);
+int mn_dqn_act(const float *obs_dev, const float *const *weights, float *image_dev, int32_t repack, float *qvals_dev, int32_t *actions_dev,
+               int32_t n, void *stream);
+
 typedef struct mn_xchg mn_xchg;
 int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out);
 int mn_xchg_export(mn_xchg *x, void *handle_out);
