@@ -86,6 +86,8 @@ SIGNATURES = [
     ("mn_iqn_set_grid", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_tau_mode", C.c_int, [_vp, _i32]),
     ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
+    ("mn_rollout_policy", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mn_planner_act", C.c_int, [_vp, _i32, _i32, _pd, _pd, _vp, _vp]),
     ("mn_dqn_image_floats", C.c_int64, []),
     ("mn_dqn_act", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp, _i32, _vp, _vp, _i32, _vp]),
     ("mn_xchg_create", C.c_int, [_i32, _i32, C.POINTER(_vp)]),

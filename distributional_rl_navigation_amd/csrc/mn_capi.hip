@@ -338,6 +338,28 @@ extern "C" int mn_rollout(mn_handle *h, int32_t n_steps, const int32_t *actions_
     return MN_OK;
 }
 
+extern "C" int mn_rollout_policy(mn_handle *h, int32_t n_steps, int32_t policy, float *obs_dev, float *obs_trace_dev, float *reward_trace_dev,
+                                 uint8_t *done_trace_dev, uint8_t *info_trace_dev, int32_t *action_trace_dev, void *stream) {
+    if (!h || !obs_dev || n_steps < 1 || (policy != MN_POLICY_APF && policy != MN_POLICY_BA)) return MN_ERR_INVALID;
+    MN_ON_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    const bool prof = h->prof_n < h->prof_max;
+    if (prof) (void)hipEventRecord(h->ev[2 * h->prof_n], s);
+    mn_launch_rollout_policy(h->A, h->P, h->params.precision, n_steps, policy, obs_dev, obs_trace_dev, reward_trace_dev, done_trace_dev,
+                             info_trace_dev, action_trace_dev, s);
+    if (prof) { (void)hipEventRecord(h->ev[2 * h->prof_n + 1], s); h->prof_n++; }
+    MN_HIP(h, hipGetLastError());
+    h->step_parity = 0;
+    h->last_parity = 0;
+    return MN_OK;
+}
+
+extern "C" int mn_planner_act(const float *obs_dev, int32_t n, int32_t policy, const double *a, const double *w, int32_t *actions_dev, void *stream) {
+    if (!obs_dev || !actions_dev || !a || !w || n <= 0 || (policy != MN_POLICY_APF && policy != MN_POLICY_BA)) return MN_ERR_INVALID;
+    mn_launch_planner_act(obs_dev, n, policy, a, w, actions_dev, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
 extern "C" int mn_random_actions(uint64_t action_seed, uint64_t step_index, uint64_t first_env_index, int32_t n,
                                  int32_t *actions_dev, void *stream) {
     if (!actions_dev || n <= 0) return MN_ERR_INVALID;

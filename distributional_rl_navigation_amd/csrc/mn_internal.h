@@ -94,6 +94,10 @@ void mn_launch_rollout(const MnArrays &A, const MnDev &P, int precision, int lan
                        uint64_t seed, uint64_t step0, uint64_t env0, float *obs_out, float *obs_trace, float *reward_trace,
                        uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s);
 void mn_launch_random_actions(uint64_t seed, uint64_t step, uint64_t env0, int n, int32_t *out, hipStream_t s);
+// episodes under a device-side policy (MN_POLICY_APF / MN_POLICY_BA, mn_planners.h), and one policy step for a vector of observations
+void mn_launch_rollout_policy(const MnArrays &A, const MnDev &P, int precision, int n_steps, int policy, float *obs_io, float *obs_trace,
+                              float *reward_trace, uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s);
+void mn_launch_planner_act(const float *obs, int n, int policy, const double *a, const double *w, int32_t *actions, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
                      const int32_t *list_dev, int mode, float *obs, hipStream_t s);

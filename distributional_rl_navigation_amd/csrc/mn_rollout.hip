@@ -14,6 +14,7 @@
 __device__ unsigned long long g_rollout_phase[16];
 #define MN_PHASE_VAR g_rollout_phase
 #endif
+#include "mn_planners.h"
 #include "mn_reset_body.h"
 #include "mn_step_body.h"
 
@@ -118,6 +119,89 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES(L)) void mn_rollout_k
     if (stepped) ln.store(A);
 }
 
+// ---- episodes under an observation-reading policy, one launch (mn_rollout_policy; round 4) ------------------------------------------
+// The reference's classical-baseline sweeps (run_experiments.py:100-190,213-282: APF / BA on 500 worlds, one episode each) call a python
+// policy on every observation; the batched path so far paid a launch trio per policy step.  Here the policy is a device function
+// (mn_planners.h) and runs INSIDE the rollout: after a step the lane group parks the observation row in LDS, lane 0 of the group evaluates
+// the policy on it -- on the float32 row, exactly what the launch-per-step path feeds planners.py -- and hands the action to the group
+// for the next step.  EPISODE semantics: an env that finishes is NOT reset; it idles for the rest of the launch (its traces read reward 0,
+// done 1, the terminal info code, action -1), its terminal pose and counters are stored.  Per step the same MnLane::step as everywhere else:
+// bit-identical to a loop of (policy launch, mn_step) on the same worlds.
+template <typename M, bool PARITY, int L>
+__global__ __launch_bounds__(MN_WAVE, 1) void mn_rollout_policy_kernel(MnArrays A, MnDev P, int n_steps, int policy, float *__restrict__ obs_io, MnTrace T) {
+    __shared__ float rows[MN_WAVE / L][28];
+    using Lane = MnLane<M, PARITY, L>;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = tid / L, q = tid % L, slot = (threadIdx.x & (MN_WAVE - 1)) / L;
+    const size_t n = (size_t)A.n;
+    if (tid == 0) { A.queue_count[0] = 0u; A.queue_count[1] = 0u; }
+    const MnRing none = {};
+    MnPlanTabs tabs;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tabs.a[k] = P.a[k]; tabs.w[k] = P.w[k]; }
+    Lane ln;
+    ln.load(A, e, q);
+    // the observation the episode continues from (mn_reset / mn_load_worlds left it in obs_io)
+    for (int k = q; k < MN_OBS_DIM; k += L) rows[slot][k] = ln.active ? obs_io[(size_t)e * MN_OBS_DIM + k] : 0.f;
+    bool alive = ln.active;
+    int last_info = 0;
+    for (int t = 0; t < n_steps; ++t) {
+        __syncthreads();      // (one wavefront per workgroup) the row of the previous step is complete
+        int action = 0;
+        if (q == 0 && alive) action = mn_policy_act(policy, rows[slot], tabs);
+        action = __shfl(action, (int)(threadIdx.x & (MN_WAVE - 1)) - q);      // from the group's lane 0
+        __syncthreads();      // every lane has its action before the step overwrites the row
+        float *trow = T.obs ? T.obs + ((size_t)t * n + (ln.active ? e : 0)) * MN_OBS_DIM : nullptr;
+        const MnStepOut o = ln.template step<false>(A, P, action, rows[slot], (PARITY && A.obs64) ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none,
+                                                    nullptr, nullptr, (alive && trow) ? trow : nullptr);
+        if (ln.active && q == 0) {
+            const size_t k = (size_t)t * n + e;
+            if (T.reward) T.reward[k] = alive ? (float)o.reward : 0.f;
+            if (T.done) T.done[k] = alive ? (uint8_t)o.done : (uint8_t)1;
+            if (T.info) T.info[k] = alive ? (uint8_t)o.info : (uint8_t)last_info;
+            if (T.action) T.action[k] = alive ? action : -1;
+        }
+        if (alive) {
+            if (o.done) {      // terminal pose, counters and observation of this env are final
+                ln.store(A);
+                __builtin_amdgcn_wave_barrier();
+                for (int k = q; k < MN_OBS_DIM; k += L) obs_io[(size_t)e * MN_OBS_DIM + k] = rows[slot][k];
+                last_info = o.info;
+                alive = false;
+            }
+        }
+        // (an env that has finished keeps stepping from its terminal pose -- the lane group's cross-lane work is wave-uniform -- but
+        // nothing of it is stored or traced; its row in LDS no longer feeds a policy call)
+        if (!__any(alive)) {      // the whole wave is done: fill the remaining trace entries and leave
+            for (int t2 = t + 1; t2 < n_steps; ++t2)
+                if (ln.active && q == 0) {
+                    const size_t k = (size_t)t2 * n + e;
+                    if (T.reward) T.reward[k] = 0.f;
+                    if (T.done) T.done[k] = 1;
+                    if (T.info) T.info[k] = (uint8_t)last_info;
+                    if (T.action) T.action[k] = -1;
+                }
+            return;
+        }
+    }
+    if (alive) {      // still running after n_steps: the state the next call continues from
+        ln.store(A);
+        __syncthreads();
+        for (int k = q; k < MN_OBS_DIM; k += L) obs_io[(size_t)e * MN_OBS_DIM + k] = rows[slot][k];
+    }
+}
+
+// one policy step for a whole vector of observation rows (the launch-per-step path of experiments.py)
+__global__ __launch_bounds__(256) void mn_planner_act_kernel(const float *__restrict__ obs, int n, int policy, MnPlanTabs tabs, int32_t *__restrict__ actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float o[MN_OBS_DIM];
+    const float2 *row = reinterpret_cast<const float2 *>(obs + (size_t)i * MN_OBS_DIM);
+#pragma unroll
+    for (int k = 0; k < MN_OBS_DIM / 2; ++k) { const float2 v = row[k]; o[2 * k] = v.x; o[2 * k + 1] = v.y; }
+    actions[i] = mn_policy_act(policy, o, tabs);
+}
+
 template <typename M, bool PARITY>
 void launch_rollout(int lanes, const MnArrays &A, const MnDev &P, int n_steps, const int32_t *actions_in, uint64_t seed,
                     uint64_t step0, uint64_t env0, float *obs_out, const MnTrace &T, hipStream_t s) {
@@ -161,6 +245,21 @@ extern "C" int mn_debug_rollout_phases(unsigned long long *out_host, int reset) 
     return MN_OK;
 }
 #endif
+
+void mn_launch_rollout_policy(const MnArrays &A, const MnDev &P, int precision, int n_steps, int policy, float *obs_io, float *obs_trace,
+                              float *reward_trace, uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s) {
+    const MnTrace T = {obs_trace, reward_trace, done_trace, info_trace, action_trace};
+    constexpr int LL = 8;      // eight lanes per env: the sweeps this serves are a few hundred to a few thousand envs, latency-bound per wave
+    const dim3 grid((unsigned)((size_t)A.npad * LL / MN_WAVE));
+    if (precision == MN_PRECISION_F64) hipLaunchKernelGGL((mn_rollout_policy_kernel<double, true, LL>), grid, dim3(MN_WAVE), 0, s, A, P, n_steps, policy, obs_io, T);
+    else hipLaunchKernelGGL((mn_rollout_policy_kernel<float, false, LL>), grid, dim3(MN_WAVE), 0, s, A, P, n_steps, policy, obs_io, T);
+}
+
+void mn_launch_planner_act(const float *obs, int n, int policy, const double *a, const double *w, int32_t *actions, hipStream_t s) {
+    MnPlanTabs tabs;
+    for (int k = 0; k < 3; ++k) { tabs.a[k] = a[k]; tabs.w[k] = w[k]; }
+    hipLaunchKernelGGL(mn_planner_act_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, n, policy, tabs, actions);
+}
 
 void mn_launch_random_actions(uint64_t seed, uint64_t step, uint64_t env0, int n, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(mn_random_actions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, step, env0, n, out);

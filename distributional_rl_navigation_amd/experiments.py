@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .marinenav_env.vec_env import VecMarineNavEnv
-from .planners import apf_act_batch, ba_act_batch
+from .planners import planner_act_batch
 
 POLICIES = ("adaptive_IQN", "IQN_0.25", "IQN_0.5", "IQN_0.75", "IQN_1.0", "APF", "BA")   # run_experiments.py:216 (minus DQN)
 ALL_POLICIES = POLICIES[:5] + ("DQN",) + POLICIES[5:]                                        # run_experiments.py:216, needs `dqn=`
@@ -68,8 +68,49 @@ def _episode_record(world, params, name, actions, traj, cvars=None, quantiles=No
 
 
 @torch.no_grad()
+def _classical_episodes(worlds, name, device, max_steps, seed):
+    """All of `worlds` under the classical baseline `name` ("APF" / "BA"), one episode each, as ONE launch: the policy runs inside the
+    rollout kernel (VecMarineNavEnv.rollout_policy -> mn_rollout_policy).  Same result record as the launch-per-step path."""
+    num = len(worlds)
+    env = VecMarineNavEnv(num, device=device, precision="f64")
+    _configure(env)
+    env.load_worlds(worlds)
+    dev = env.device
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    tr = env.rollout_policy(max_steps, name)
+    e1.record()
+    reward, done, info, acts = tr["reward"], tr["done"].bool(), tr["info"], tr["action"]
+    T = reward.shape[0]
+    a_tab = torch.tensor(env.params.a[:], device=dev); w_tab = torch.tensor(env.params.w[:], device=dev)
+    energy_tab = ((a_tab / a_tab.max()).abs().view(3, 1) + (w_tab / w_tab.max()).abs().view(1, 3)).reshape(-1)
+    alive = torch.ones(num, dtype=torch.bool, device=dev)
+    ret = torch.zeros(num, dtype=torch.float64, device=dev); energy = torch.zeros_like(ret)
+    length = torch.zeros(num, dtype=torch.int64, device=dev)
+    last_info = torch.zeros(num, dtype=torch.uint8, device=dev)
+    for t in range(T):      # the bookkeeping of the per-step loop below, on the traces (same operations, same order)
+        ret += torch.where(alive, (env.discount ** t) * reward[t].double(), torch.zeros_like(ret))
+        length += alive.long()
+        energy += torch.where(alive, energy_tab[acts[t].clamp_min(0).long()].double(), torch.zeros_like(energy))
+        last_info = torch.where(alive, info[t], last_info)
+        alive = alive & ~done[t]
+        if not bool(alive.any()):
+            break
+    torch.cuda.synchronize(dev)
+    length_h, info_h, acts_h = length.cpu().numpy(), last_info.cpu().numpy(), acts.cpu().numpy()
+    dtN = env.params.dt * env.params.N
+    per_action = e0.elapsed_time(e1) * 1e-3 / max(1, int(length_h.sum()))
+    rec = dict(success=[bool(v) for v in info_h == 4], out_of_area=[bool(v) for v in info_h == 1],
+               time=[float(dtN * l) for l in length_h], energy=[float(v) for v in energy.cpu().numpy()],
+               reward=[float(v) for v in ret.cpu().numpy()],
+               actions=[[int(x) for x in acts_h[:length_h[i], i]] for i in range(num)],
+               computation_times=[per_action] * int(length_h.sum()))
+    env.close()
+    return rec
+
+
 def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, device="cuda:0", max_steps=1000, dqn=None,
-                   capture=False):
+                   capture=False, classical_rollout=True):
     """run_experiments.py:213-282 for the IQN policies, the classical APF / BA baselines and (when `dqn`, a
     `dqn.DQNPolicy`, is given and "DQN" is in `policies`) the greedy DQN baseline.  Returns {policy: dict(success, time, energy,
     out_of_area, reward, actions)} with one entry per world.  With `capture` each policy also gets the reference's `ep_data`
@@ -80,6 +121,15 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
     policy group (HIP events) divided by the rows the launch served, one entry per step of every episode -- the amortised cost of one
     action, which is what `avg_compute_t` (run_experiments.py:274) averages."""
     worlds = generate_worlds(num, n_obs, n_cores, seed, device)
+    # APF / BA: the policy is a device function inside the episode rollout kernel -- one launch per policy for all worlds -- unless the
+    # per-sub-step trajectory is wanted (`capture`), which the launch-per-step path below records
+    requested = tuple(policies)
+    rolled = {}
+    if classical_rollout and not capture:
+        rolled = {name: _classical_episodes(worlds, name, device, max_steps, seed) for name in requested if name in ("APF", "BA")}
+        policies = tuple(p for p in requested if p not in rolled)
+        if not policies:
+            return {name: rolled[name] for name in requested}, worlds
     n = num * len(policies)
     env = VecMarineNavEnv(n, device=device, precision="f64")
     _configure(env)
@@ -143,8 +193,7 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
             if name == "DQN":                                                # run_experiments.py:86 (greedy predict)
                 a[rows] = timed(name, lambda: dqn.act_batch(obs[rows]))
                 continue
-            fn = apf_act_batch if name == "APF" else ba_act_batch
-            a[rows] = timed(name, lambda: fn(obs[rows].double(), a_tab.double(), w_tab.double()).to(torch.int32))
+            a[rows] = timed(name, lambda: planner_act_batch(obs[rows], name, env.params.a[:], env.params.w[:]))      # one HIP launch (mn_planner_act)
         obs, reward, done, info = env.step(a)
         if capture:
             cap_traj.append(env.get_trajectory())
@@ -191,4 +240,5 @@ def run_experiment(agent, n_obs, n_cores, num=500, seed=15, policies=POLICIES, d
                     eps_.append(_episode_record(worlds[i - p * num], env.params, name, acts_h[:L, i], traj, seed=seed))
             out[name]["ep_data"] = eps_
     env.close()
-    return out, worlds
+    out.update(rolled)
+    return {name: out[name] for name in requested}, worlds

@@ -229,6 +229,27 @@ class VecMarineNavEnv:
         out["final_obs"] = self.obs
         return out
 
+    POLICIES = {"APF": 1, "BA": 2}      # MN_POLICY_APF / MN_POLICY_BA (include/marinenav_hip.h)
+
+    def rollout_policy(self, n_steps, policy, trace=("reward", "done", "info", "action")):
+        """Every env's CURRENT episode under the classical baseline `policy` ("APF" = APF.py:17-78, "BA" = BA.py:14-155) for up to
+        `n_steps` steps in ONE launch (C-ABI mn_rollout_policy): the policy is evaluated on the device on each step's observation row.
+        No resets: a finished env idles (reward 0, done 1, terminal info, action -1 in the traces).  Step for step identical to the
+        loop (planners.planner_act_batch, step).  Returns the requested traces + `final_obs` (terminal observations where finished)."""
+        T, n, dev = int(n_steps), self.n_envs, self.device
+        mk = dict(obs=lambda: torch.zeros(T, n, OBS_DIM, dtype=torch.float32, device=dev),
+                  reward=lambda: torch.empty(T, n, dtype=torch.float32, device=dev),
+                  done=lambda: torch.empty(T, n, dtype=torch.uint8, device=dev),
+                  info=lambda: torch.empty(T, n, dtype=torch.uint8, device=dev),
+                  action=lambda: torch.empty(T, n, dtype=torch.int32, device=dev))
+        tr = {k: mk[k]() for k in trace}
+        p = lambda k: _ptr(tr[k]) if k in tr else None
+        self._check(self.L.mn_rollout_policy(self.h, T, int(self.POLICIES[policy]), _ptr(self.obs), p("obs"), p("reward"), p("done"), p("info"),
+                                             p("action"), self._stream()))
+        out = dict(tr)
+        out["final_obs"] = self.obs
+        return out
+
     def random_actions(self, action_seed, step):
         """The actions `rollout(action_seed=...)` takes at step index `step` (int32 [n] on the device)."""
         a = torch.empty(self.n_envs, dtype=torch.int32, device=self.device)

@@ -10,6 +10,28 @@ import math
 import torch
 
 
+def planner_act_batch(obs, kind, a, w):
+    """One policy step of the classical baselines for obs [N, 26] float32 ON THE GPU as one HIP launch (C-ABI mn_planner_act: the device
+    functions of csrc/mn_planners.h, float64 arithmetic on the float32 observation rows) -> actions [N] int32.  `kind`: "APF" | "BA".
+    The tensor formulations below (`apf_act_batch`, `ba_act_batch`) are the same maps in PyTorch ops: the definition the kernel is tested
+    against, and what runs on CPU tensors."""
+    import ctypes as C
+    from . import _capi
+    assert obs.is_cuda and obs.dtype == torch.float32
+    obs = obs.contiguous()
+    n = obs.shape[0]
+    out = torch.empty(n, dtype=torch.int32, device=obs.device)
+    if n == 0:
+        return out
+    at = (C.c_double * 3)(*[float(v) for v in a])
+    wt = (C.c_double * 3)(*[float(v) for v in w])
+    rc = _capi.lib().mn_planner_act(C.c_void_p(obs.data_ptr()), n, {"APF": 1, "BA": 2}[kind], at, wt, C.c_void_p(out.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_planner_act failed ({rc})")
+    return out
+
+
 def _wrap_to_pi(a):
     """BA.py:157-162 / APF.py:55-59: wrap to [-pi, pi).  Arguments are differences of two atan2 values
     (or one +- a margin), i.e. inside (-3pi, 3pi): two conditional shifts reproduce the reference's while

@@ -171,6 +171,19 @@ int mn_step_append(mn_handle *h, const int32_t *actions_dev, const float *prev_o
 int mn_rollout(mn_handle *h, int32_t n_steps, const int32_t *actions_dev, uint64_t action_seed, uint64_t first_step_index,
                uint64_t first_env_index, float *obs_dev, float *obs_trace_dev, float *reward_trace_dev,
                uint8_t *done_trace_dev, uint8_t *info_trace_dev, int32_t *action_trace_dev, void *stream);
+/* EPISODES under an observation-reading policy in ONE launch (the classical baselines of run_experiments.py:100-190,
+ * 213-282).  policy = MN_POLICY_APF (APF_agent.act, APF.py:17-78) or MN_POLICY_BA (BA_agent.act, BA.py:14-155), evaluated on the device on
+ * the float32 observation row each step produces (tables a / w = the handle's robot parameters).  Every env runs its CURRENT episode --
+ * starting from the observation in obs_dev -- for up to n_steps steps; an env that finishes is NOT reset: it idles, its traces read
+ * reward 0 / done 1 / its terminal info code / action -1 from then on, obs_dev keeps its terminal observation.  Step for step
+ * bit-identical to a loop of (mn_planner_act, mn_step).  Traces as mn_rollout ([n_steps][n] ...; any may be NULL). */
+#define MN_POLICY_APF 1
+#define MN_POLICY_BA 2
+int mn_rollout_policy(mn_handle *h, int32_t n_steps, int32_t policy, float *obs_dev, float *obs_trace_dev, float *reward_trace_dev,
+                      uint8_t *done_trace_dev, uint8_t *info_trace_dev, int32_t *action_trace_dev, void *stream);
+/* One policy step of the same device functions for n observation rows [n][26] f32 -> actions [n] i32; a[3], w[3]: HOST arrays, the
+ * robot's acceleration / angular-velocity tables (robot.py:35-36). */
+int mn_planner_act(const float *obs_dev, int32_t n, int32_t policy, const double *a, const double *w, int32_t *actions_dev, void *stream);
 /* The action draws of mn_rollout for one step: actions_dev[i] = action of env (first_env_index + i) at step step_index. */
 int mn_random_actions(uint64_t action_seed, uint64_t step_index, uint64_t first_env_index, int32_t n, int32_t *actions_dev,
                       void *stream);
