@@ -57,7 +57,9 @@ def test_dqn_kernel_against_float64_and_eager_for_any_batch_size(torch):
     pol.use_fused_act = True
     scale = float(ref.abs().max())
     e_hip, e_eager = float((q.double() - ref).abs().max()) / scale, float((q_eager.double() - ref).abs().max()) / scale
-    assert e_hip < 2e-6 and e_hip < 2.0 * e_eager + 2e-7, (e_hip, e_eager)
+    # (this network is badly conditioned for float32 -- random observations give ~1e-5 of max |Q| in ANY float32 evaluation -- so the
+    # yardstick is eager PyTorch float32 on the same GPU, not an absolute figure)
+    assert e_hip < 1.5 * e_eager + 2e-7 and e_hip < 1e-4, (e_hip, e_eager)
     a = pol.act_batch(obs)
     assert a.dtype == torch.int32 and bool((a.long() == q.argmax(1)).all())
     for lo, hi in ((0, 1), (5, 22), (100, 116), (4000, 4099)):
@@ -66,7 +68,10 @@ def test_dqn_kernel_against_float64_and_eager_for_any_batch_size(torch):
         pol.q_net.q_net[2].weight.mul_(1.25); pol.q_net.features_extractor.hidden_layer.bias.add_(0.5)
         ref2 = copy.deepcopy(pol.q_net).double()(obs.double())
     q2 = pol.q_values(obs)
-    assert float((q2.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6 and not torch.equal(q2, q)
+    pol.use_fused_act = False
+    e2_eager = float((pol.q_values(obs).double() - ref2).abs().max()) / float(ref2.abs().max())
+    pol.use_fused_act = True
+    assert float((q2.double() - ref2).abs().max()) / float(ref2.abs().max()) < 1.5 * e2_eager + 2e-7 and not torch.equal(q2, q)
 
 
 def test_dqn_closed_loop_on_hip_env(torch):
