@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) void iqn_prep32_kernel(IqnWeights w, float *__
 
 #include "iqn_act_split.h"
 #include "iqn_act_split32.h"
+#include "iqn_act_tiled.h"
 
 // ---- what clock does THIS GPU sustain under f16 matrix load?  (mn_probe_mfma_clock; round 4)
 // The same act binary runs 10-12 % slower on some boxes of the pool (304-318 us vs 352-367 us per 65 536-env launch) while the
@@ -821,7 +822,9 @@ struct mn_iqn_ctx {
     uint32_t *packed_sp = nullptr; // weight image of the split-f16 kernel (iqn_act_split.h)
     uint32_t *packed_sp32 = nullptr;   // ... and of its 32x32x16 form (iqn_act_split32.h)
     float *consts_sp = nullptr;    // its scale / bound constants
-    float *h1_sp = nullptr;        // the launch's layer-1 constant [32 taus x 208] of the shared-tau kernel (mn_iqn_set_tau_mode)
+    float *h1_sp = nullptr;        // the launch's layer-1 constant [32 taus x 208] of the shared-tau kernels (mn_iqn_set_tau_mode) + 32 block maxima
+    uint32_t *timg = nullptr;      // tiled shared-tau kernel (iqn_act_tiled.h): T = W2 h1 as hi / lo f16 pairs, and its auxiliary float block
+    float *taux = nullptr;
     int tau_mode = 0;              // 0 = every environment its own 32 taus (the reference's per-call draw), 1 = one set of 32 per launch
     bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
@@ -856,6 +859,8 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::TL_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::OFF_FB * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -871,7 +876,9 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp32), sp32::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->h1_sp), sp::H1_FLOATS * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->h1_sp), (sp::H1_FLOATS + 32) * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->timg), sp::T_WORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->taux), sp::TA_FLOATS * sizeof(float)) != hipSuccess ||
         hipMemset(c->consts_sp, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(c->packed);
         (void)hipFree(c->packed32);
@@ -879,6 +886,8 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         (void)hipFree(c->packed_sp32);
         (void)hipFree(c->consts_sp);
         (void)hipFree(c->h1_sp);
+        (void)hipFree(c->timg);
+        (void)hipFree(c->taux);
         delete c;
         return MN_ERR_ALLOC;
     }
@@ -898,6 +907,8 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->packed_sp32);
     (void)hipFree(c->consts_sp);
     (void)hipFree(c->h1_sp);
+    (void)hipFree(c->timg);
+    (void)hipFree(c->taux);
     (void)hipFree(c->slot_sp[0]);
     (void)hipFree(c->slot_sp[1]);
     (void)hipFree(c->slot_consts);
@@ -922,7 +933,7 @@ extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
 }
 
 extern "C" int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode) {
-    if (!c || mode < 0 || mode > 1) return MN_ERR_INVALID;
+    if (!c || mode < 0 || mode > 2) return MN_ERR_INVALID;
     c->tau_mode = mode;
     return MN_OK;
 }
@@ -979,7 +990,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     // quantile capture (act_eval): the split-f16 kernel's QUANT form for variants 2 and 3, the exact 16x16x4 kernel's for 0 and 1
     const bool use_sp = c->variant == 2 || (quantiles_dev && c->variant == 3), use_sp32 = !quantiles_dev && c->variant == 3;
     const bool use32 = !quantiles_dev && c->variant == 1;
-    if (c->tau_mode == 1) {
+    if (c->tau_mode != 0) {
         // Launch-shared taus: ONE set of 32 quantile fractions for every environment of the launch (iqn_act_split.h, stage_sh).  Only the
         // split-f16 kernel has this form; per-row CVaR (adaptive policies) needs per-environment taus; the explicitly managed image slots
         // of the two-stream loop would pair a lagging image with a layer-1 constant of the live weights.
@@ -995,6 +1006,16 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
                            c->packed_sp, (const uint64_t *)rng_state_dev, draws_dev, n, rng_state_dev ? nullptr : taus_dev, cvar, pack_blocks, c->h1_sp);
         if (rng_state_dev) explore_u_dev = eps > 0.f ? draws_dev + K_TAUS : nullptr;
         c->dirty_sp = false;
+        if (c->tau_mode == 1 && !quantiles_dev && n >= sp::TILED_MIN_ENVS) {
+            // large batch: the MFMA columns are environments (iqn_act_tiled.h): T = W2 h1 built once, 32 environments per wavefront
+            hipLaunchKernelGGL(sp::iqn_tiled_prep_kernel, dim3(sp::T_PREP_BLOCKS + sp::TA_PREP_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                               (const float *)c->h1_sp, c->timg, c->taux);
+            hipLaunchKernelGGL(sp::iqn_qvals_tiled_kernel, dim3((n + 255) / 256), dim3(512), sp::TL_FLOATS * sizeof(float), s, obs_dev,
+                               (const uint32_t *)c->packed_sp, (const uint32_t *)c->timg, (const float *)c->taux, qvals_dev, explore_u_dev, eps,
+                               actions_dev, n, rng_state_dev);
+            if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
+            return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+        }
         if (quantiles_dev)
             hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<true, true, 8>), dim3(blocks), dim3(512), sp::OFF_FB * sizeof(float), s, obs_dev, (const float *)nullptr,
                                (const uint32_t *)c->packed_sp, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)c->h1_sp);

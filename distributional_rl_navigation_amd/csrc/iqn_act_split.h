@@ -651,7 +651,16 @@ __global__ __launch_bounds__(256) void iqn_shared_prep_kernel(IqnWeights w, cons
         const int j = 16 * t + 4 * (lane >> 4) + r, ti = 16 * nt + (lane & 15);
         float a = w.b1[j];
         for (int k = 0; k < N_COS; ++k) a = fmaf(w.W1[j * N_COS + k], cs[ti][k], a);
-        h1[o] = fmaxf(a, 0.f);
+        a = fmaxf(a, 0.f);
+        h1[o] = a;
+        // this block's maximum behind the constant (the tiled kernel's preparation scales T = W2 h1 by it)
+        __shared__ float bmax[4];
+        float m = a;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) bmax[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) h1[H1_FLOATS + hb] = fmaxf(fmaxf(bmax[0], bmax[1]), fmaxf(bmax[2], bmax[3]));
         return;
     }
     if (taus_in) return;

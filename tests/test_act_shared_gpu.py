@@ -252,3 +252,93 @@ def test_argument_checks(torch):
     finally:
         ctx.set_variant(ctx.DEFAULT_VARIANT)
         ctx.set_tau_mode(0)
+
+
+# ---- the environment-tiled form (csrc/iqn_act_tiled.h): mode 1 from 16 384 rows up ----------------------------------------------------
+def _f64_ref(torch, net, obs, row):
+    n = obs.shape[0]
+    bc = row.view(1, 32).expand(n, 32).contiguous()
+    with torch.no_grad():
+        return copy.deepcopy(net).double().get_qvals(obs.double(), 1.0, taus=bc.double()), bc
+
+
+@pytest.mark.parametrize("which", ["seeded", "pretrained"])
+def test_env_tiled_kernel_is_float32_class_and_agrees_with_the_wavefront_per_row_form(torch, which):
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
+    net = _net(torch, which)
+    obs, row = _inputs(torch, 16384 + 37, 5.0)      # ragged: the last workgroup's waves are partly / entirely past the end
+    ref, bc = _f64_ref(torch, net, obs, row)
+    ctx = act_context(net)
+    try:
+        ctx.set_variant(0)
+        _, qe = fused_act(net, obs, 0.0, 1.0, taus=bc, want_qvals=True)
+    finally:
+        ctx.set_variant(ctx.DEFAULT_VARIANT)
+    aw, qw = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="wave")
+    at, qt = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    assert ctx.tau_mode == 1 and not torch.equal(qw, qt)      # (another kernel ran: another rounding)
+
+    def err(q):
+        d = (q.double() - ref).abs()
+        return float(d.max() / ref.abs().max()), float((d.pow(2).mean() / ref.pow(2).mean()).sqrt())
+    (mx_e, rms_e), (mx_t, rms_t) = err(qe), err(qt)
+    assert rms_t < 1.25 * rms_e + 2e-8 and mx_t < 1.5 * mx_e + 1e-7, (mx_e, rms_e, mx_t, rms_t)
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * float(ref.abs().max())
+    assert torch.equal(at.long()[clear], ref.argmax(dim=1)[clear]) and bool((at.long() == qt.argmax(1)).all())
+    # rows do not depend on the batch they are in
+    _, q_more = fused_act(net, torch.cat([obs, obs[:5000]]).contiguous(), 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    assert torch.equal(q_more[:obs.shape[0]], qt) and torch.equal(q_more[obs.shape[0]:], qt[:5000])
+
+
+@pytest.mark.parametrize("case", ["obs x 1e6", "obs x 1e-6", "obs zero", "weights x 30", "weights x 1e-3", "one huge weight", "one env huge among small",
+                                  "tiny layer-1 bounds"])
+def test_env_tiled_kernel_range_scaling_cases(torch, case):
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+    net = _net(torch, "seeded")
+    obs, row = _inputs(torch, 16384, 5.0)
+    with torch.no_grad():
+        if case == "obs x 1e6": obs *= 1e6
+        elif case == "obs x 1e-6": obs *= 1e-6
+        elif case == "obs zero": obs.zero_()
+        elif case == "weights x 30":
+            for p in net.parameters():
+                if p.dim() == 2: p.mul_(30.0)
+        elif case == "weights x 1e-3":
+            for p in net.parameters():
+                if p.dim() == 2: p.mul_(1e-3)
+        elif case == "one huge weight":
+            net.hidden_layer.weight[3, 100] = 500.0; net.cos_embedding.weight[100, 7] = -80.0
+        elif case == "one env huge among small":
+            obs *= 1e-3; obs[17] = 1e5
+        elif case == "tiny layer-1 bounds":      # B1_j << 1: the feature operand must be scaled by max |f|, not by the activation bound
+            net.cos_embedding.weight.mul_(1e-4); net.cos_embedding.bias.mul_(1e-4); obs *= 100.0
+    ref, bc = _f64_ref(torch, net, obs, row)
+    _, q0 = fused_act(net, obs, 0.0, 1.0, taus=bc, want_qvals=True)
+    _, q1 = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    assert bool(torch.isfinite(q1).all())
+    row_scale = ref.abs().max(dim=1).values.clamp_min(1e-30)
+    e0 = float(((q0.double() - ref).abs().max(dim=1).values / row_scale).max())
+    e1 = float(((q1.double() - ref).abs().max(dim=1).values / row_scale).max())
+    assert e1 < 2.0 * e0 + 1e-6, (case, e0, e1)
+
+
+def test_env_tiled_kernel_library_draws_and_exploration(torch):
+    from distributional_rl_navigation_amd.iqn.fused_act import ActRng, fused_act
+    net = _net(torch, "pretrained")
+    obs, _ = _inputs(torch, 30000, 5.0)
+    n = obs.shape[0]
+    rng = ActRng(77, DEV)
+    a, q = fused_act(net, obs, 0.0, 0.5, rng=rng, want_qvals=True, shared_taus=True)
+    assert int(rng.state[1]) == 1
+    row = rng.draws(n, 32)[:32].clone()
+    _, q_inj = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    assert torch.equal(q, q_inj) and bool((a.long() == q.argmax(1)).all())
+    a_e = fused_act(net, obs, 1.0, 1.0, rng=rng, shared_taus=True)
+    cnt = torch.bincount(a_e.long(), minlength=9).float() / n
+    assert bool(((a_e >= 0) & (a_e < 9)).all()) and float((cnt - 1 / 9).abs().max()) < 0.01
+    a_g = fused_act(net, obs, 0.3, 1.0, rng=rng, shared_taus=True)
+    u = rng.draws(n, 32)[32:32 + n]
+    a_greedy = fused_act(net, obs, 0.0, 1.0, taus=rng.draws(n, 32)[:32].clone(), shared_taus=True)
+    keep = u > 0.3
+    assert torch.equal(a_g[keep], a_greedy[keep]) and 0.67 < float(keep.float().mean()) < 0.73
