@@ -235,7 +235,7 @@ def test_argument_checks(torch):
     net = _net(torch, "seeded")
     ctx = act_context(net)
     lib = _capi.lib()
-    assert lib.mn_iqn_set_tau_mode(ctx.h, 2) != 0 and lib.mn_iqn_set_tau_mode(None, 1) != 0
+    assert lib.mn_iqn_set_tau_mode(ctx.h, 3) != 0 and lib.mn_iqn_set_tau_mode(None, 1) != 0
     obs = torch.zeros(8, 26, device=DEV); row = torch.rand(32, device=DEV); q = torch.empty(8, 9, device=DEV)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     try:
