@@ -182,34 +182,47 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) hs[c][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int PF = T_U4_PER_TAU / 512;      // 7 16-byte units of the next tau's tile per thread
-    static_assert(T_U4_PER_TAU % 512 == 0, "prefetch shape");
+    static_assert(T_U4_PER_TAU % 512 == 0 && PF == KB2, "prefetch shape: one unit per thread and K block");
+    int lbase = lane;      // opaque LDS index base (keeps hipcc from materialising one address register per read)
+    asm volatile("" : "+v"(lbase));
     for (int tau = 0; tau < K_TAUS; ++tau) {
-        const int cur = (tau & 1) ? TL_T1 : TL_T0, nxt = (tau & 1) ? TL_T0 : TL_T1;
+        const int cur = ((tau & 1) ? TL_T1 : TL_T0) + lbase, nxt = ((tau & 1) ? TL_T0 : TL_T1) + tid;
         const bool more = tau + 1 < K_TAUS;
-        u32x4 pf[PF];
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) pf[u] = t4[(size_t)(tau + 1) * T_U4_PER_TAU + u * 512 + tid];
-        }
-        // layer 2: acc2[mt][c] = T[tau] (S1 f), three f16 products per float32 product
+        const u32x4 *tnext = t4 + (size_t)(more ? tau + 1 : tau) * T_U4_PER_TAU + tid;
+        // layer 2: acc2[mt][c] = T[tau] (Sf f), three f16 products per float32 product.  One software-pipelined stream of 28 steps
+        // (K block, output tile): the A operands of step s + 2 are requested from LDS before the six MFMAs of step s are issued, so a
+        // wave hides its own LDS latency (the per-tau barrier keeps the waves of a workgroup in step: a partner wave is in the same
+        // phase, not in another one).  The next tau's tile travels global -> registers -> the other LDS buffer in the same stream, one
+        // 16-byte unit per K block (the buffer was last read one iteration ago, before the barrier that ended it).
         f32x4 acc2[4][TC];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int NS = 4 * KB2, AHEAD = 2;
+        u32x4 ah[AHEAD + 1], al[AHEAD + 1], pf = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int kb = 0; kb < KB2; ++kb)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, lds4[cur + ((mt * KB2 + kb) * 2) * 64 + lane]);
-                const f16x8 al = __builtin_bit_cast(f16x8, lds4[cur + ((mt * KB2 + kb) * 2 + 1) * 64 + lane]);
-#pragma unroll
-                for (int c = 0; c < TC; ++c) {
-                    acc2[mt][c] = mf(al, fh[c][kb], acc2[mt][c]);
-                    acc2[mt][c] = mf(ah, fl[c][kb], acc2[mt][c]);
-                    acc2[mt][c] = mf(ah, fh[c][kb], acc2[mt][c]);
-                }
+        for (int s0 = 0; s0 < AHEAD; ++s0) {
+            ah[s0] = lds4[cur + (((s0 & 3) * KB2 + (s0 >> 2)) * 2) * 64];
+            al[s0] = lds4[cur + (((s0 & 3) * KB2 + (s0 >> 2)) * 2 + 1) * 64];
+        }
+        static_for<NS>([&](auto S_) {
+            constexpr int s = decltype(S_)::value, kb = s >> 2, mt = s & 3, slot = s % (AHEAD + 1);
+            if constexpr (s + AHEAD < NS) {
+                constexpr int s2 = s + AHEAD, slot2 = s2 % (AHEAD + 1);
+                ah[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2) * 64];
+                al[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2 + 1) * 64];
             }
+            if constexpr (mt == 0) pf = tnext[kb * 512];                                  // next tau, unit kb: requested ...
+            if constexpr (mt == 3) { if (more) lds4[nxt + kb * 512] = pf; }               // ... and parked three steps later
+            const f16x8 a_h = __builtin_bit_cast(f16x8, ah[slot]), a_l = __builtin_bit_cast(f16x8, al[slot]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_l, fh[c][kb], acc2[mt][c]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fl[c][kb], acc2[mt][c]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fh[c][kb], acc2[mt][c]);
+        });
         // layer-2 epilogue: S2 h2 = relu(acc2 c2e + S2 b2), split in place: the B operands of layer 3
         f16x8 b3h[2][TC], b3l[2][TC];
 #pragma unroll
@@ -230,14 +243,14 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, lds4[TL_W3 + ((mt * 2 + kb) * 2) * 64 + lane]);
-                const f16x8 al = __builtin_bit_cast(f16x8, lds4[TL_W3 + ((mt * 2 + kb) * 2 + 1) * 64 + lane]);
+                const f16x8 ah = __builtin_bit_cast(f16x8, lds4[TL_W3 + lbase + ((mt * 2 + kb) * 2) * 64]);
+                const f16x8 al = __builtin_bit_cast(f16x8, lds4[TL_W3 + lbase + ((mt * 2 + kb) * 2 + 1) * 64]);
 #pragma unroll
-                for (int c = 0; c < TC; ++c) {
-                    acc3[mt][c] = mf(al, b3h[kb][c], acc3[mt][c]);
-                    acc3[mt][c] = mf(ah, b3l[kb][c], acc3[mt][c]);
-                    acc3[mt][c] = mf(ah, b3h[kb][c], acc3[mt][c]);
-                }
+                for (int c = 0; c < TC; ++c) acc3[mt][c] = mf(al, b3h[kb][c], acc3[mt][c]);
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc3[mt][c] = mf(ah, b3l[kb][c], acc3[mt][c]);
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc3[mt][c] = mf(ah, b3h[kb][c], acc3[mt][c]);
             }
         // layer-3 epilogue + the tau sum (a column is one environment: a running sum, no cross-lane work)
 #pragma unroll
@@ -246,12 +259,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
 #pragma unroll
             for (int c = 0; c < TC; ++c) hs[c][mt] += relu4s(fma4(acc3[mt][c], sc[c].c3e, bb * sc[c].S3));
         }
-        // the next tau's tile into the other buffer (last read one iteration ago, before the barrier that ended it)
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) lds4[nxt + u * 512 + tid] = pf[u];
-        }
-        __syncthreads();
+        __syncthreads();      // every wave has read T[tau] and parked its share of T[tau + 1]
     }
 
     // ---- output layer on the tau mean (linear: W4 mean(h3) + b4), argmax, epsilon-greedy --------------------------------------------------
