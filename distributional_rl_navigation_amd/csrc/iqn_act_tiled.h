@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         constexpr int NS = 4 * KB2, AHEAD = 2;
-        u32x4 ah[AHEAD + 1], al[AHEAD + 1], pf = {0u, 0u, 0u, 0u};
+        u32x4 ah[AHEAD + 1], al[AHEAD + 1], pf[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int s0 = 0; s0 < AHEAD; ++s0) {
             ah[s0] = lds4[cur + (((s0 & 3) * KB2 + (s0 >> 2)) * 2) * 64];
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
                 ah[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2) * 64];
                 al[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2 + 1) * 64];
             }
-            if constexpr (mt == 0) pf = tnext[kb * 512];                                  // next tau, unit kb: requested ...
-            if constexpr (mt == 3) { if (more) lds4[nxt + kb * 512] = pf; }               // ... and parked three steps later
+            if constexpr (mt == 0) pf[kb & 1] = tnext[kb * 512];                          // next tau, unit kb: requested ...
+            if constexpr (mt == 3 && kb >= 1) { if (more) lds4[nxt + (kb - 1) * 512] = pf[(kb - 1) & 1]; }      // ... and parked seven steps (~42 MFMAs) later
+            __builtin_amdgcn_sched_barrier(0);      // (left alone hipcc sinks the global load to its use and waits for it there)
             const f16x8 a_h = __builtin_bit_cast(f16x8, ah[slot]), a_l = __builtin_bit_cast(f16x8, al[slot]);
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_l, fh[c][kb], acc2[mt][c]);
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fl[c][kb], acc2[mt][c]);
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fh[c][kb], acc2[mt][c]);
+            __builtin_amdgcn_sched_barrier(0);
         });
         // layer-2 epilogue: S2 h2 = relu(acc2 c2e + S2 b2), split in place: the B operands of layer 3
         f16x8 b3h[2][TC], b3l[2][TC];
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
 #pragma unroll
             for (int c = 0; c < TC; ++c) hs[c][mt] += relu4s(fma4(acc3[mt][c], sc[c].c3e, bb * sc[c].S3));
         }
+        if (more) lds4[nxt + (KB2 - 1) * 512] = pf[(KB2 - 1) & 1];      // the last unit of the next tile
         __syncthreads();      // every wave has read T[tau] and parked its share of T[tau + 1]
     }
 
