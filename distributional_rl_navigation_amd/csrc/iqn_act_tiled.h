@@ -18,6 +18,10 @@
 // TILED_MIN_ENVS environments up and the wave-per-environment kernel below that.  Same arithmetic classes as the other split-f16 kernels
 // (three f16 products per float32 product, power-of-two scaling from guaranteed bounds); one more float32 rounding in T = W2 h1.
 
+#ifndef TILED_ABL
+#define TILED_ABL 0      // measurement builds only (scripts/act_tiled_ablation.sh; results are wrong by construction): 1 no layer-2 / -3 epilogues,
+#endif                   // 2 no per-tau barrier and no T prefetch, 4 no layer-3 MFMAs, 8 no layer-2 MFMAs, 16 no LDS reads of T
+
 namespace sp {
 
 constexpr int TILED_MIN_ENVS = 16384;
@@ -213,16 +217,21 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
                 ah[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2) * 64];
                 al[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2 + 1) * 64];
             }
-            if constexpr (mt == 0) pf[kb & 1] = tnext[kb * 512];                          // next tau, unit kb: requested ...
-            if constexpr (mt == 3 && kb >= 1) { if (more) lds4[nxt + (kb - 1) * 512] = pf[(kb - 1) & 1]; }      // ... and parked seven steps (~42 MFMAs) later
+            if constexpr (mt == 0 && !(TILED_ABL & 2)) pf[kb & 1] = tnext[kb * 512];                          // next tau, unit kb: requested ...
+            if constexpr (mt == 3 && kb >= 1 && !(TILED_ABL & 2)) { if (more) lds4[nxt + (kb - 1) * 512] = pf[(kb - 1) & 1]; }      // ... and parked seven steps (~42 MFMAs) later
             __builtin_amdgcn_sched_barrier(0);      // (left alone hipcc sinks the global load to its use and waits for it there)
             const f16x8 a_h = __builtin_bit_cast(f16x8, ah[slot]), a_l = __builtin_bit_cast(f16x8, al[slot]);
+            if constexpr (!(TILED_ABL & 8)) {
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_l, fh[c][kb], acc2[mt][c]);
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fl[c][kb], acc2[mt][c]);
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = mf(a_h, fh[c][kb], acc2[mt][c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc2[mt][c] += __builtin_bit_cast(f32x4, ah[slot]) + __builtin_bit_cast(f32x4, al[slot]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         // layer-2 epilogue: S2 h2 = relu(acc2 c2e + S2 b2), split in place: the B operands of layer 3
@@ -231,9 +240,11 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
         for (int kb = 0; kb < 2; ++kb) {
             const f32x4 bb0 = ldsv[(TL_B2 >> 2) + 4 * (2 * kb) + g], bb1 = ldsv[(TL_B2 >> 2) + 4 * (2 * kb + 1) + g];
 #pragma unroll
-            for (int c = 0; c < TC; ++c)
+            for (int c = 0; c < TC; ++c) {
+                if (TILED_ABL & 1) { b3h[kb][c] = __builtin_bit_cast(f16x8, acc2[2 * kb][c]); b3l[kb][c] = __builtin_bit_cast(f16x8, acc2[2 * kb + 1][c]); continue; }
                 split_tiles(relu4s(fma4(acc2[2 * kb][c], sc[c].c2e, bb0 * sc[c].S2)), relu4s(fma4(acc2[2 * kb + 1][c], sc[c].c2e, bb1 * sc[c].S2)),
                             b3h[kb][c], b3l[kb][c]);
+            }
         }
         // layer 3
         f32x4 acc3[4][TC];
@@ -247,6 +258,11 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
             for (int mt = 0; mt < 4; ++mt) {
                 const f16x8 ah = __builtin_bit_cast(f16x8, lds4[TL_W3 + lbase + ((mt * 2 + kb) * 2) * 64]);
                 const f16x8 al = __builtin_bit_cast(f16x8, lds4[TL_W3 + lbase + ((mt * 2 + kb) * 2 + 1) * 64]);
+                if (TILED_ABL & 4) {
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) acc3[mt][c] += __builtin_bit_cast(f32x4, ah) + __builtin_bit_cast(f32x4, b3h[kb][c]) + __builtin_bit_cast(f32x4, b3l[kb][c]);
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < TC; ++c) acc3[mt][c] = mf(al, b3h[kb][c], acc3[mt][c]);
 #pragma unroll
@@ -259,10 +275,12 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
         for (int mt = 0; mt < 4; ++mt) {
             const f32x4 bb = ldsv[(TL_B3 >> 2) + 4 * mt + g];
 #pragma unroll
-            for (int c = 0; c < TC; ++c) hs[c][mt] += relu4s(fma4(acc3[mt][c], sc[c].c3e, bb * sc[c].S3));
+            for (int c = 0; c < TC; ++c) hs[c][mt] += (TILED_ABL & 1) ? acc3[mt][c] : relu4s(fma4(acc3[mt][c], sc[c].c3e, bb * sc[c].S3));
         }
+        if (!(TILED_ABL & 2)) {
         if (more) lds4[nxt + (KB2 - 1) * 512] = pf[(KB2 - 1) & 1];      // the last unit of the next tile
         __syncthreads();      // every wave has read T[tau] and parked its share of T[tau + 1]
+        }
     }
 
     // ---- output layer on the tau mean (linear: W4 mean(h3) + b4), argmax, epsilon-greedy --------------------------------------------------
