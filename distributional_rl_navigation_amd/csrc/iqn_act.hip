@@ -933,7 +933,7 @@ extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
 }
 
 extern "C" int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode) {
-    if (!c || mode < 0 || mode > 2) return MN_ERR_INVALID;
+    if (!c || mode < 0 || mode > 3) return MN_ERR_INVALID;
     c->tau_mode = mode;
     return MN_OK;
 }
@@ -1006,7 +1006,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
                            c->packed_sp, (const uint64_t *)rng_state_dev, draws_dev, n, rng_state_dev ? nullptr : taus_dev, cvar, pack_blocks, c->h1_sp);
         if (rng_state_dev) explore_u_dev = eps > 0.f ? draws_dev + K_TAUS : nullptr;
         c->dirty_sp = false;
-        if (c->tau_mode == 1 && !quantiles_dev && n >= sp::TILED_MIN_ENVS) {
+        if (!quantiles_dev && ((c->tau_mode == 1 && n >= sp::TILED_MIN_ENVS) || c->tau_mode == 3)) {
             // large batch: the MFMA columns are environments (iqn_act_tiled.h): T = W2 h1 built once, 32 environments per wavefront
             hipLaunchKernelGGL(sp::iqn_tiled_prep_kernel, dim3(sp::T_PREP_BLOCKS + sp::TA_PREP_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp,
                                (const float *)c->h1_sp, c->timg, c->taux);

@@ -15,7 +15,11 @@
 // all (a lane's column IS one environment: the tau mean is a running sum in registers).  The encoders run as exact-f32 MFMAs
 // (v_mfma_f32_16x16x4_f32, block-diagonal 208 x 32 matrix): their C tiles are the B operand's k slots, as everywhere in this file family.
 // A workgroup (8 waves = 256 environments) streams all of T once, so the form only pays for large batches: the dispatcher uses it from
-// TILED_MIN_ENVS environments up and the wave-per-environment kernel below that.  Same arithmetic classes as the other split-f16 kernels
+// TILED_MIN_ENVS environments up and the wave-per-environment kernel below that (mn_iqn_set_tau_mode(ctx, 3) forces it: tests).
+// Where the time goes (scripts/act_tiled_ablation.sh, profiles/r04_act_tiled_ablation.txt, 65 536 rows incl. 12 us of preparation launches):
+// 192 us as built; 162 without the layer-2 / -3 epilogues; 179 without the per-tau barrier and T prefetch; 172 without the layer-3 MFMAs;
+// 127 without the layer-2 MFMAs; 110 without any MFMA; 68 without MFMAs, epilogues and barrier -- i.e. the matrix instructions add only
+// ~80 us on top of ~110 us of everything else (LDS reads of T: 14.7 MB per CU and launch, epilogues, barriers, encoders).  Same arithmetic classes as the other split-f16 kernels
 // (three f16 products per float32 product, power-of-two scaling from guaranteed bounds); one more float32 rounding in T = W2 h1.
 
 #ifndef TILED_ABL
@@ -24,7 +28,10 @@
 
 namespace sp {
 
-constexpr int TILED_MIN_ENVS = 16384;
+// A workgroup takes 256 environments through all 32 taus in ~170 us whatever the batch: the form wins once every CU has a workgroup
+// (65 536 rows on a 256-CU chip: 186 vs 198 us per launch incl. the preparation launches) and loses below (the wavefront-per-row kernel
+// scales down with the batch: 16 384 rows in ~55 us).
+constexpr int TILED_MIN_ENVS = 65536;
 constexpr int T_U4_PER_TAU = 4 * KB2 * 2 * 64;               // 3 584 16-byte units = 57 344 B: [mt][kb][piece][lane]
 constexpr int T_WORDS = K_TAUS * T_U4_PER_TAU * 4;           // 458 752 32-bit words
 // auxiliary float block behind T (indices in floats): the encoders as one block-diagonal matrix in dense A-fragment order, their biases

@@ -75,7 +75,8 @@ class ActContext:
     def set_tau_mode(self, mode):
         """0 = every observation row its own 32 taus (default, the reference's per-call draw); 1 = one set of 32 taus per launch:
         layer 1 of the network becomes a constant of the launch (C-ABI mn_iqn_set_tau_mode; split-f16 kernel only); 2 = the same
-        with the wavefront-per-row kernel for every batch size (1 switches to the environment-tiled kernel for large batches)."""
+        with the wavefront-per-row kernel for every batch size (1 switches to the environment-tiled kernel for large batches); 3 = the
+        environment-tiled kernel for every batch size."""
         if int(mode) == self.tau_mode:
             return
         rc = _capi.lib().mn_iqn_set_tau_mode(self.h, int(mode))
@@ -184,9 +185,9 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
     dev = states.device
     ctx = act_context(net)
     shared = bool(shared_taus) and not torch.is_tensor(cvar) and ctx.variant == 2
-    # mode 1: the library picks the kernel form (from 16 384 rows up the MFMA columns are environments, iqn_act_tiled.h; below, one
-    # wavefront per row); shared_taus="wave" pins the wavefront-per-row form (mode 2: A / B measurements, tests)
-    ctx.set_tau_mode((2 if shared_taus == "wave" else 1) if shared else 0)
+    # mode 1: the library picks the kernel form (from 65 536 rows up the MFMA columns are environments, iqn_act_tiled.h; below, one
+    # wavefront per row); shared_taus="wave" / "tiled" pin a form (modes 2 / 3: A / B measurements, tests)
+    ctx.set_tau_mode({"wave": 2, "tiled": 3}.get(shared_taus, 1) if shared else 0)
     actions = torch.empty(n, dtype=torch.int32, device=dev)
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
     quant = torch.empty(n, net.K, net.action_size, dtype=torch.float32, device=dev) if want_quantiles else None

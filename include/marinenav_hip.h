@@ -280,10 +280,10 @@ int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
  *      preparation launch computes once (exact float32): 216 instead of 372 matrix instructions per row, no per-row cosines.
  *      mn_iqn_act then reads taus [32]; mn_iqn_act_rng writes draws[0 .. 32) = the taus, draws[32 .. 32 + n) = exploration uniforms.
  *      Only with variant 2, without per-row cvar (cvar_row_dev == NULL) and without a selected image slot: else MN_ERR_INVALID.
- *      Two kernel forms serve it: up to 16 383 rows (and for quantile output) one wavefront per row with the taus in the MFMA columns;
- *      from 16 384 rows the ENVIRONMENTS are the columns -- T[tau] = W2 diag(h1[tau]) is built once per launch, a wavefront splits the
+ *      Two kernel forms serve it: up to 65 535 rows (and for quantile output) one wavefront per row with the taus in the MFMA columns;
+ *      from 65 536 rows (every CU of the chip gets a 256-row workgroup) the ENVIRONMENTS are the columns -- T[tau] = W2 diag(h1[tau]) is built once per launch, a wavefront splits the
  *      features of 32 rows once and streams T through LDS: ~260 instead of ~730 vector instructions per row.
- *   2: as 1, but always the wavefront-per-row form (A / B measurements).
+ *   2: as 1, but always the wavefront-per-row form; 3: as 1, but always the environment-tiled form (A / B measurements, tests).
  * A row's result for GIVEN taus is the same function in both modes up to float32 rounding (tests). */
 int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
 /* Measurement aid (bench.py: `gpu_clock_probe`): runs a pure stream of the act kernel's matrix instruction (v_mfma_f32_16x16x32_f16, two

@@ -19,6 +19,6 @@ def run(shared, calls=40):
     ms, k = ctx.profile_end()
     return ms * 1e3
 for r in range(rounds):
-    a = run(False); b = run("wave"); c = run(True)
+    a = run(False); b = run("wave"); c = run("tiled")
     print(f"round {r}: per-env taus {a:7.1f} us   shared taus, wavefront per env {b:7.1f} us ({b / a:.3f})   shared taus, env-tiled {c:7.1f} us ({c / a:.3f})"
           f"   ({n} envs, prep launches included)", flush=True)

@@ -235,7 +235,7 @@ def test_argument_checks(torch):
     net = _net(torch, "seeded")
     ctx = act_context(net)
     lib = _capi.lib()
-    assert lib.mn_iqn_set_tau_mode(ctx.h, 3) != 0 and lib.mn_iqn_set_tau_mode(None, 1) != 0
+    assert lib.mn_iqn_set_tau_mode(ctx.h, 4) != 0 and lib.mn_iqn_set_tau_mode(None, 1) != 0
     obs = torch.zeros(8, 26, device=DEV); row = torch.rand(32, device=DEV); q = torch.empty(8, 9, device=DEV)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     try:
@@ -254,7 +254,7 @@ def test_argument_checks(torch):
         ctx.set_tau_mode(0)
 
 
-# ---- the environment-tiled form (csrc/iqn_act_tiled.h): mode 1 from 16 384 rows up ----------------------------------------------------
+# ---- the environment-tiled form (csrc/iqn_act_tiled.h): what mode 1 runs from 65 536 rows up; pinned here with shared_taus="tiled" (mode 3) ----------------------------------------------------
 def _f64_ref(torch, net, obs, row):
     n = obs.shape[0]
     bc = row.view(1, 32).expand(n, 32).contiguous()
@@ -275,8 +275,8 @@ def test_env_tiled_kernel_is_float32_class_and_agrees_with_the_wavefront_per_row
     finally:
         ctx.set_variant(ctx.DEFAULT_VARIANT)
     aw, qw = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="wave")
-    at, qt = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
-    assert ctx.tau_mode == 1 and not torch.equal(qw, qt)      # (another kernel ran: another rounding)
+    at, qt = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="tiled")
+    assert ctx.tau_mode == 3 and not torch.equal(qw, qt)      # (another kernel ran: another rounding)
 
     def err(q):
         d = (q.double() - ref).abs()
@@ -287,7 +287,7 @@ def test_env_tiled_kernel_is_float32_class_and_agrees_with_the_wavefront_per_row
     clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * float(ref.abs().max())
     assert torch.equal(at.long()[clear], ref.argmax(dim=1)[clear]) and bool((at.long() == qt.argmax(1)).all())
     # rows do not depend on the batch they are in
-    _, q_more = fused_act(net, torch.cat([obs, obs[:5000]]).contiguous(), 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    _, q_more = fused_act(net, torch.cat([obs, obs[:5000]]).contiguous(), 0.0, 1.0, taus=row, want_qvals=True, shared_taus="tiled")
     assert torch.equal(q_more[:obs.shape[0]], qt) and torch.equal(q_more[obs.shape[0]:], qt[:5000])
 
 
@@ -315,7 +315,7 @@ def test_env_tiled_kernel_range_scaling_cases(torch, case):
             net.cos_embedding.weight.mul_(1e-4); net.cos_embedding.bias.mul_(1e-4); obs *= 100.0
     ref, bc = _f64_ref(torch, net, obs, row)
     _, q0 = fused_act(net, obs, 0.0, 1.0, taus=bc, want_qvals=True)
-    _, q1 = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    _, q1 = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="tiled")
     assert bool(torch.isfinite(q1).all())
     row_scale = ref.abs().max(dim=1).values.clamp_min(1e-30)
     e0 = float(((q0.double() - ref).abs().max(dim=1).values / row_scale).max())
@@ -329,16 +329,30 @@ def test_env_tiled_kernel_library_draws_and_exploration(torch):
     obs, _ = _inputs(torch, 30000, 5.0)
     n = obs.shape[0]
     rng = ActRng(77, DEV)
-    a, q = fused_act(net, obs, 0.0, 0.5, rng=rng, want_qvals=True, shared_taus=True)
+    a, q = fused_act(net, obs, 0.0, 0.5, rng=rng, want_qvals=True, shared_taus="tiled")
     assert int(rng.state[1]) == 1
     row = rng.draws(n, 32)[:32].clone()
-    _, q_inj = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    _, q_inj = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="tiled")
     assert torch.equal(q, q_inj) and bool((a.long() == q.argmax(1)).all())
-    a_e = fused_act(net, obs, 1.0, 1.0, rng=rng, shared_taus=True)
+    a_e = fused_act(net, obs, 1.0, 1.0, rng=rng, shared_taus="tiled")
     cnt = torch.bincount(a_e.long(), minlength=9).float() / n
     assert bool(((a_e >= 0) & (a_e < 9)).all()) and float((cnt - 1 / 9).abs().max()) < 0.01
-    a_g = fused_act(net, obs, 0.3, 1.0, rng=rng, shared_taus=True)
+    a_g = fused_act(net, obs, 0.3, 1.0, rng=rng, shared_taus="tiled")
     u = rng.draws(n, 32)[32:32 + n]
-    a_greedy = fused_act(net, obs, 0.0, 1.0, taus=rng.draws(n, 32)[:32].clone(), shared_taus=True)
+    a_greedy = fused_act(net, obs, 0.0, 1.0, taus=rng.draws(n, 32)[:32].clone(), shared_taus="tiled")
     keep = u > 0.3
     assert torch.equal(a_g[keep], a_greedy[keep]) and 0.67 < float(keep.float().mean()) < 0.73
+
+
+def test_mode_1_switches_to_the_env_tiled_form_at_65536_rows(torch):
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+    net = _net(torch, "pretrained")
+    obs, row = _inputs(torch, 65536, 5.0)
+    _, q_auto = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    _, q_tiled = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="tiled")
+    _, q_wave = fused_act(net, obs, 0.0, 1.0, taus=row, want_qvals=True, shared_taus="wave")
+    assert torch.equal(q_auto, q_tiled) and not torch.equal(q_auto, q_wave)
+    _, q_small = fused_act(net, obs[:30000].contiguous(), 0.0, 1.0, taus=row, want_qvals=True, shared_taus=True)
+    assert torch.equal(q_small, q_wave[:30000])
+    scale = float(q_wave.abs().max())
+    assert float((q_tiled - q_wave).abs().max()) / scale < 3e-6
