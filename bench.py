@@ -196,9 +196,9 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
                             "act_kernel": "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)", "act_launch_ms": act_ms,
                             "roofline_frac_f32_mfma": alg_tf / F32_MFMA_PEAK_TFLOPS if alg_tf else None}
     # (a') launch-shared taus: one set of 32 quantile fractions per act launch instead of per env (opt-in, IQNAgent.shared_taus)
-    def shared_leg(fn, steps, warm):
+    def shared_leg(fn, steps, warm, form=True):
         nonlocal obs
-        agent.shared_taus = True
+        agent.shared_taus = form
         try:
             dt, obs = _timed(device, fn, steps, warm, obs, lambda: ctx.profile_begin(min(steps, 50)))
             ms, _ = ctx.profile_end()
@@ -208,8 +208,13 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
     steps = max(20, args.steps // 2)
     dt, act_ms = shared_leg(loop_step, steps, 10)
     rate = n / (act_ms * 1e-3) / 1e12 if act_ms > 0 else None
+    dt_w, act_ms_wave = shared_leg(loop_step, 30, 5, form="wave")
+    tiled = n >= 65536
     out["act_shared_taus"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-                              "act_kernel": "iqn_qvals_split_kernel<false, SHARED=true> (layer 1 = a [32 x 208] constant of the launch; 216 v_mfma_f32_16x16x32_f16 per env)",
+                              "act_kernel": ("iqn_qvals_tiled_kernel (launch-shared taus, the MFMA columns are environments: T = W2 diag(h1) built once per launch, features split "
+                                             "once per env; 216 v_mfma_f32_16x16x32_f16 + ~260 vector instructions per env)" if tiled else
+                                             "iqn_qvals_split_kernel<false, SHARED=true> (layer 1 = a [32 x 208] constant of the launch; 216 v_mfma_f32_16x16x32_f16 per env)"),
+                              "launch_ms_wavefront_per_env_form": act_ms_wave, "value_wavefront_per_env_form": n * 30 / dt_w,
                               "launch_ms": act_ms, "tau_draw": "32 taus ~ U[0,1) x cvar per LAUNCH, shared by its envs (default: per env)",
                               "frac_algorithmic_remaining_flops": ACT_SHARED_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
                               "frac_algorithmic_full_network_flops": ACT_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
