@@ -43,7 +43,10 @@ ACT_SPLIT_MFMA_FLOP_PER_ENV_STEP = 372 * 16384   # split-f16 act kernel: 372 v_m
 # 2 * FETCH_SIZE + WRITE_SIZE (calibration: profiles/r01_pmc_calibration.txt).  step = plain mn_step (r01), step_append = the
 # fused step + replay append kernel of the training loop, rollout = mn_rollout at 4 096 envs x 100 steps per launch
 # (profiles/r02_full_loop_kernel_stats.txt, profiles/r02_configs1_rollout.txt)
-PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 79.8e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 69.2e6}
+# r04 (profiles/r04_full_loop_kernel_stats.txt): the float64 step + append kernel without the float64 observation copies (mn_enable_obs64 off in the loop):
+# 2 x 20.31 + 25.36 = 66.0 MB per 65 536-env launch (r03, copies always written: 79.8 MB); the reset kernel 2 x 0.77 + 1.64 = 3.2 MB per launch (~2 000 episodes end per step)
+PMC_TRAFFIC_BYTES = {"step": 30.0e6, "step_append": 51.5e6, "step_append_f64": 66.0e6, "act": 24.8e6, "act_split": 24.2e6, "rollout_4096x100": 69.2e6, "reset_f64": 3.2e6}
+RESET_KERNEL_US_FROM_PROFILE = 24.7      # mn_reset_kernel<double, true>, mean of the 120 in-loop launches of the same profile (28.9 incl. the initial all-env reset of 539 us)
 # mn_step_append also moves the transition into the replay ring: + 104 B (obs_t row read) + 2 x 104 + 8 + 4 + 4 B written
 APPEND_BYTES_PER_ENV_STEP = 104 + 2 * 104 + 8 + 4 + 4
 
@@ -329,6 +332,9 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
         # the one-shot exchange over IPC-mapped mailboxes instead of the RCCL all-reduce (iqn/mailbox.py; one rank: its own mailbox only)
         agent.exchange = "mailbox"
         try:
+            agent.exchange_fused_adam = False
+            sl["mailbox_ws1_exchange_then_adam_two_launches"] = learner_rate()
+            agent.exchange_fused_adam = True
             sl["mailbox_ws1_exchange"] = learner_rate()
             sl["mailbox_overhead_us_per_step"] = 1e6 * (1.0 / sl["mailbox_ws1_exchange"] - 1.0 / sl["no_group"])
             sl["mailbox_ws1_exchange_graphed_16_step_events"] = graphed_rate()
@@ -393,6 +399,7 @@ def main():
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
                                                                "timed by the default run as also.act_shared_taus)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the two ~50 ms MFMA clock probes around the timed region (cleaner rocprofv3 tables)")
     ap.add_argument("--act-grid", type=int, default=1024, help="with --halves > 1: workgroups of an act launch (mn_iqn_set_grid)")
     args = ap.parse_args()
     if args.precision is None:
@@ -518,7 +525,7 @@ def main():
         act_context(agent.qnetwork_local).set_variant(args.act_variant)
     obs = run_steps(args.warmup, obs)
     g0 = agent.grad_steps if agent else 0
-    clock_before = gpu_clock_probe(device) if rank == 0 else None      # ~50 ms of matrix load, outside the timed region
+    clock_before = gpu_clock_probe(device) if (rank == 0 and not args.no_clock_probe) else None      # ~50 ms of matrix load, outside the timed region
     fence()
     # HIP-event pairs are recorded around the first n_prof act / step launches of the timed region; not around all of
     # them, because the four event records per vector step cost ~18 us of stream time (measured: 1.079 ms/step with
@@ -538,7 +545,7 @@ def main():
     if fused:
         act_ms, act_launches = act_context(agent.qnetwork_local).profile_end()
     grad_steps = (agent.grad_steps - g0) if agent else 0
-    clock_after = gpu_clock_probe(device) if rank == 0 else None
+    clock_after = gpu_clock_probe(device) if (rank == 0 and not args.no_clock_probe) else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -661,7 +668,12 @@ def main():
                 "traffic_from_profile": {"bytes_per_launch": (PMC_TRAFFIC_BYTES["rollout_4096x100"] if (roll, n) == (100, 4096) else None) if roll else
                                          (PMC_TRAFFIC_BYTES["step_append_f64"] if (fused_append and (n // H, args.cores, args.obstacles, args.precision) == (65536, 8, 10, "f64")) else
                                           (PMC_TRAFFIC_BYTES["step_append" if fused_append else "step"] if (n // H, args.cores, args.obstacles, args.precision) == (65536, 8, 10, "mixed") else None)),
-                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch): float64 kernels profiles/r03_full_loop_kernel_stats.txt, mixed-precision kernels profiles/r02_full_loop_kernel_stats_split_act.txt, mn_rollout profiles/r03_rollout_phase_timing.txt"},
+                                         "source": "rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE per launch): float64 kernels profiles/r04_full_loop_kernel_stats.txt, mixed-precision kernels profiles/r02_full_loop_kernel_stats_split_act.txt, mn_rollout profiles/r03_rollout_phase_timing.txt"},
+                # the other env kernel of a vector step: the reset of the envs that finished (one wavefront per env, outside the figures above)
+                "reset_kernel": None if (roll or agent is None or args.precision != "f64" or n // H != 65536) else
+                                {"kernel": "mn_reset_kernel<double, true>", "launch_us_from_profile": RESET_KERNEL_US_FROM_PROFILE,
+                                 "traffic_bytes_per_launch_from_profile": PMC_TRAFFIC_BYTES["reset_f64"], "episodes_ending_per_vector_step": "~2 000 of 65 536",
+                                 "source": "profiles/r04_full_loop_kernel_stats.txt"},
                 "algorithmic_bytes_per_env_step": bytes_per,
                 "algorithmic_bytes_step_only": bytes_step,
                 "frac_step_bytes_only": (bytes_step * per_launch / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_kernel_ms > 0 else None,
@@ -683,7 +695,8 @@ def main():
                 peak = F16_MFMA_PEAK_TFLOPS
                 if args.shared_taus and args.act_variant == 2:
                     tf = ACT_SHARED_MFMA_FLOP_PER_ENV_STEP * n_act / (act_ms * 1e-3) / 1e12
-                    kern = "iqn_qvals_split_kernel<false, SHARED=true> (launch-shared taus: layer 1 is a constant of the launch, 216 MFMAs per env)"
+                    kern = ("iqn_qvals_tiled_kernel (launch-shared taus, environments in the MFMA columns: T = W2 diag(h1) built once per launch, 216 MFMAs per env)" if n_act >= 65536 else
+                            "iqn_qvals_split_kernel<false, SHARED=true> (launch-shared taus: layer 1 is a constant of the launch, 216 MFMAs per env)")
             else:
                 tf = alg_tf
                 kern = "iqn_qvals32_kernel (v_mfma_f32_32x32x2_f32)" if args.act_variant == 1 else "iqn_qvals_kernel<false> (v_mfma_f32_16x16x4_f32)"

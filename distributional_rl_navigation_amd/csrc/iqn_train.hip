@@ -1109,6 +1109,115 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     }
 }
 
+// The one-shot exchange AND the optimizer step in one launch (mn_iqn_train_exchange_adam): a shared learner's gradient step then has the
+// same three launches as an independent learner's.  Block b (of iqn_adam's 140) first gathers ITS 256 parameters' gradients from every
+// rank's mailbox -- threads 0..63, one float4 column each, exactly iqn_grad_gather's work for columns [64 b, 64 b + 64) -- and forms the two
+// norm partials those columns make up (iqn_grad_sumsq's blocks 2 b and 2 b + 1: same grouping, same order), publishes them as self-tagged
+// granules in this rank's private partial array, and then runs iqn_adam's own body, reading all 280 partials by polling their tags: the
+// partials ARE the grid-wide dependency, no barrier and no second launch.  Every sum is formed in the order the two-launch path forms it:
+// bit-identical to mn_iqn_train_exchange + mn_iqn_train_adam.  (All 140 blocks of 256 threads are resident together on any device this
+// library targets; the polls are bounded like iqn_grad_gather's.)
+__global__ __launch_bounds__(256) void iqn_adam_xchg(XchgPeers peers, int world, gu64 *__restrict__ xsq, const float *__restrict__ ws, int n_part,
+                                                     float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                                     int32_t *__restrict__ step, unsigned *__restrict__ ticket, double lr, double b1, double b2,
+                                                     double eps_d, double max_norm_d, float grad_scale, unsigned *__restrict__ status) {
+    __shared__ float red[4];
+    __shared__ float s_bc[2];
+    __shared__ float sq[64];
+    __shared__ float gsh[256];
+    const int tid = threadIdx.x, p = blockIdx.x * 256 + tid;
+    if (ticket[6] != WS_MAGIC) return;
+    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)));
+    float mp = 0.f, vp = 0.f, pp = 0.f;
+    if (p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
+    bool late = false;
+    if (tid < 64) {
+        const int q = (blockIdx.x * 64 + tid) * 4;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q < P_PAD) {
+            for (int r = 0; r < world; ++r) {
+                const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
+                uint64_t x[4];
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        ok = ok && (uint32_t)(x[k] >> 32) == tag;
+                    }
+                    if (ok) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (q + k >= P_TOTAL) e[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gsh[4 * tid + k] = e[k];
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = e[k] * grad_scale;
+        sq[tid] = ((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]) + s[3] * s[3];
+    }
+    __syncthreads();
+    if (tid == 0 || tid == 32) {
+        float t = 0.f;
+        for (int k = 0; k < RED_COLS; ++k) t += sq[tid + k];
+        __hip_atomic_store(xsq + 2 * blockIdx.x + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static_assert(RED_COLS == 32 && N_RED == 2 * N_ADAM, "an Adam block's 256 parameters are two norm partials of 32 float4 columns");
+    float part = 0.f;
+    for (int c = tid; c < N_RED; c += 256) {
+        uint64_t x;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            x = __hip_atomic_load(xsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(x >> 32) == tag) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        part += __uint_as_float((uint32_t)x);
+    }
+    if (late) atomicAdd(status, 1u);
+    int t_step = 0;
+    if (tid == 255) {
+        t_step = *step + 1;
+        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const float sumsq = (red[0] + red[1]) + (red[2] + red[3]);
+    const float norm = sqrtf(sumsq);
+    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
+    const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
+    if (p < P_TOTAL) {
+        float gq = gsh[tid] * grad_scale;
+        gq *= coef;
+        grad[p] = gq;
+        const float mm = mp + (gq - mp) * w1;
+        const float vv = vp * b2f + w2 * (gq * gq);
+        m[p] = mm;
+        v[p] = vv;
+        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+    if (tid == 255) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *step = t_step;
+        }
+    }
+}
+
 // ReplayBuffer.sample (replay_buffer.py:42-47: random.sample = uniform WITHOUT replacement) plus the 2 x batch x 8
 // tau draws of the step (model.py:149), as a stand-alone launch: the batch iqn_train_fwdbwd draws for itself when it is given
 // the generator state instead of index / tau buffers.  Counter-based: state = {seed, call counter} on the device, advanced here.
@@ -1248,6 +1357,7 @@ struct mn_xchg {
     const gu64 *peer[XCHG_MAX_RANKS] = {};     // own + IPC-mapped peers, by rank
     bool opened[XCHG_MAX_RANKS] = {};
     unsigned *status = nullptr;                // device word: number of granule groups that timed out
+    gu64 *xsq = nullptr;                       // [N_RED] self-tagged norm partials of the fused exchange + Adam launch (private to this rank)
 };
 
 extern "C" int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out) {
@@ -1255,14 +1365,16 @@ extern "C" int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out) {
     mn_xchg *x = new mn_xchg();
     x->rank = rank; x->world = world;
     const size_t bytes = 2 * (size_t)P_PAD * sizeof(uint64_t);
-    void *p = nullptr;
+    void *p = nullptr, *sqp = nullptr;
     // plain device memory: granules are written and polled with system-scope (cache-bypassing) accesses, and hipIpcGetMemHandle exports it
     if (hipGetDevice(&x->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&x->status), sizeof(unsigned)) != hipSuccess || hipMemset(x->status, 0, sizeof(unsigned)) != hipSuccess ||
+        hipMalloc(&sqp, N_RED * sizeof(uint64_t)) != hipSuccess || hipMemset(sqp, 0, N_RED * sizeof(uint64_t)) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(p); (void)hipFree(x->status); delete x;
+        (void)hipFree(p); (void)hipFree(x->status); (void)hipFree(sqp); delete x;
         return MN_ERR_ALLOC;
     }
+    x->xsq = (gu64 *)sqp;
     x->own = (gu64 *)p;
     x->peer[rank] = x->own;
     *out = x;
@@ -1311,6 +1423,22 @@ extern "C" int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, 
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 
+extern "C" int mn_iqn_train_exchange_adam(mn_xchg *x, float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev,
+                                          float *workspace, int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm,
+                                          float grad_scale, void *stream) {
+    if (!x || !params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !workspace || batch <= 0 || batch % BE || !(grad_scale > 0.f)) return MN_ERR_INVALID;
+    XchgPeers peers;
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
+        peers.mb[r] = r < x->world ? x->peer[r] : nullptr;
+        if (r < x->world && !peers.mb[r]) return MN_ERR_INVALID;
+    }
+    const int n_part = batch / BE;
+    unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(n_part) + 2);
+    hipLaunchKernelGGL(iqn_adam_xchg, dim3(N_ADAM), dim3(256), 0, (hipStream_t)stream, peers, x->world, x->xsq, (const float *)workspace, n_part, params, grad,
+                       exp_avg, exp_avg_sq, step_dev, ticket, lr, beta1, beta2, eps, max_norm, grad_scale, x->status);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
 extern "C" int mn_xchg_status(mn_xchg *x, int32_t *timeouts) {
     if (!x || !timeouts) return MN_ERR_INVALID;
     unsigned v = 0;
@@ -1325,6 +1453,7 @@ extern "C" int mn_xchg_destroy(mn_xchg *x) {
         if (x->opened[r]) (void)hipIpcCloseMemHandle((void *)x->peer[r]);
     (void)hipFree((void *)x->own);
     (void)hipFree(x->status);
+    (void)hipFree((void *)x->xsq);
     delete x;
     return MN_OK;
 }

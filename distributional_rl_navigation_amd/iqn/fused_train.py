@@ -250,6 +250,10 @@ class FusedTrainer:
             if mb is None:
                 from .mailbox import MailboxExchange
                 mb = self._mailbox = MailboxExchange(self.device)
+            if getattr(ag, "exchange_fused_adam", True):      # one launch: gather + norm + clip + Adam (bit-identical to the two below)
+                mb.exchange_adam(self, B, 1.0 / mb.world, ag.LR)
+                weights_changed(ag.qnetwork_local)
+                return self.loss[0]
             scale, rewritten = 1.0 / mb.world, 2
             mb.exchange(self.grad, self._workspace(B), B, scale)
         elif ag.distributed:

@@ -69,6 +69,16 @@ class MailboxExchange:
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_exchange failed ({rc})")
 
+    def exchange_adam(self, trainer, batch, grad_scale, lr):
+        """`exchange` and the clip + Adam update as ONE launch (C-ABI mn_iqn_train_exchange_adam), on `trainer`'s flat buffers."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        rc = _capi.lib().mn_iqn_train_exchange_adam(self.h, p(trainer.local), p(trainer.grad), p(trainer.exp_avg), p(trainer.exp_avg_sq), p(trainer.step_dev),
+                                                    p(trainer._workspace(batch)), int(batch), C.c_double(lr), C.c_double(0.9), C.c_double(0.999),
+                                                    C.c_double(1e-8), C.c_double(0.5), C.c_float(grad_scale), stream)
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_iqn_train_exchange_adam failed ({rc})")
+
     def timeouts(self):
         n = C.c_int32()
         torch.cuda.synchronize(self.device)

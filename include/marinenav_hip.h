@@ -389,7 +389,8 @@ int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
  * through IPC-mapped pointers, i.e. directly over xGMI -- polling each granule until it carries the current step's tag, and leaves
  *     grad = sum over ranks, in rank order (bit-identical on every rank; equal to an all-reduce(SUM) for two ranks)
  * plus the norm partials of grad_scale * grad, so that the step continues with mn_iqn_train_adam(..., grad_scale, grad_rewritten = 2).
- * Four launches per step instead of five (no collective launch, no separate norm pass), no host synchronisation, graph-capturable.
+ * Four launches per step instead of five (no collective launch, no separate norm pass) -- three with mn_iqn_train_exchange_adam --, no host
+ * synchronisation, graph-capturable.
  *   mn_xchg_create(rank, world <= 8)    this rank's context + mailbox on the current device
  *   mn_xchg_export(x, handle[64])       hipIpcMemHandle_t of the mailbox, to be sent to every peer (e.g. torch.distributed.all_gather_object)
  *   mn_xchg_import(x, peer, handle[64]) maps a peer's mailbox (once per peer)
@@ -417,6 +418,11 @@ int mn_xchg_export(mn_xchg *x, void *handle_out);
 int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle);
 int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void *stream);
 int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t batch, float grad_scale, void *stream);
+/* mn_iqn_train_exchange + mn_iqn_train_adam(..., grad_rewritten = 2) as ONE launch: every Adam block gathers its own parameters' gradients
+ * from the mailboxes and the norm partials travel between the blocks as self-tagged granules.  Bit-identical to the two calls; a shared
+ * learner's gradient step is then three launches, like an independent learner's. */
+int mn_iqn_train_exchange_adam(mn_xchg *x, float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
+                               int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, float grad_scale, void *stream);
 int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
 int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
