@@ -1013,6 +1013,40 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restri
 // gather of step k + 1, which needed every peer's step k + 1, which every peer published after ITS gather of step k.
 constexpr int XCHG_MAX_RANKS = 8;
 struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS]; };
+// e[0..3] = sum over ranks, IN RANK ORDER, of granules q .. q + 3 of the step tagged `tag`.  All ranks' granules are requested together
+// (independent system-scope loads in flight over the fabric at once, not one round trip per peer); a pass that finds a stale tag is repeated
+// as a whole.  Returns true if the bound (~2 s of the 100 MHz counter) was hit.
+__device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, uint32_t tag, int q, float (&e)[4]) {
+    uint64_t x[XCHG_MAX_RANKS][4];
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    bool late = false;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+            if (r < world) {
+                const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[r][k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+            if (r < world)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ok = ok && (uint32_t)(x[r][k] >> 32) == tag;
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+        if (r < world)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[r][k]);
+    return late;
+}
 __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int world, const float *__restrict__ ws, int n_part,
                                                             float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale,
                                                             unsigned *__restrict__ status) {
@@ -1022,24 +1056,7 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (q < P_PAD) {
         bool late = false;
-        for (int r = 0; r < world; ++r) {
-            const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
-            uint64_t x[4];
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    x[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ok = ok && (uint32_t)(x[k] >> 32) == tag;
-                }
-                if (ok) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
-        }
+        late = xchg_gather4(peers, world, tag, q, e);
         if (late) atomicAdd(status, 1u);
         if (q + 3 < P_TOTAL) *reinterpret_cast<float4 *>(grad + q) = make_float4(e[0], e[1], e[2], e[3]);
         else
@@ -1135,24 +1152,7 @@ __global__ __launch_bounds__(256) void iqn_adam_xchg(XchgPeers peers, int world,
         const int q = (blockIdx.x * 64 + tid) * 4;
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (q < P_PAD) {
-            for (int r = 0; r < world; ++r) {
-                const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
-                uint64_t x[4];
-                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        ok = ok && (uint32_t)(x[k] >> 32) == tag;
-                    }
-                    if (ok) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
-            }
+            late = xchg_gather4(peers, world, tag, q, e);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (q + k >= P_TOTAL) e[k] = 0.f;
