@@ -1056,7 +1056,24 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (q < P_PAD) {
         bool late = false;
-        late = xchg_gather4(peers, world, tag, q, e);
+        for (int r = 0; r < world; ++r) {      // (rank after rank: this kernel is the measurement / fallback form; the fused launch below requests all ranks at once)
+            const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
+            uint64_t x[4];
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = ok && (uint32_t)(x[k] >> 32) == tag;
+                }
+                if (ok) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
+        }
         if (late) atomicAdd(status, 1u);
         if (q + 3 < P_TOTAL) *reinterpret_cast<float4 *>(grad + q) = make_float4(e[0], e[1], e[2], e[3]);
         else
