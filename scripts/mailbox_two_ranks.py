@@ -1,3 +1,6 @@
+"""Two ranks (two processes on ONE GPU) x 12 gradient steps of a shared learner through each gradient transport -- the all-reduce path (bucket over gloo),
+the mailbox exchange fused with Adam ("mailbox"), the mailbox exchange as its own launch ("mailbox2") -- printing whether the ranks stayed bit-identical, the
+granule timeouts and the checksum of the parameters (equal across the transports).  Debugging aid for tests/test_multigpu_paths_gpu.py."""
 import os, sys, subprocess, socket, tempfile
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
