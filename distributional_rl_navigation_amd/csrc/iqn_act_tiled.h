@@ -210,7 +210,10 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc2[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int NS = 4 * KB2, AHEAD = 2;
+#ifndef TILED_AHEAD
+#define TILED_AHEAD 2
+#endif
+        constexpr int NS = 4 * KB2, AHEAD = TILED_AHEAD;
         u32x4 ah[AHEAD + 1], al[AHEAD + 1], pf[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int s0 = 0; s0 < AHEAD; ++s0) {
