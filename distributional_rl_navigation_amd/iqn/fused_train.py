@@ -167,14 +167,28 @@ class FusedTrainer:
         if ring_version is not None:
             key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr() if self._ws is not None else 0)
             flags = 2 | (1 if key == self._staged_key else 0)
-        rc = L.mn_iqn_train_grad_sampled(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size),
-                                         _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target),
-                                         _p(self._workspace(batch)), _p(self.grad), _p(self.loss), batch, ag.N,
-                                         C.c_float(ag.GAMMA ** ag.n_step), flags, stream)
+        if self._two_launches():      # forward / backward, then reduction + clip + Adam in ONE launch (mn_iqn_train_step): bit-identical
+            rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size), _p(self.rng_state), None, None, None,
+                                     _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target), _p(self._workspace(batch)), _p(self.grad),
+                                     _p(self.loss), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev), batch, ag.N, C.c_float(ag.GAMMA ** ag.n_step), flags,
+                                     C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5), stream)
+        else:
+            rc = L.mn_iqn_train_grad_sampled(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size),
+                                             _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target),
+                                             _p(self._workspace(batch)), _p(self.grad), _p(self.loss), batch, ag.N,
+                                             C.c_float(ag.GAMMA ** ag.n_step), flags, stream)
         self._staged_key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr()) if ring_version is not None else None
         if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_train_grad_sampled failed ({rc}): need batch <= 1024 and ring_size >= batch")
+            raise _capi.MarineNavHipError(f"mn_iqn_train_grad_sampled / mn_iqn_train_step failed ({rc}): need batch <= 1024 and ring_size >= batch")
+        if self._two_launches():
+            weights_changed(ag.qnetwork_local)
+            return self.loss[0]
         return self._finish_step(batch)
+
+    def _two_launches(self):
+        """A single learner's step is two launches (mn_iqn_train_step); a shared learner puts its all-reduce / exchange between the gradient and
+        the Adam launch and keeps three.  `agent.two_launch_step = False` selects the three-launch path (A / B measurements, tests)."""
+        return not self.agent.distributed and getattr(self.agent, "two_launch_step", True)
 
     def graphed_steps(self, ring, ring_size, batch, n_steps):
         """`n_steps` x step_sampled as ONE hipGraph launch (captured on first use, re-captured when the ring's tensors / size, the
@@ -230,6 +244,15 @@ class FusedTrainer:
         tl = tl.to(self.device, torch.float32).contiguous().view(B, ag.N)
         L = _capi.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self._two_launches():
+            rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), 0, None, _p(idx), _p(tt), _p(tl), None, None,
+                                     _p(self.local), _p(self.target), _p(self._workspace(B)), _p(self.grad), _p(self.loss), _p(self.exp_avg),
+                                     _p(self.exp_avg_sq), _p(self.step_dev), B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), 0,
+                                     C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5), stream)
+            if rc:
+                raise _capi.MarineNavHipError(f"mn_iqn_train_step failed ({rc})")
+            weights_changed(ag.qnetwork_local)
+            return self.loss[0]
         rc = L.mn_iqn_train_grad(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), _p(idx), _p(tt), _p(tl),
                                  _p(self.local), _p(self.target), _p(self._workspace(B)), _p(self.grad), _p(self.loss),
                                  B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), stream)

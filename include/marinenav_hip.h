@@ -379,6 +379,17 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * them for grad_scale * grad; with grad_rewritten = 1 or (grad_rewritten = 0 and grad_scale != 1) the
  * norm is recomputed from grad.
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
+/* The whole gradient step of a single learner -- IQNAgent.train (agent.py:269-304) incl. clip_grad_norm_ and optimizer.step() -- as TWO
+ * launches: forward / backward, then a launch in which every block reduces the partial gradients of its own 256 parameters, exchanges the norm
+ * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4).  rng_state_dev != NULL: the batch is drawn in the
+ * launch (arguments as mn_iqn_train_grad_sampled; idx_dev / taus_*_dev ignored); NULL: the given batch (as mn_iqn_train_grad).  params_local is
+ * updated in place, grad_out receives the clipped gradient.  Bit-identical to mn_iqn_train_grad* + mn_iqn_train_adam(grad_scale = 1): those stay
+ * for callers that put something between the two (the shared learner's all-reduce / exchange). */
+int mn_iqn_train_step(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
+                      const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev, const float *taus_target_dev,
+                      const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local, const float *params_target,
+                      float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, int32_t batch,
+                      int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
 int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
 

@@ -293,7 +293,7 @@ def test_iqn_c_abi_argument_checks(torch):
     L = _capi.lib()
     # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
     # staging tag / magic word + the staged next batch (256 slots of 72 floats)
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 256 * 72
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + 256 * 72      # (+ the 280 tagged norm partials of the two-launch step)
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -577,3 +577,36 @@ def test_n_step_agent_runs_the_vector_loop(torch):
     torch.cuda.synchronize()
     assert len(ag.memory) == 256 * (8 - 2) and ag.grad_steps >= 2 and np.isfinite(float(stats["loss"]))
     env.close()
+
+
+def test_two_launch_step_equals_the_three_launch_step_bitwise(torch):
+    """`mn_iqn_train_step` (round 4): forward / backward, then ONE launch in which every block reduces its own parameters' partial gradients,
+    exchanges the norm partials as self-tagged granules and applies clip + Adam -- against `mn_iqn_train_grad*` + `mn_iqn_train_adam` (three
+    launches): losses, clipped gradients, parameters, moments, Adam step, generator state bit-identical over sampled steps (staged batches incl.),
+    a ring write in between, given-batch steps with injected taus, and a captured 8-step hipGraph."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    runs = []
+    for two in (True, False):
+        ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
+        ag.two_launch_step = two
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        ag.memory.add_batch(*_random_batch(torch, 2048, g))
+        losses = [float(ag.train_from_memory()) for _ in range(12)]
+        ag.memory.add_batch(*_random_batch(torch, 300, g))
+        losses += [float(ag.train_from_memory()) for _ in range(5)]
+        for k in range(3):
+            exp = _random_batch(torch, 64, g)
+            tt = torch.rand(64, 8, device=dev, generator=g); tl = torch.rand(64, 8, device=dev, generator=g)
+            losses.append(float(ag.train(exp, taus_target=tt, taus_local=tl)))
+        ag.use_fused_graph = True
+        losses.append(float(ag.train_steps_from_memory(8)))
+        losses.append(float(ag.train_steps_from_memory(8)))
+        ft = ag._fused
+        assert ft._two_launches() == two
+        runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone(), ag.grad_steps))
+    a, b = runs
+    assert a[0] == b[0] and all(np.isfinite(a[0]))
+    for x, y in zip(a[1:5], b[1:5]):
+        assert torch.equal(x, y)
+    assert a[5] == b[5] == 12 + 5 + 3 + 16 and torch.equal(a[6], b[6]) and a[7] == b[7]
