@@ -490,7 +490,9 @@ __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_par
 // [10..11] device pointer (u64) of this rank's gradient mailbox, 0 = none (mn_xchg_attach: the reduction kernel publishes into it)
 // [12 ..] N_RED self-tagged norm partials (u64) of the fused reduction + Adam launch (iqn_grad_reduce_adam)
 __host__ __device__ constexpr int64_t ws_xsq(int n_part) { return ws_epoch(n_part) + 12; }
-__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_xsq(n_part) + 2 * N_RED; }
+// then n_part "row complete" words (u32 step tags) of the one-launch step: workgroup w's partial-gradient row and loss partial are final
+__host__ __device__ constexpr int64_t ws_done(int n_part) { return ws_xsq(n_part) + 2 * N_RED; }
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_done(n_part) + pad4(n_part); }
 constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
@@ -511,14 +513,230 @@ __device__ __forceinline__ void write_batch_copies(const BatchArgs &ba, uint64_t
         for (int e = threadIdx.x; e < 2 * batch * NQ; e += THREADS) ba.taus_out[e] = sample_tau(base, e);
 }
 
+constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
+constexpr int RED_MAX_PER = 128 / RED_SEG;   // covers batch <= 256 with every load in flight; larger batches loop
+
+// ---- The reduction AND the optimizer step in one launch (round 4; mn_iqn_train_step*): a gradient step is TWO launches ------------------
+// Adam block b (of iqn_adam's 140, here with 512 threads) does iqn_grad_reduce's work for ITS 64 float4 columns -- thread (cx, seg) sums
+// segment seg of the partials of column 64 b + cx with every load in flight, the eight segment sums are combined in iqn_grad_reduce's order --
+// forms the two norm partials those columns make up (iqn_grad_reduce's blocks 2 b and 2 b + 1: same grouping, same order), publishes them as
+// self-tagged granules in the workspace, and runs iqn_adam's body for its 256 parameters on the 280 partials it polls: the partials are the
+// grid-wide dependency, no barrier, no third launch (the pattern of iqn_adam_xchg).  Loss, staging of the next batch, generator counter and
+// hand-off epoch as in iqn_grad_reduce.  Every sum in the order of the three-launch path: BIT-IDENTICAL to iqn_grad_reduce + iqn_adam.
+// All 140 blocks are resident together (the polls are bounded anyway: ~2 s, then the loss is NaN).
+constexpr int RA_COLS = 64, RA_BT = RA_COLS * RED_SEG;      // 512 threads: one wavefront per segment
+static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "an Adam block's 64 columns are two of the reduction's column groups");
+// `vb` of `nvb` = the block's index among the reduction blocks (the stand-alone launch: vb; as the third role of the forward / backward
+// launch: vb - its workgroups).  `done` != NULL (third role): the partial gradients are being written by workgroups of the SAME launch;
+// done[w] == done_tag says workgroup w's partial row and loss partial are complete -- each wave waits for the 16 rows of its segment.
+__device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, float *__restrict__ ws, int n_part, float *__restrict__ grad,
+                                                 float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
+                                                 float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
+                                                 double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag) {
+    __shared__ float4 red[RED_SEG][RA_COLS];
+    __shared__ float sq[RA_COLS];
+    __shared__ float gsh[4 * RA_COLS];
+    __shared__ float nred[4];
+    __shared__ float s_bc[2];
+    const int tid = threadIdx.x, cx = tid % RA_COLS, seg = tid / RA_COLS;
+    const int col = vb * RA_COLS + cx;
+    if (*reinterpret_cast<const uint32_t *>(ws + ws_epoch(n_part) + 8) != WS_MAGIC) {      // see iqn_grad_reduce
+        if (vb == 0 && tid == 0) loss_out[0] = __builtin_nanf("");
+        return;
+    }
+    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);      // the epoch this step ends with
+    // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
+    const int p = vb * 256 + tid;
+    float mp = 0.f, vp = 0.f, pp = 0.f;
+    if (tid < 256 && p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
+    // staging of the NEXT step's batch (see iqn_grad_reduce): a pure copy, any thread mapping does
+    constexpr int SPB = RA_BT / STG;
+    const int batch = n_part * BE;
+    int st_slot = -1, st_e = 0;
+    float st_v = 0.f;
+    if (prefetch_next && rng_state && vb >= 1) {
+        const int t_slot = tid / STG;
+        st_e = tid % STG;
+        for (int j = vb - 1; j * SPB < batch; j += nvb - 1)
+            if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
+    }
+    if (st_slot >= 0) {
+        const uint64_t base_n = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2));
+        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)st_slot);
+        if (st_e < OBS) st_v = ba.ring_s[row * OBS + st_e];
+        else if (st_e < 2 * OBS) st_v = ba.ring_ns[row * OBS + st_e - OBS];
+        else if (st_e == 2 * OBS) st_v = (float)ba.ring_a[row];
+        else if (st_e == 2 * OBS + 1) st_v = ba.ring_r[row];
+        else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
+        else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
+    }
+    const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
+    bool late = false;
+    if (done) {      // wait for this segment's rows (one wavefront = one segment: lane i watches row w0 + i, + 64, ...)
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            bool ok = true;
+            for (int w = w0 + (tid & 63); w < w1; w += 64) ok = ok && __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == done_tag;
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // nothing cached before the rows were complete is used below
+        __syncthreads();                                                              // ... and every row (the loss partials) is complete for every wave
+    }
+    float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
+    if (vb == 0 && tid < 256)
+        for (int wq = tid; wq < n_part; wq += 256) lpart += ws[ws_loss(n_part) + wq];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < N_COLS) {
+        const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
+        for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
+            float4 t[RED_MAX_PER];
+#pragma unroll
+            for (int u = 0; u < RED_MAX_PER; ++u)
+                t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < RED_MAX_PER; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+        }
+    }
+    red[seg][cx] = acc;
+    __syncthreads();
+    if (seg == 0) {
+        float4 s = red[0][cx];
+#pragma unroll
+        for (int q = 1; q < RED_SEG; ++q) { s.x += red[q][cx].x; s.y += red[q][cx].y; s.z += red[q][cx].z; s.w += red[q][cx].w; }
+        float ss = 0.f;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (col < N_COLS) {
+            e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
+            ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
+        }
+        sq[cx] = ss;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gsh[4 * cx + k] = e[k];
+    }
+    __syncthreads();
+    gu64 *xsq = (gu64 *)(ws + ws_xsq(n_part));
+    if (tid == 0 || tid == RED_COLS) {
+        float t = 0.f;
+        for (int k = 0; k < RED_COLS; ++k) t += sq[tid + k];
+        ws[ws_sq(n_part) + 2 * vb + (tid >> 5)] = t;      // (also where the three-launch path keeps them)
+        __hip_atomic_store(xsq + 2 * vb + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (vb == 0) {      // the loss, in iqn_grad_reduce's order
+        __shared__ float lw[4];
+        float l = lpart;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+        if (tid < 256 && (tid & 63) == 0) lw[tid >> 6] = l;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int k = 0; k < 4; ++k) t += lw[k];
+            *loss_out = t;
+        }
+    }
+    if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
+    // ---- clip + Adam (iqn_adam's body) on the 280 partials, polled: the data is the flag
+    float part = 0.f;
+    if (tid < 256)
+        for (int c = tid; c < N_RED; c += 256) {
+            uint64_t x;
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                x = __hip_atomic_load(xsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(x >> 32) == tag) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            part += __uint_as_float((uint32_t)x);
+        }
+    int t_step = 0;
+    if (tid == 255) {
+        t_step = *step + 1;
+        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (tid < 256 && (tid & 63) == 0) nred[tid >> 6] = part;
+    __syncthreads();
+    const float sumsq = (nred[0] + nred[1]) + (nred[2] + nred[3]);
+    const float norm = sqrtf(sumsq);
+    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
+    const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
+    const float wm = (float)(1.0 - b1), b2f = (float)b2, wv = (float)(1.0 - b2), eps = (float)eps_d;
+    if (tid < 256 && p < P_TOTAL) {
+        float gq = gsh[tid] * 1.0f;
+        gq *= coef;
+        grad[p] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
+        const float mm = mp + (gq - mp) * wm;
+        const float vv = vp * b2f + wv * (gq * gq);
+        m[p] = mm;
+        v[p] = vv;
+        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+    // the block that finishes LAST advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
+    // (every block read all of them before taking its ticket)
+    __syncthreads();
+    if (tid == 0) {
+        unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nvb - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
+            *step = *step + 1;
+            uint64_t *stg_tag = reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part) + 4);
+            if (rng_state) {
+                const uint64_t c = rng_state[1] + 1;
+                rng_state[1] = c;
+                stg_tag[0] = c;
+                stg_tag[1] = prefetch_next ? (uint64_t)ba.ring_n : 0;
+            } else {
+                stg_tag[1] = 0;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict__ ws, int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
+                                                              uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
+                                                              float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
+                                                              int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
+    reduce_adam_body(blockIdx.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u);
+}
+
+// The rest of the step as a THIRD ROLE of the forward / backward launch (n_wg > 0; round 4: one launch per gradient step): workgroups
+// [n_fwd, n_fwd + n_wg) are reduction + Adam blocks (reduce_adam_body).  They are dispatched after every forward / backward workgroup (higher
+// block indices), land on the CUs the target workgroups vacate half way through the launch, and wait there for the "row complete" words the local
+// workgroups write after their last partial-gradient store -- no launch boundary between the backward pass and the optimizer step.
+struct StepTail {
+    int n_wg;
+    int prefetch_next;
+    float *grad, *loss_out, *params, *m, *v;
+    int32_t *step;
+    uint64_t *rng_state;
+    double lr, b1, b2, eps, max_norm;
+};
+
 __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const float *__restrict__ PL, const float *__restrict__ PT,
-                                                            float *__restrict__ ws, int batch, float gamma, int mode, int use_staged) {
+                                                            float *__restrict__ ws, int batch, float gamma, int mode, int use_staged, StepTail tail) {
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
     __shared__ int s_got;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int n_part = batch / BE;
     const bool two_roles = mode == MODE_TWO_ROLES;
+    if (tail.n_wg) {
+        const int n_fwd = two_roles ? 2 * n_part : n_part;
+        if ((int)blockIdx.x >= n_fwd) {
+            const uint32_t dtag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;      // = the hand-off tag below
+            reduce_adam_body((int)blockIdx.x - n_fwd, tail.n_wg, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
+                             tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm,
+                             reinterpret_cast<const uint32_t *>(ws + ws_done(n_part)), dtag);
+            return;
+        }
+    }
 #ifdef MN_TRAIN_PHASES
     const int ph_local = two_roles ? n_part : 0;
 #endif
@@ -835,13 +1053,17 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     if (tid < P_PAD - P_TOTAL) out[P_TOTAL + tid] = 0.f;   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
     if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
+    if (tail.n_wg) {      // one-launch step: this workgroup's row (and loss partial) is final -- tell the reduction blocks of this launch
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_done(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // grad[p] = sum over workgroups of partial[wg][p].  One thread = one float4 column of one of RED_SEG contiguous segments of the
 // partials: its (up to) n_part / 8 loads are all in flight before the first add (the round-2 kernel did four dependent rounds of
 // eight), summed in index order; the eight segment sums are combined in a fixed order -> deterministic.  Also: this block's sum of
 // squares of the reduced gradient (iqn_adam's norm), the loss (block 0), the generator's call counter and the hand-off epoch.
-constexpr int RED_MAX_PER = 128 / RED_SEG;   // covers batch <= 256 with every load in flight; larger batches loop
 __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__restrict__ ws, int n_part, float *__restrict__ grad,
                                                                        float *__restrict__ loss_out, uint64_t *__restrict__ rng_state,
                                                                        BatchArgs ba, int prefetch_next) {
@@ -973,7 +1195,6 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
 }
 
 
-constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
 
 // clip_grad_norm_(max_norm) (torch/nn/utils/clip_grad.py: coef = min(1, max_norm / (norm + 1e-6))) followed by
 // torch.optim.Adam's update: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
@@ -1141,174 +1362,6 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
         if (old == gridDim.x - 1) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *step = t_step;
-        }
-    }
-}
-
-// ---- The reduction AND the optimizer step in one launch (round 4; mn_iqn_train_step*): a gradient step is TWO launches ------------------
-// Adam block b (of iqn_adam's 140, here with 512 threads) does iqn_grad_reduce's work for ITS 64 float4 columns -- thread (cx, seg) sums
-// segment seg of the partials of column 64 b + cx with every load in flight, the eight segment sums are combined in iqn_grad_reduce's order --
-// forms the two norm partials those columns make up (iqn_grad_reduce's blocks 2 b and 2 b + 1: same grouping, same order), publishes them as
-// self-tagged granules in the workspace, and runs iqn_adam's body for its 256 parameters on the 280 partials it polls: the partials are the
-// grid-wide dependency, no barrier, no third launch (the pattern of iqn_adam_xchg).  Loss, staging of the next batch, generator counter and
-// hand-off epoch as in iqn_grad_reduce.  Every sum in the order of the three-launch path: BIT-IDENTICAL to iqn_grad_reduce + iqn_adam.
-// All 140 blocks are resident together (the polls are bounded anyway: ~2 s, then the loss is NaN).
-constexpr int RA_COLS = 64, RA_BT = RA_COLS * RED_SEG;      // 512 threads: one wavefront per segment
-static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "an Adam block's 64 columns are two of the reduction's column groups");
-__global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict__ ws, int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
-                                                              uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
-                                                              float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
-                                                              int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
-    __shared__ float4 red[RED_SEG][RA_COLS];
-    __shared__ float sq[RA_COLS];
-    __shared__ float gsh[4 * RA_COLS];
-    __shared__ float nred[4];
-    __shared__ float s_bc[2];
-    const int tid = threadIdx.x, cx = tid % RA_COLS, seg = tid / RA_COLS;
-    const int col = blockIdx.x * RA_COLS + cx;
-    if (*reinterpret_cast<const uint32_t *>(ws + ws_epoch(n_part) + 8) != WS_MAGIC) {      // see iqn_grad_reduce
-        if (blockIdx.x == 0 && tid == 0) loss_out[0] = __builtin_nanf("");
-        return;
-    }
-    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);      // the epoch this step ends with
-    // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
-    const int p = blockIdx.x * 256 + tid;
-    float mp = 0.f, vp = 0.f, pp = 0.f;
-    if (tid < 256 && p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
-    float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
-    if (blockIdx.x == 0 && tid < 256)
-        for (int wq = tid; wq < n_part; wq += 256) lpart += ws[ws_loss(n_part) + wq];
-    // staging of the NEXT step's batch (see iqn_grad_reduce): a pure copy, any thread mapping does
-    constexpr int SPB = RA_BT / STG;
-    const int batch = n_part * BE;
-    int st_slot = -1, st_e = 0;
-    float st_v = 0.f;
-    if (prefetch_next && rng_state && blockIdx.x >= 1) {
-        const int t_slot = tid / STG;
-        st_e = tid % STG;
-        for (int j = blockIdx.x - 1; j * SPB < batch; j += gridDim.x - 1)
-            if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
-    }
-    if (st_slot >= 0) {
-        const uint64_t base_n = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2));
-        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)st_slot);
-        if (st_e < OBS) st_v = ba.ring_s[row * OBS + st_e];
-        else if (st_e < 2 * OBS) st_v = ba.ring_ns[row * OBS + st_e - OBS];
-        else if (st_e == 2 * OBS) st_v = (float)ba.ring_a[row];
-        else if (st_e == 2 * OBS + 1) st_v = ba.ring_r[row];
-        else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
-        else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
-    }
-    const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < N_COLS) {
-        const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
-        for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
-            float4 t[RED_MAX_PER];
-#pragma unroll
-            for (int u = 0; u < RED_MAX_PER; ++u)
-                t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < RED_MAX_PER; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
-        }
-    }
-    red[seg][cx] = acc;
-    __syncthreads();
-    if (seg == 0) {
-        float4 s = red[0][cx];
-#pragma unroll
-        for (int q = 1; q < RED_SEG; ++q) { s.x += red[q][cx].x; s.y += red[q][cx].y; s.z += red[q][cx].z; s.w += red[q][cx].w; }
-        float ss = 0.f;
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (col < N_COLS) {
-            e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
-            ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
-        }
-        sq[cx] = ss;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gsh[4 * cx + k] = e[k];
-    }
-    __syncthreads();
-    gu64 *xsq = (gu64 *)(ws + ws_xsq(n_part));
-    if (tid == 0 || tid == RED_COLS) {
-        float t = 0.f;
-        for (int k = 0; k < RED_COLS; ++k) t += sq[tid + k];
-        ws[ws_sq(n_part) + 2 * blockIdx.x + (tid >> 5)] = t;      // (also where the three-launch path keeps them)
-        __hip_atomic_store(xsq + 2 * blockIdx.x + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (blockIdx.x == 0) {      // the loss, in iqn_grad_reduce's order
-        __shared__ float lw[4];
-        float l = lpart;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-        if (tid < 256 && (tid & 63) == 0) lw[tid >> 6] = l;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.f;
-            for (int k = 0; k < 4; ++k) t += lw[k];
-            *loss_out = t;
-        }
-    }
-    if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
-    // ---- clip + Adam (iqn_adam's body) on the 280 partials, polled: the data is the flag
-    bool late = false;
-    float part = 0.f;
-    if (tid < 256)
-        for (int c = tid; c < N_RED; c += 256) {
-            uint64_t x;
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                x = __hip_atomic_load(xsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(x >> 32) == tag) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            part += __uint_as_float((uint32_t)x);
-        }
-    int t_step = 0;
-    if (tid == 255) {
-        t_step = *step + 1;
-        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
-        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (tid < 256 && (tid & 63) == 0) nred[tid >> 6] = part;
-    __syncthreads();
-    const float sumsq = (nred[0] + nred[1]) + (nred[2] + nred[3]);
-    const float norm = sqrtf(sumsq);
-    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
-    const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
-    const float wm = (float)(1.0 - b1), b2f = (float)b2, wv = (float)(1.0 - b2), eps = (float)eps_d;
-    if (tid < 256 && p < P_TOTAL) {
-        float gq = gsh[tid] * 1.0f;
-        gq *= coef;
-        grad[p] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
-        const float mm = mp + (gq - mp) * wm;
-        const float vv = vp * b2f + wv * (gq * gq);
-        m[p] = mm;
-        v[p] = vv;
-        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
-    }
-    // the block that finishes LAST advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
-    // (every block read all of them before taking its ticket)
-    __syncthreads();
-    if (tid == 0) {
-        unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
-            *step = *step + 1;
-            uint64_t *stg_tag = reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part) + 4);
-            if (rng_state) {
-                const uint64_t c = rng_state[1] + 1;
-                rng_state[1] = c;
-                stg_tag[0] = c;
-                stg_tag[1] = prefetch_next ? (uint64_t)ba.ring_n : 0;
-            } else {
-                stg_tag[1] = 0;
-            }
         }
     }
 }
@@ -1499,8 +1552,17 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     hipStream_t s = (hipStream_t)stream;
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
-    hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(mode == MODE_TWO_ROLES ? 2 * n_part : n_part), dim3(THREADS), LDS_BYTES, s, ba,
-                       params_local, params_target, workspace, batch, gamma, mode, use_staged);
+    const int n_fwd = mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
+    if (adam && (flags & MN_TRAIN_ONE_LAUNCH)) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
+        const StepTail tail = {N_ADAM, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
+                               adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm};
+        hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + N_ADAM), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+                           mode, use_staged, tail);
+        return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+    }
+    const StepTail no_tail = {};
+    hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
+                       params_local, params_target, workspace, batch, gamma, mode, use_staged, no_tail);
     if (adam)
         hipLaunchKernelGGL(iqn_grad_reduce_adam, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
                            adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm);

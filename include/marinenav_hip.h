@@ -381,7 +381,9 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 /* The whole gradient step of a single learner -- IQNAgent.train (agent.py:269-304) incl. clip_grad_norm_ and optimizer.step() -- as TWO
  * launches: forward / backward, then a launch in which every block reduces the partial gradients of its own 256 parameters, exchanges the norm
- * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4).  rng_state_dev != NULL: the batch is drawn in the
+ * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4) -- or, with MN_TRAIN_ONE_LAUNCH in `flags`, as ONE
+ * launch: those 140 blocks are a third workgroup role of the forward / backward launch, dispatched behind its workgroups, and wait for the
+ * "row complete" words the backward pass leaves (bit-identical again).  rng_state_dev != NULL: the batch is drawn in the
  * launch (arguments as mn_iqn_train_grad_sampled; idx_dev / taus_*_dev ignored); NULL: the given batch (as mn_iqn_train_grad).  params_local is
  * updated in place, grad_out receives the clipped gradient.  Bit-identical to mn_iqn_train_grad* + mn_iqn_train_adam(grad_scale = 1): those stay
  * for callers that put something between the two (the shared learner's all-reduce / exchange). */
@@ -461,6 +463,7 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
  * if the ring was not written since the staging call (then the step is bit-identical to the unstaged one). */
 #define MN_TRAIN_USE_STAGED 1
 #define MN_TRAIN_STAGE_NEXT 2
+#define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step only: the reduction + clip + Adam blocks ride in the forward / backward launch (third role) */
 int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                               const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,
                               int64_t *idx_out, float *taus_out, const float *params_local, const float *params_target,

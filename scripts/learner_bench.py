@@ -18,9 +18,11 @@ n = 100_000
 ag.memory.add_batch(torch.randn(n, 26, device=dev, generator=g), torch.randint(0, 9, (n,), device=dev, generator=g),
                     torch.randn(n, device=dev, generator=g), torch.randn(n, 26, device=dev, generator=g),
                     (torch.rand(n, device=dev, generator=g) < 0.05).float())
-for mode, two in ((0, True), (0, False), (1, True), (0, True), (0, False)):
+for mode, launches in ((0, 1), (0, 2), (0, 3), (1, 1), (0, 1), (0, 2), (0, 3)):
     _capi.lib().mn_iqn_train_set_mode(mode)
-    ag.two_launch_step = two      # True: forward / backward + (reduction + clip + Adam) = two launches (mn_iqn_train_step); False: three
+    # launches per gradient step: 3 = forward / backward, reduction, Adam; 2 = forward / backward, (reduction + clip + Adam) (mn_iqn_train_step);
+    # 1 = the same with the reduction + Adam blocks as a third workgroup role of the forward / backward launch (MN_TRAIN_ONE_LAUNCH)
+    ag.two_launch_step, ag.one_launch_step = launches < 3, launches == 1
     for _ in range(20):
         ag.train_from_memory()
     torch.cuda.synchronize()
@@ -29,9 +31,9 @@ for mode, two in ((0, True), (0, False), (1, True), (0, True), (0, False)):
         ag.train_from_memory()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"mode {mode}, {'two' if two else 'three'} launches per step: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
+    print(f"mode {mode}, {launches} launch(es) per step: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
 _capi.lib().mn_iqn_train_set_mode(0)
-ag.two_launch_step = True
+ag.two_launch_step, ag.one_launch_step = True, True
 # the same gradient steps as captured hipGraphs of G steps each (IQNAgent.use_fused_graph)
 for G in (16, 64):
     ag.use_fused_graph = True

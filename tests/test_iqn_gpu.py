@@ -293,7 +293,7 @@ def test_iqn_c_abi_argument_checks(torch):
     L = _capi.lib()
     # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
     # staging tag / magic word + the staged next batch (256 slots of 72 floats)
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + 256 * 72      # (+ the 280 tagged norm partials of the two-launch step)
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + 128 + 256 * 72      # (+ the 280 tagged norm partials and 128 row-complete words of the two- / one-launch step)
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -579,17 +579,21 @@ def test_n_step_agent_runs_the_vector_loop(torch):
     env.close()
 
 
-def test_two_launch_step_equals_the_three_launch_step_bitwise(torch):
-    """`mn_iqn_train_step` (round 4): forward / backward, then ONE launch in which every block reduces its own parameters' partial gradients,
-    exchanges the norm partials as self-tagged granules and applies clip + Adam -- against `mn_iqn_train_grad*` + `mn_iqn_train_adam` (three
-    launches): losses, clipped gradients, parameters, moments, Adam step, generator state bit-identical over sampled steps (staged batches incl.),
-    a ring write in between, given-batch steps with injected taus, and a captured 8-step hipGraph."""
+def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
+    """`mn_iqn_train_step` (round 4): the reduction, clip and Adam as ONE launch in which every block reduces its own parameters' partial
+    gradients and exchanges the norm partials as self-tagged granules (two launches per step), or as a third workgroup role of the forward /
+    backward launch itself (MN_TRAIN_ONE_LAUNCH: one launch per step) -- against `mn_iqn_train_grad*` + `mn_iqn_train_adam` (three launches):
+    losses, clipped gradients, parameters, moments, Adam step, generator state bit-identical over sampled steps (staged batches incl.), a ring
+    write in between, given-batch steps with injected taus, a captured 8-step hipGraph, and in the local-only workgroup mode."""
+    from distributional_rl_navigation_amd import _capi
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev = "cuda:0"
     runs = []
-    for two in (True, False):
+    for two, one in ((True, True), (True, False), (False, False), (True, True)):
         ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
-        ag.two_launch_step = two
+        ag.two_launch_step, ag.one_launch_step = two, one
+        if len(runs) == 3:
+            _capi.lib().mn_iqn_train_set_mode(1)      # every workgroup computes its own TD targets: no target role in the launch
         g = torch.Generator(device=dev); g.manual_seed(5)
         ag.memory.add_batch(*_random_batch(torch, 2048, g))
         losses = [float(ag.train_from_memory()) for _ in range(12)]
@@ -605,8 +609,11 @@ def test_two_launch_step_equals_the_three_launch_step_bitwise(torch):
         ft = ag._fused
         assert ft._two_launches() == two
         runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone(), ag.grad_steps))
-    a, b = runs
-    assert a[0] == b[0] and all(np.isfinite(a[0]))
-    for x, y in zip(a[1:5], b[1:5]):
-        assert torch.equal(x, y)
-    assert a[5] == b[5] == 12 + 5 + 3 + 16 and torch.equal(a[6], b[6]) and a[7] == b[7]
+    _capi.lib().mn_iqn_train_set_mode(0)
+    ref = runs[2]      # three launches
+    assert all(np.isfinite(ref[0]))
+    for r in (runs[0], runs[1], runs[3]):
+        assert r[0] == ref[0]
+        for x, y in zip(r[1:5], ref[1:5]):
+            assert torch.equal(x, y)
+        assert r[5] == ref[5] == 12 + 5 + 3 + 16 and torch.equal(r[6], ref[6]) and r[7] == ref[7]
