@@ -168,7 +168,7 @@ class FusedTrainer:
             key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr() if self._ws is not None else 0)
             flags = 2 | (1 if key == self._staged_key else 0)
         if self._two_launches():      # forward / backward, then reduction + clip + Adam in ONE launch (mn_iqn_train_step): bit-identical
-            flags |= 4 if getattr(ag, "one_launch_step", True) else 0      # MN_TRAIN_ONE_LAUNCH: ... as a third role of the SAME launch
+            flags |= 4 if getattr(ag, "one_launch_step", False) else 0      # MN_TRAIN_ONE_LAUNCH: ... as a third role of the SAME launch
             rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size), _p(self.rng_state), None, None, None,
                                      _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target), _p(self._workspace(batch)), _p(self.grad),
                                      _p(self.loss), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev), batch, ag.N, C.c_float(ag.GAMMA ** ag.n_step), flags,
@@ -248,7 +248,7 @@ class FusedTrainer:
         if self._two_launches():
             rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), 0, None, _p(idx), _p(tt), _p(tl), None, None,
                                      _p(self.local), _p(self.target), _p(self._workspace(B)), _p(self.grad), _p(self.loss), _p(self.exp_avg),
-                                     _p(self.exp_avg_sq), _p(self.step_dev), B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), 4 if getattr(ag, "one_launch_step", True) else 0,
+                                     _p(self.exp_avg_sq), _p(self.step_dev), B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), 4 if getattr(ag, "one_launch_step", False) else 0,
                                      C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5), stream)
             if rc:
                 raise _capi.MarineNavHipError(f"mn_iqn_train_step failed ({rc})")

@@ -33,7 +33,7 @@ for mode, launches in ((0, 1), (0, 2), (0, 3), (1, 1), (0, 1), (0, 2), (0, 3)):
     dt = time.perf_counter() - t0
     print(f"mode {mode}, {launches} launch(es) per step: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
 _capi.lib().mn_iqn_train_set_mode(0)
-ag.two_launch_step, ag.one_launch_step = True, True
+ag.two_launch_step, ag.one_launch_step = True, False
 # the same gradient steps as captured hipGraphs of G steps each (IQNAgent.use_fused_graph)
 for G in (16, 64):
     ag.use_fused_graph = True
