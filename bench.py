@@ -332,10 +332,12 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
         # the one-shot exchange over IPC-mapped mailboxes instead of the RCCL all-reduce (iqn/mailbox.py; one rank: its own mailbox only)
         agent.exchange = "mailbox"
         try:
-            agent.exchange_fused_adam = False
-            sl["mailbox_ws1_exchange_then_adam_two_launches"] = learner_rate()
+            agent.exchange_fused_adam, agent.two_launch_step = False, False
+            sl["mailbox_ws1_four_launches"] = learner_rate()      # forward / backward, reduction (publishes), gather, Adam
             agent.exchange_fused_adam = True
-            sl["mailbox_ws1_exchange"] = learner_rate()
+            sl["mailbox_ws1_three_launches"] = learner_rate()     # ... gather + clip + Adam in one launch
+            agent.two_launch_step = True
+            sl["mailbox_ws1_exchange"] = learner_rate()           # the exchange inside the reduction + Adam launch: two launches, like a single learner
             sl["mailbox_overhead_us_per_step"] = 1e6 * (1.0 / sl["mailbox_ws1_exchange"] - 1.0 / sl["no_group"])
             sl["mailbox_ws1_exchange_graphed_16_step_events"] = graphed_rate()
             sl["mailbox_timeouts"] = agent._fused._mailbox.timeouts()

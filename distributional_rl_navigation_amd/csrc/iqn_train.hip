@@ -516,6 +516,42 @@ __device__ __forceinline__ void write_batch_copies(const BatchArgs &ba, uint64_t
 constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
 constexpr int RED_MAX_PER = 128 / RED_SEG;   // covers batch <= 256 with every load in flight; larger batches loop
 
+constexpr int XCHG_MAX_RANKS = 8;
+struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS + 1]; };      // by rank; mb[world] = this rank's own mailbox once more (the alias the fused step writes through)
+// e[0..3] = sum over ranks, IN RANK ORDER, of granules q .. q + 3 of the step tagged `tag`.  All ranks' granules are requested together
+// (independent system-scope loads in flight over the fabric at once, not one round trip per peer); a pass that finds a stale tag is repeated
+// as a whole.  Returns true if the bound (~2 s of the 100 MHz counter) was hit.
+__device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, uint32_t tag, int q, float (&e)[4]) {
+    uint64_t x[XCHG_MAX_RANKS][4];
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    bool late = false;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+            if (r < world) {
+                const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[r][k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+#pragma unroll
+        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+            if (r < world)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ok = ok && (uint32_t)(x[r][k] >> 32) == tag;
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r)
+        if (r < world)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[r][k]);
+    return late;
+}
 // ---- The reduction AND the optimizer step in one launch (round 4; mn_iqn_train_step*): a gradient step is TWO launches ------------------
 // Adam block b (of iqn_adam's 140, here with 512 threads) does iqn_grad_reduce's work for ITS 64 float4 columns -- thread (cx, seg) sums
 // segment seg of the partials of column 64 b + cx with every load in flight, the eight segment sums are combined in iqn_grad_reduce's order --
@@ -532,7 +568,8 @@ static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "
 __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, float *__restrict__ ws, int n_part, float *__restrict__ grad,
                                                  float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
                                                  float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
-                                                 double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag) {
+                                                 double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag,
+                                                 const XchgPeers *peers = nullptr, int world = 1, float grad_scale = 1.0f) {
     __shared__ float4 red[RED_SEG][RA_COLS];
     __shared__ float sq[RA_COLS];
     __shared__ float gsh[4 * RA_COLS];
@@ -611,6 +648,22 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
             e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
             ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
         }
+        if (peers) {      // shared learner, one-shot exchange IN this launch (mn_iqn_train_step_xchg): publish this rank's columns, gather every rank's
+            if (col < N_COLS) {
+                gu64 *dst = (gu64 *)peers->mb[world] + (size_t)(tag & 1u) * P_PAD + 4 * col;      // mb[world] = this rank's own mailbox (writable alias)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_store(dst + k, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(e[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                late = xchg_gather4(*peers, world, tag, 4 * col, e) || late;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (4 * col + k >= P_TOTAL) e[k] = 0.f;
+            }
+            float sc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sc[k] = e[k] * grad_scale;
+            ss = ((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]) + sc[3] * sc[3];      // iqn_grad_sumsq's / iqn_adam_xchg's expression
+        }
         sq[cx] = ss;
 #pragma unroll
         for (int k = 0; k < 4; ++k) gsh[4 * cx + k] = e[k];
@@ -667,7 +720,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
     const float wm = (float)(1.0 - b1), b2f = (float)b2, wv = (float)(1.0 - b2), eps = (float)eps_d;
     if (tid < 256 && p < P_TOTAL) {
-        float gq = gsh[tid] * 1.0f;
+        float gq = gsh[tid] * grad_scale;
         gq *= coef;
         grad[p] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
         const float mm = mp + (gq - mp) * wm;
@@ -704,6 +757,17 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict_
                                                               float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                               int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
     reduce_adam_body(blockIdx.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u);
+}
+
+// ... and with the shared learner's one-shot gradient exchange inside (mn_iqn_train_step_xchg): two launches per step for a shared learner too
+__global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__restrict__ ws, int n_part, float *__restrict__ grad, float *__restrict__ loss_out,
+                                                                   uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
+                                                                   float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
+                                                                   int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d,
+                                                                   XchgPeers peers, int world, float grad_scale, unsigned *__restrict__ status) {
+    reduce_adam_body(blockIdx.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u,
+                     &peers, world, grad_scale);
+    (void)status;
 }
 
 // The rest of the step as a THIRD ROLE of the forward / backward launch (n_wg > 0; round 4: one launch per gradient step): workgroups
@@ -1234,42 +1298,6 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restri
 // is the current step's (bounded: ~2 s of the 100 MHz counter, then the status word is raised and the step continues with what is there --
 // a wait can never hang the device).  Two slots alternate with the step parity: a rank publishes step k + 2 into slot k & 1 only after its
 // gather of step k + 1, which needed every peer's step k + 1, which every peer published after ITS gather of step k.
-constexpr int XCHG_MAX_RANKS = 8;
-struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS]; };
-// e[0..3] = sum over ranks, IN RANK ORDER, of granules q .. q + 3 of the step tagged `tag`.  All ranks' granules are requested together
-// (independent system-scope loads in flight over the fabric at once, not one round trip per peer); a pass that finds a stale tag is repeated
-// as a whole.  Returns true if the bound (~2 s of the 100 MHz counter) was hit.
-__device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, uint32_t tag, int q, float (&e)[4]) {
-    uint64_t x[XCHG_MAX_RANKS][4];
-    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    bool late = false;
-    for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
-            if (r < world) {
-                const gu64 *src = peers.mb[r] + (size_t)(tag & 1u) * P_PAD + q;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[r][k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-#pragma unroll
-        for (int r = 0; r < XCHG_MAX_RANKS; ++r)
-            if (r < world)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ok = ok && (uint32_t)(x[r][k] >> 32) == tag;
-        if (ok) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = 0.f;
-#pragma unroll
-    for (int r = 0; r < XCHG_MAX_RANKS; ++r)
-        if (r < world)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[r][k]);
-    return late;
-}
 __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int world, const float *__restrict__ ws, int n_part,
                                                             float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale,
                                                             unsigned *__restrict__ status) {
@@ -1513,10 +1541,15 @@ extern "C" int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void
     return MN_OK;
 }
 
+struct mn_xchg;
 struct AdamArgs {      // non-null: the reduction launch also performs clip + Adam (iqn_grad_reduce_adam): two launches per gradient step
     float *params, *exp_avg, *exp_avg_sq;
     int32_t *step_dev;
     double lr, beta1, beta2, eps, max_norm;
+    const XchgPeers *peers;      // shared learner: the one-shot exchange inside the same launch
+    int world;
+    float grad_scale;
+    unsigned *status;
 };
 
 static int launch_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
@@ -1553,7 +1586,7 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
     const int n_fwd = mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
-    if (adam && (flags & MN_TRAIN_ONE_LAUNCH)) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
+    if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH)) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
         const StepTail tail = {N_ADAM, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
                                adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm};
         hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + N_ADAM), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
@@ -1563,7 +1596,11 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     const StepTail no_tail = {};
     hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
                        params_local, params_target, workspace, batch, gamma, mode, use_staged, no_tail);
-    if (adam)
+    if (adam && adam->peers)
+        hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
+                           adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm,
+                           *adam->peers, adam->world, adam->grad_scale, adam->status);
+    else if (adam)
         hipLaunchKernelGGL(iqn_grad_reduce_adam, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
                            adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm);
     else
@@ -1582,7 +1619,7 @@ extern "C" int mn_iqn_train_step(const float *ring_states, const float *ring_nex
                                  int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                                  double eps, double max_norm, void *stream) {
     if (!params_local || !exp_avg || !exp_avg_sq || !step_dev) return MN_ERR_INVALID;
-    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm};
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, nullptr, 1, 1.0f, nullptr};
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
                        rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
                        grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags, stream, &adam);
@@ -1731,4 +1768,29 @@ extern "C" int mn_xchg_destroy(mn_xchg *x) {
     (void)hipFree((void *)x->xsq);
     delete x;
     return MN_OK;
+}
+
+// mn_iqn_train_step for a SHARED learner: the one-shot gradient exchange happens inside the reduction + Adam launch -- every Adam block
+// publishes its 64 reduced columns into this rank's mailbox, gathers the same columns of every rank (rank order), and goes on as in
+// mn_iqn_train_step with grad_scale * sum.  Two launches per step, no collective; bit-identical to mn_iqn_train_grad* + mn_iqn_train_exchange +
+// mn_iqn_train_adam(grad_rewritten = 2).  (The workspace need not be attached with mn_xchg_attach for this path: the forward / backward
+// launch's stand-alone reduction kernel is not used.)
+extern "C" int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                                      const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev,
+                                      const float *taus_target_dev, const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                                      const float *params_target, float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                                      int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
+                                      double eps, double max_norm, float grad_scale, void *stream) {
+    if (!x || !params_local || !exp_avg || !exp_avg_sq || !step_dev || !(grad_scale > 0.f)) return MN_ERR_INVALID;
+    XchgPeers peers;
+    for (int r = 0; r <= XCHG_MAX_RANKS; ++r) peers.mb[r] = nullptr;
+    for (int r = 0; r < x->world; ++r) {
+        peers.mb[r] = x->peer[r];
+        if (!peers.mb[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
+    }
+    peers.mb[x->world] = x->own;
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, &peers, x->world, grad_scale, x->status};
+    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
+                       rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
+                       grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags & ~MN_TRAIN_ONE_LAUNCH, stream, &adam);
 }

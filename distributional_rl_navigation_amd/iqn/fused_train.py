@@ -169,10 +169,8 @@ class FusedTrainer:
             flags = 2 | (1 if key == self._staged_key else 0)
         if self._two_launches():      # forward / backward, then reduction + clip + Adam in ONE launch (mn_iqn_train_step): bit-identical
             flags |= 4 if getattr(ag, "one_launch_step", False) else 0      # MN_TRAIN_ONE_LAUNCH: ... as a third role of the SAME launch
-            rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size), _p(self.rng_state), None, None, None,
-                                     _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target), _p(self._workspace(batch)), _p(self.grad),
-                                     _p(self.loss), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev), batch, ag.N, C.c_float(ag.GAMMA ** ag.n_step), flags,
-                                     C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5), stream)
+            rc = self._step_call((states, next_states, actions, rewards, dones), ring_size, self.rng_state, None, None, None, self._idx[batch],
+                                 self._taus[batch], batch, flags, stream)
         else:
             rc = L.mn_iqn_train_grad_sampled(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size),
                                              _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]), _p(self.local), _p(self.target),
@@ -187,9 +185,32 @@ class FusedTrainer:
         return self._finish_step(batch)
 
     def _two_launches(self):
-        """A single learner's step is two launches (mn_iqn_train_step); a shared learner puts its all-reduce / exchange between the gradient and
-        the Adam launch and keeps three.  `agent.two_launch_step = False` selects the three-launch path (A / B measurements, tests)."""
-        return not self.agent.distributed and getattr(self.agent, "two_launch_step", True)
+        """A single learner's step is two launches (mn_iqn_train_step); so is a shared learner's with the mailbox exchange (the exchange happens
+        inside the reduction + Adam launch, mn_iqn_train_step_xchg); with an RCCL all-reduce between the gradient and Adam it stays three.
+        `agent.two_launch_step = False` selects the three-launch paths (A / B measurements, tests)."""
+        ag = self.agent
+        if not getattr(ag, "two_launch_step", True):
+            return False
+        if not ag.distributed:
+            return True
+        return getattr(ag, "exchange", "collective") == "mailbox" and getattr(ag, "exchange_fused_adam", True)
+
+    def _step_call(self, ring5, ring_size, rng, idx, tt, tl, idx_out, taus_out, batch, flags, stream):
+        """mn_iqn_train_step / mn_iqn_train_step_xchg with this trainer's buffers."""
+        ag, L = self.agent, _capi.lib()
+        states, next_states, actions, rewards, dones = ring5
+        q = lambda t: _p(t) if t is not None else None
+        common = (q(states), q(next_states), q(actions), q(rewards), q(dones), int(ring_size), q(rng), q(idx), q(tt), q(tl), q(idx_out), q(taus_out),
+                  _p(self.local), _p(self.target), _p(self._workspace(batch)), _p(self.grad), _p(self.loss), _p(self.exp_avg), _p(self.exp_avg_sq),
+                  _p(self.step_dev), batch, ag.N, C.c_float(ag.GAMMA ** ag.n_step), flags, C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999),
+                  C.c_double(1e-8), C.c_double(0.5))
+        if ag.distributed:
+            mb = self._mailbox
+            if mb is None:
+                from .mailbox import MailboxExchange
+                mb = self._mailbox = MailboxExchange(self.device)
+            return L.mn_iqn_train_step_xchg(mb.h, *common, C.c_float(1.0 / mb.world), stream)
+        return L.mn_iqn_train_step(*common, stream)
 
     def graphed_steps(self, ring, ring_size, batch, n_steps):
         """`n_steps` x step_sampled as ONE hipGraph launch (captured on first use, re-captured when the ring's tensors / size, the
@@ -246,10 +267,8 @@ class FusedTrainer:
         L = _capi.lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self._two_launches():
-            rc = L.mn_iqn_train_step(_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), 0, None, _p(idx), _p(tt), _p(tl), None, None,
-                                     _p(self.local), _p(self.target), _p(self._workspace(B)), _p(self.grad), _p(self.loss), _p(self.exp_avg),
-                                     _p(self.exp_avg_sq), _p(self.step_dev), B, ag.N, C.c_float(ag.GAMMA ** ag.n_step), 4 if getattr(ag, "one_launch_step", False) else 0,
-                                     C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5), stream)
+            rc = self._step_call((states, next_states, actions, rewards, dones), 0, None, idx, tt, tl, None, None, B,
+                                 4 if getattr(ag, "one_launch_step", False) else 0, stream)
             if rc:
                 raise _capi.MarineNavHipError(f"mn_iqn_train_step failed ({rc})")
             weights_changed(ag.qnetwork_local)

@@ -436,6 +436,15 @@ int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t bat
  * learner's gradient step is then three launches, like an independent learner's. */
 int mn_iqn_train_exchange_adam(mn_xchg *x, float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
                                int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, float grad_scale, void *stream);
+/* mn_iqn_train_step for a SHARED learner: the exchange happens INSIDE the reduction + clip + Adam launch (every Adam block publishes its 64
+ * reduced columns into this rank's mailbox, gathers the same columns of every rank in rank order and continues with grad_scale x the sum).  Two
+ * launches per gradient step, like a single learner's; bit-identical to the four-launch sequence above.  Arguments as mn_iqn_train_step. */
+int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
+                           const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev,
+                           const float *taus_target_dev, const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                           const float *params_target, float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq,
+                           int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
+                           double eps, double max_norm, float grad_scale, void *stream);
 int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
 int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out

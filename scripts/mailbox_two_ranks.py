@@ -1,5 +1,5 @@
 """Two ranks (two processes on ONE GPU) x 12 gradient steps of a shared learner through each gradient transport -- the all-reduce path (bucket over gloo),
-the mailbox exchange fused with Adam ("mailbox"), the mailbox exchange as its own launch ("mailbox2") -- printing whether the ranks stayed bit-identical, the
+the mailbox exchange inside the reduction + Adam launch ("mailbox"), fused with Adam only ("mailbox3"), as its own launch ("mailbox4") -- printing whether the ranks stayed bit-identical, the
 granule timeouts and the checksum of the parameters (equal across the transports).  Debugging aid for tests/test_multigpu_paths_gpu.py."""
 import os, sys, subprocess, socket, tempfile
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -9,7 +9,7 @@ import test_multigpu_paths_gpu as T
 d = tempfile.mkdtemp()
 script = os.path.join(d, "worker.py")
 open(script, "w").write(T._TWO_RANK_WORKER)
-for mode in ("mailbox2", "mailbox", "mailbox2", "collective"):
+for mode in ("mailbox", "mailbox3", "mailbox4", "collective"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     out = os.path.join(d, mode + ".pt")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

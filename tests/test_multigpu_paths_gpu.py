@@ -83,13 +83,16 @@ from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 rank, port, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
 exchange = sys.argv[5] if len(sys.argv) > 5 else "collective"
 n_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-fused_adam = exchange != "mailbox2"      # "mailbox": gather + Adam in one launch; "mailbox2": mn_iqn_train_exchange, then mn_iqn_train_adam
+# "mailbox": the exchange inside the reduction + Adam launch (mn_iqn_train_step_xchg: two launches per step); "mailbox3": reduction (publishes), then gather +
+# Adam in one launch (mn_iqn_train_exchange_adam); "mailbox4": reduction, mn_iqn_train_exchange, mn_iqn_train_adam
+fused_adam, two_launch = exchange != "mailbox4", exchange == "mailbox"
 exchange = "mailbox" if exchange.startswith("mailbox") else exchange
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
 dev = "cuda:0"
 agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, device=dev, seed=3, distributed=True, rank=rank)
 agent.exchange = exchange      # "collective": the bucket travels over gloo; "mailbox": IPC-mapped mailboxes, gloo only carries the handles
 agent.exchange_fused_adam = fused_adam
+agent.two_launch_step = two_launch or exchange != "mailbox"
 assert agent.use_fused_train
 for step in range(n_steps):
     tt, tl = _taus(torch, 10 * step + rank, 32, dev)
@@ -147,10 +150,12 @@ def test_mailbox_exchange_two_ranks_equals_the_all_reduce_path_bitwise(torch, tm
     kernel -- no collective.  Same batches through the all-reduce path (bucket over gloo): parameters bit-identical after 12 steps,
     ranks bit-identical to each other, no granule timed out."""
     a = _two_rank_run(torch, tmp_path, "collective", "collective", 12)
-    b = _two_rank_run(torch, tmp_path, "mailbox", "mailbox", 12)        # exchange + clip + Adam as one launch (mn_iqn_train_exchange_adam)
-    c = _two_rank_run(torch, tmp_path, "mailbox2", "mailbox2", 12)      # mn_iqn_train_exchange, then mn_iqn_train_adam
-    assert a["same"] and b["same"] and c["same"] and b["timeouts"] == 0 and c["timeouts"] == 0
-    assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], c["params"])
+    b = _two_rank_run(torch, tmp_path, "mailbox", "mailbox", 12)        # two launches per step: the exchange inside the reduction + Adam launch
+    c = _two_rank_run(torch, tmp_path, "mailbox3", "mailbox3", 12)      # three: reduction (publishes), then gather + clip + Adam
+    d = _two_rank_run(torch, tmp_path, "mailbox4", "mailbox4", 12)      # four: reduction, mn_iqn_train_exchange, mn_iqn_train_adam
+    for r in (a, b, c, d):
+        assert r["same"] and r["timeouts"] == 0
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], c["params"]) and torch.equal(a["params"], d["params"])
 
 
 def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graphed(torch):
@@ -160,10 +165,11 @@ def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graph
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         runs = []
-        for distributed, graphed, fused in ((False, False, True), (True, False, True), (True, True, True), (True, False, False), (True, True, False)):
+        for distributed, graphed, fused, two in ((False, False, True, True), (True, False, True, True), (True, True, True, True), (True, False, True, False),
+                                                 (True, False, False, False), (True, True, False, False)):
             ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
             ag.exchange = "mailbox"
-            ag.exchange_fused_adam = fused
+            ag.exchange_fused_adam, ag.two_launch_step = fused, two
             ag.use_fused_graph = graphed
             ag.memory.add_batch(*_batch(torch, 7, 300, dev))
             losses = [float(ag.train_steps_from_memory(8)) for _ in range(3)]
