@@ -107,11 +107,15 @@ struct PassBufs { float *c, *h1, *x, *h2, *h3, *feat, *q; };
 #ifdef MN_TRAIN_PHASES
 __device__ unsigned long long g_phase[2][32];
 __device__ unsigned long long g_phase2[2][2][8];      // [reduce, adam][block 0, a middle block][stamp]
+__device__ unsigned long long g_wgt[1024][2];         // every forward / backward workgroup: start, end
+__device__ unsigned long long g_phase3[3][8];         // reduction + Adam blocks (fused launch or third role): first, middle, last block
 #define PH2(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) g_phase2[kern][blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
+#define PH3(k) do { if (threadIdx.x == 0 && (vb == 0 || vb == nvb / 2 || vb == nvb - 1)) g_phase3[vb == 0 ? 0 : (vb == nvb - 1 ? 2 : 1)][k] = wall_clock64(); } while (0)
 #define PH(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_phase[blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
 #else
 #define PH(k) do { } while (0)
 #define PH2(kern, k) do { } while (0)
+#define PH3(k) do { } while (0)
 #endif
 
 // ---- MFMA tile primitives --------------------------------------------------------------------------------------------
@@ -232,7 +236,12 @@ __device__ __forceinline__ void rows_gemm_fixed_b(const float *A, int lda, const
 #endif
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc, int float_off, const f32x4 &v) {
+__device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc, int float_off, const f32x4 &v, bool wt = false) {
+    if (wt) {      // one-launch step: write-through at agent scope (sc1) -- the row is read by other XCDs' workgroups of THIS launch, and the
+                   // "row complete" word behind it then needs no L2 write-back, only the stores' acknowledgements (s_waitcnt vmcnt(0))
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, 16);
+        return;
+    }
 #if MN_PSTORE == 0
     *reinterpret_cast<f32x4 *>(base + float_off) = v;
 #elif MN_PSTORE == 1
@@ -246,7 +255,10 @@ __device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc
 
 // the small rest of a partial row (biases, output layer, encoders: 15 % of it) goes out as plain stores: non-temporal 4-byte
 // stores measured slower (39.4 vs 37.0 us per step), as did non-temporal loads in the reduction (42.8)
-__device__ __forceinline__ void pstore1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void pstore1(float *p, float v, bool wt = false) {
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 
 // ---- the batch draw ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser (Steele, Lea, Flood 2014)
@@ -581,6 +593,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
         if (vb == 0 && tid == 0) loss_out[0] = __builtin_nanf("");
         return;
     }
+    PH3(0);
     const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);      // the epoch this step ends with
     // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
     const int p = vb * 256 + tid;
@@ -609,35 +622,51 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     }
     const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
     bool late = false;
-    if (done) {      // wait for this segment's rows (one wavefront = one segment: lane i watches row w0 + i, + 64, ...)
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            bool ok = true;
-            for (int w = w0 + (tid & 63); w < w1; w += 64) ok = ok && __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == done_tag;
-            if (__all(ok)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-            __builtin_amdgcn_s_sleep(4);
+    if (done) {      // wait for the rows: ONE wavefront per block polls all n_part words (lane i watches rows i, i + 64, ...), every ~0.5 us.  (Eight
+                     // polling wavefronts per block without a pause saturated the memory channel of the words and delayed the stores behind them.)
+        if (tid < 64) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+                for (int w = tid; w < n_part; w += 64) ok = ok && __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == done_tag;
+                if (__all(ok)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // nothing cached before the rows were complete is used below
-        __syncthreads();                                                              // ... and every row (the loss partials) is complete for every wave
+        late = __syncthreads_or(late);      // every row (and loss partial) is complete, for every wave
     }
+    PH3(1);
+    // Third role: the rows were written (through, at agent scope) by workgroups of this launch on other XCDs, and this XCD's L2 may still hold
+    // last step's copies of them.  They are read with agent-scope (sc1) loads, which do not hit such lines -- not behind an acquire fence:
+    // buffer_inv sc1 by 17 blocks per XCD, one after the other, cost 9 us of the first one-launch form.
     float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
     if (vb == 0 && tid < 256)
-        for (int wq = tid; wq < n_part; wq += 256) lpart += ws[ws_loss(n_part) + wq];
+        for (int wq = tid; wq < n_part; wq += 256)
+            lpart += done ? __hip_atomic_load(ws + ws_loss(n_part) + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ws[ws_loss(n_part) + wq];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
+        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
         for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
             float4 t[RED_MAX_PER];
+            if (done) {
 #pragma unroll
-            for (int u = 0; u < RED_MAX_PER; ++u)
-                t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < RED_MAX_PER; ++u)
+                    t[u] = wb + u < w1 ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((wb + u) * N_COLS + col) * 16, 0, 16))
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int u = 0; u < RED_MAX_PER; ++u)
+                    t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
             for (int u = 0; u < RED_MAX_PER; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
         }
     }
     red[seg][cx] = acc;
     __syncthreads();
+    PH3(2);
     if (seg == 0) {
         float4 s = red[0][cx];
 #pragma unroll
@@ -704,6 +733,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
             }
             part += __uint_as_float((uint32_t)x);
         }
+    PH3(3);
     int t_step = 0;
     if (tid == 255) {
         t_step = *step + 1;
@@ -732,6 +762,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     // the block that finishes LAST advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
     // (every block read all of them before taking its ticket)
     __syncthreads();
+    PH3(4);
     if (tid == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -803,6 +834,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
 #ifdef MN_TRAIN_PHASES
     const int ph_local = two_roles ? n_part : 0;
+    if (threadIdx.x == 0) g_wgt[blockIdx.x][0] = wall_clock64();
 #endif
     PH(0);
     const bool is_target = two_roles && (int)blockIdx.x < n_part;        // target workgroups come FIRST in dispatch order:
@@ -918,6 +950,9 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         }
         PH(7);   /* granules published */
         if (blockIdx.x == 0) write_batch_copies(ba, base, batch);
+#ifdef MN_TRAIN_PHASES
+        if (threadIdx.x == 0) g_wgt[blockIdx.x][1] = wall_clock64();
+#endif
         return;
     }
 
@@ -977,6 +1012,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
     float *out = ws + (size_t)part * P_PAD;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
+    const bool wt = tail.n_wg != 0;      // one-launch step: every store of the row goes through to memory (agent scope)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int t = tid + THREADS * e, r = t >> 6, k = t & 63, be = r >> 3;
@@ -1004,7 +1040,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     if (tid == 0) {
         float l = 0.f;
         for (int r = 0; r < ROWS; ++r) l += S[S_MISC + 2 * BE + r];
-        ws[ws_loss(n_part) + part] = l;
+        pstore1(ws + ws_loss(n_part) + part, l, wt);
     }
 
     // ---- backward (all 8 waves)
@@ -1022,7 +1058,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // ends up with four consecutive input columns per lane and tile
         const int mo = wave - 4;
         rows_gemm_fixed_b<4>(S + S_H2, LDC, S + S_DH3 + mo * 16, LDC, 0, 1, 4, [&](int nk, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W3 + (mo * 16 + i) * H + nk * 16 + 4 * g, acc);
+            pstore4(out, out_rsrc, O_W3 + (mo * 16 + i) * H + nk * 16 + 4 * g, acc, wt);
         });
     }
     for (int e = tid; e < NA * H + NA + H; e += THREADS) {   // dW4, db4, db3
@@ -1031,16 +1067,16 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             const int a = e >> 6, k = e & 63;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r] * S[S_H3 + r * LDC + k];
-            pstore1(out + O_W4 + e, v);
+            pstore1(out + O_W4 + e, v, wt);
         } else if (e < NA * H + NA) {
             const int a = e - NA * H;
             for (int r = 0; r < ROWS; ++r)
                 if (s_act[r >> 3] == a) v += S[S_G + r];
-            pstore1(out + O_B4 + a, v);
+            pstore1(out + O_B4 + a, v, wt);
         } else {
             const int k = e - NA * H - NA;
             for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + k];
-            pstore1(out + O_B3 + k, v);
+            pstore1(out + O_B3 + k, v, wt);
         }
     }
     __syncthreads();
@@ -1061,13 +1097,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // acc[r] = dW2[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int mo = wave & 3;
         rows_gemm_fixed_b<7>(S + S_X, LDF, S + S_DH2 + mo * 16, LDC, wave >> 2, 2, NT1, [&](int nk, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W2 + (mo * 16 + i) * F + nk * 16 + 4 * g, acc);
+            pstore4(out, out_rsrc, O_W2 + (mo * 16 + i) * F + nk * 16 + 4 * g, acc, wt);
         });
     }
     if (tid < H) {
         float v = 0.f;
         for (int r = 0; r < ROWS; ++r) v += S[S_DH2 + r * LDC + tid];
-        pstore1(out + O_B2 + tid, v);
+        pstore1(out + O_B2 + tid, v, wt);
     }
     __syncthreads();
     PH(11);  /* dx, dW2 */
@@ -1091,37 +1127,56 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // acc[r] = dW1[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int nk = wave & 3;
         rows_gemm_fixed_a<7>(S + S_C + nk * 16, LDC, S + S_DX, LDF, wave >> 2, 2, NT1, [&](int mo, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g, acc);
+            pstore4(out, out_rsrc, O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g, acc, wt);
         });
     }
     if (tid < F) {
         float v = 0.f;
         for (int r = 0; r < ROWS; ++r) v += S[S_DX + r * LDF + tid];
-        pstore1(out + O_B1 + tid, v);
+        pstore1(out + O_B1 + tid, v, wt);
     } else if (tid >= 256 && tid < 256 + F) {
         // encoders: dW = df^T obs, db = sum df
         const int o = tid - 256;
         const float d0 = S[S_DF + o], d1 = S[S_DF + F + o];
         const float *x0 = S + S_OBS, *x1 = S + S_OBS + 28;
         if (o < 16) {
-            for (int k = 0; k < 2; ++k) pstore1(out + O_VW + o * 2 + k, d0 * x0[k] + d1 * x1[k]);
-            pstore1(out + O_VB + o, d0 + d1);
+            for (int k = 0; k < 2; ++k) pstore1(out + O_VW + o * 2 + k, d0 * x0[k] + d1 * x1[k], wt);
+            pstore1(out + O_VB + o, d0 + d1, wt);
         } else if (o < 32) {
-            for (int k = 0; k < 2; ++k) pstore1(out + O_GW + (o - 16) * 2 + k, d0 * x0[2 + k] + d1 * x1[2 + k]);
-            pstore1(out + O_GB + o - 16, d0 + d1);
+            for (int k = 0; k < 2; ++k) pstore1(out + O_GW + (o - 16) * 2 + k, d0 * x0[2 + k] + d1 * x1[2 + k], wt);
+            pstore1(out + O_GB + o - 16, d0 + d1, wt);
         } else {
-            for (int k = 0; k < 22; ++k) pstore1(out + O_SW + (o - 32) * 22 + k, d0 * x0[4 + k] + d1 * x1[4 + k]);
-            pstore1(out + O_SB + o - 32, d0 + d1);
+            pstore1(out + O_SB + o - 32, d0 + d1, wt);
         }
     }
-    if (tid < P_PAD - P_TOTAL) out[P_TOTAL + tid] = 0.f;   // row padding: read (as zeros) by the reduction's 16-byte loads
+    {   // sensor encoder dW [176 x 22] = 968 contiguous 16-byte pieces, one or two per thread (round 4: was 22 four-byte stores per lane at an
+        // 88-byte stride -- 22 partial lines per lane, which write-through stores send to memory one by one); element (o, k) as before
+        const float *x0 = S + S_OBS, *x1 = S + S_OBS + 28;
+        for (int q = tid; q < 176 * 22 / 4; q += THREADS) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * q + c, o = 32 + e / 22, k = e % 22;
+                v[c] = S[S_DF + o] * x0[4 + k] + S[S_DF + F + o] * x1[4 + k];
+            }
+            pstore4(out, out_rsrc, O_SW + 4 * q, v, wt);
+        }
+    }
+    if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
     if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
     if (tail.n_wg) {      // one-launch step: this workgroup's row (and loss partial) is final -- tell the reduction blocks of this launch
-        __threadfence();
+        // every store of the row was a write-through one: once they are acknowledged the row is in memory, and nothing of it sits dirty in
+        // this XCD's L2 -- no __threadfence() (= an L2 write-back per workgroup, which made the first one-launch form 2.5 x slower)
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
+        PH(17);
         if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_done(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef MN_TRAIN_PHASES
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0) g_wgt[blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 // grad[p] = sum over workgroups of partial[wg][p].  One thread = one float4 column of one of RED_SEG contiguous segments of the
@@ -1505,6 +1560,12 @@ int g_train_mode = MODE_TWO_ROLES;
 #ifdef MN_TRAIN_PHASES
 extern "C" int mn_iqn_train_debug_phases(unsigned long long *out_host) {   // [2][32]: target workgroup 0, first local workgroup
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+extern "C" int mn_iqn_train_debug_wgt(unsigned long long *out_host) {   // [1024][2]: start, end of every forward / backward workgroup
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wgt), sizeof(unsigned long long) * 2048) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+extern "C" int mn_iqn_train_debug_phases3(unsigned long long *out_host) {   // [first, middle, last reduction + Adam block][8]
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase3), sizeof(unsigned long long) * 24) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 extern "C" int mn_iqn_train_debug_phases2(unsigned long long *out_host) {   // [reduce, adam][block 0, middle block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase2), sizeof(unsigned long long) * 32) == hipSuccess ? MN_OK : MN_ERR_HIP;
