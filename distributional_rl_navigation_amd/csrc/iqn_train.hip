@@ -599,6 +599,8 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     const int p = vb * 256 + tid;
     float mp = 0.f, vp = 0.f, pp = 0.f;
     if (tid < 256 && p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
+    int t_step = 0;
+    if (tid == RA_BT - 1) t_step = *step + 1;
     // staging of the NEXT step's batch (see iqn_grad_reduce): a pure copy, any thread mapping does
     constexpr int SPB = RA_BT / STG;
     const int batch = n_part * BE;
@@ -719,6 +721,12 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
         }
     }
     if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
+    // Adam's bias corrections (two float64 pow: ~500 instructions) by a thread of the last wave, which has nothing else to do while waves 0-3 poll the
+    // norm partials -- not behind the poll, and not in front of the barrier the partials are published behind; read after the barrier that follows the poll
+    if (tid == RA_BT - 1) {
+        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
+    }
     // ---- clip + Adam (iqn_adam's body) on the 280 partials, polled: the data is the flag
     float part = 0.f;
     if (tid < 256)
@@ -734,12 +742,6 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
             part += __uint_as_float((uint32_t)x);
         }
     PH3(3);
-    int t_step = 0;
-    if (tid == 255) {
-        t_step = *step + 1;
-        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
-        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (tid < 256 && (tid & 63) == 0) nred[tid >> 6] = part;
