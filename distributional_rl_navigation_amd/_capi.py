@@ -110,6 +110,7 @@ SIGNATURES = [
     ("mn_iqn_act_rng", C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _i32, _i32, _vp]),
     ("mn_replay_append", C.c_int, [_vp] * 10 + [_i64, _i64, _i64, _vp]),
     ("mn_iqn_train_workspace_floats", C.c_int64, [_i32]),
+    ("mn_iqn_train_workspace_misplaced_word", C.c_int64, [_i32]),
     ("mn_iqn_sample", C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     ("mn_iqn_train_grad", C.c_int, [_vp] * 13 + [_i32, _i32, C.c_float, _vp]),
     ("mn_iqn_train_grad_sampled", C.c_int, [_vp] * 5 + [_i64] + [_vp] * 8 + [_i32, _i32, C.c_float, _i32, _vp]),

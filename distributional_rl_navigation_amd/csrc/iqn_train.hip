@@ -44,6 +44,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "marinenav_hip.h"
@@ -107,7 +108,7 @@ struct PassBufs { float *c, *h1, *x, *h2, *h3, *feat, *q; };
 #ifdef MN_TRAIN_PHASES
 __device__ unsigned long long g_phase[2][32];
 __device__ unsigned long long g_phase2[2][2][8];      // [reduce, adam][block 0, a middle block][stamp]
-__device__ unsigned long long g_wgt[1024][2];         // every forward / backward workgroup: start, end
+__device__ unsigned long long g_wgt[1024][4];         // every forward / backward workgroup: start, end, row acknowledged, group flags seen
 __device__ unsigned long long g_phase3[3][8];         // reduction + Adam blocks (fused launch or third role): first, middle, last block
 #define PH2(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) g_phase2[kern][blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
 #define PH3(k) do { if (threadIdx.x == 0 && (vb == 0 || vb == nvb / 2 || vb == nvb - 1)) g_phase3[vb == 0 ? 0 : (vb == nvb - 1 ? 2 : 1)][k] = wall_clock64(); } while (0)
@@ -236,7 +237,14 @@ __device__ __forceinline__ void rows_gemm_fixed_b(const float *A, int lda, const
 #endif
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc, int float_off, const f32x4 &v, bool wt = false) {
+#ifndef MN_HIER_STORE
+#define MN_HIER_STORE 0
+#endif
+__device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc, int float_off, const f32x4 &v, bool wt = false, bool keep = false) {
+    if (keep) {    // XCD-grouped one-launch step: the row is read back through this XCD's L2 a few microseconds from now -- an ordinary store
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, MN_HIER_STORE);
+        return;
+    }
     if (wt) {      // one-launch step: write-through at agent scope (sc1) -- the row is read by other XCDs' workgroups of THIS launch, and the
                    // "row complete" word behind it then needs no L2 write-back, only the stores' acknowledgements (s_waitcnt vmcnt(0))
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rsrc, float_off * 4, 0, 16);
@@ -498,13 +506,27 @@ __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part)
 __host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
 __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
-// [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] unused,
+// [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] count of local workgroups of
+// XCD-grouped one-launch steps that did not run on the XCD of their group's first workgroup (u32, diagnostic: their rows took the slow way through memory),
 // [10..11] device pointer (u64) of this rank's gradient mailbox, 0 = none (mn_xchg_attach: the reduction kernel publishes into it)
 // [12 ..] N_RED self-tagged norm partials (u64) of the fused reduction + Adam launch (iqn_grad_reduce_adam)
 __host__ __device__ constexpr int64_t ws_xsq(int n_part) { return ws_epoch(n_part) + 12; }
-// then n_part "row complete" words (u32 step tags) of the one-launch step: workgroup w's partial-gradient row and loss partial are final
+// then, for the one-launch step:
+//   ws_done   n_part "row complete" words (u64 {step tag, flags}, agent scope: workgroup w's partial-gradient row is final; flag bit 0 = the row was written
+//             through to memory because the workgroup did not run on XCD (block index % 8))
+//   ws_gdone  n_part u32 step tags of the UNGROUPED form (workgroup w's row and loss partial are in memory)
+//   ws_lflag  8 x 64 u32 step tags, one 256-byte block per XCD group: the same "row complete" news for the workgroups of the same XCD, through that
+//             XCD's L2 (ordinary store, sc0 load) -- a third of the latency of the word in memory
+//   ws_lossq  n_part self-tagged loss partials (u64 {step tag, value}) of the grouped form
+//   ws_xcc    n_part u64 {step tag, XCC_ID}: where each local workgroup runs, published when it starts (the first workgroup of a group defines the group's XCD)
+//   ws_grp    the eight group rows (sum of the rows w = x mod 8) as self-tagged 8-byte granules {step tag, value}: [8][P_PAD] u64 -- the data is the flag
 __host__ __device__ constexpr int64_t ws_done(int n_part) { return ws_xsq(n_part) + 2 * N_RED; }
-__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_done(n_part) + pad4(n_part); }
+__host__ __device__ constexpr int64_t ws_gdone(int n_part) { return ws_done(n_part) + pad4(2 * n_part); }
+__host__ __device__ constexpr int64_t ws_lflag(int n_part) { return ws_gdone(n_part) + pad4(n_part); }
+__host__ __device__ constexpr int64_t ws_lossq(int n_part) { return ws_lflag(n_part) + 8 * 64; }
+__host__ __device__ constexpr int64_t ws_xcc(int n_part) { return ws_lossq(n_part) + pad4(2 * n_part); }
+__host__ __device__ constexpr int64_t ws_grp(int n_part) { return ws_xcc(n_part) + pad4(2 * n_part); }
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_grp(n_part) + 2 * (int64_t)RED_SEG * P_PAD; }
 constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
@@ -581,7 +603,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
                                                  float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
                                                  float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
                                                  double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag,
-                                                 const XchgPeers *peers = nullptr, int world = 1, float grad_scale = 1.0f) {
+                                                 const XchgPeers *peers = nullptr, int world = 1, float grad_scale = 1.0f, bool grouped = false) {
     __shared__ float4 red[RED_SEG][RA_COLS];
     __shared__ float sq[RA_COLS];
     __shared__ float gsh[4 * RA_COLS];
@@ -622,10 +644,12 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
         else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
         else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
     }
-    const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
+    // Segment `seg` of a column = the rows w = seg (mod RED_SEG), ascending (round 4; was: RED_SEG contiguous blocks of rows) -- the rows whose
+    // workgroups share an XCD (block index % 8), which is what lets the one-launch step sum a segment inside that XCD's L2 (`grouped`: the eight
+    // segment sums are already formed, in ws_grp; one row per segment is left to read).  Same order in every path: all of them stay bit-identical.
     bool late = false;
-    if (done) {      // wait for the rows: ONE wavefront per block polls all n_part words (lane i watches rows i, i + 64, ...), every ~0.5 us.  (Eight
-                     // polling wavefronts per block without a pause saturated the memory channel of the words and delayed the stores behind them.)
+    if (done && !grouped) {      // wait for the rows: ONE wavefront per block polls all n_part words (lane i watches rows i, i + 64, ...), every ~0.5 us.  (Eight
+                                 // polling wavefronts per block without a pause saturated the memory channel of the words and delayed the stores behind them.)
         if (tid < 64) {
             const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
             for (;;) {
@@ -639,35 +663,86 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
         late = __syncthreads_or(late);      // every row (and loss partial) is complete, for every wave
     }
     PH3(1);
-    // Third role: the rows were written (through, at agent scope) by workgroups of this launch on other XCDs, and this XCD's L2 may still hold
-    // last step's copies of them.  They are read with agent-scope (sc1) loads, which do not hit such lines -- not behind an acquire fence:
-    // buffer_inv sc1 by 17 blocks per XCD, one after the other, cost 9 us of the first one-launch form.
     float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grouped) {
+        // XCD-grouped one-launch step: the eight segment sums arrive as self-tagged granules (group_reduce) -- thread (cx, seg) polls the four of
+        // column `col` of group row `seg`, block 0 the n_part loss partials.  No flag, no fence: the data is the flag.  (MN_TAIL_PREPOLL: one wavefront per
+        // block first watches the "row complete" words and only then does everybody look for the granules -- measured 0.6 us per step slower, off.)
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+#ifndef MN_TAIL_PREPOLL
+#define MN_TAIL_PREPOLL 0
+#endif
+        if (MN_TAIL_PREPOLL && tid < 64) {
+            const gu64 *rc = (const gu64 *)(ws + ws_done(n_part));
+            for (;;) {
+                bool ok = true;
+                for (int w = tid; w < n_part; w += 64) ok = ok && (uint32_t)(__hip_atomic_load(rc + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == done_tag;
+                if (__all(ok)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;      // (the granule polls below run into their own bound)
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+        __syncthreads();
+        if (vb == 0 && tid < 256) {
+            const gu64 *lq = (const gu64 *)(ws + ws_lossq(n_part));
+            for (int wq = tid; wq < n_part; wq += 256) {
+                uint64_t x;
+                for (;;) {
+                    x = __hip_atomic_load(lq + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(x >> 32) == done_tag) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                lpart += __uint_as_float((uint32_t)x);
+            }
+        }
+        if (col < N_COLS) {
+            const gu64 *g = (const gu64 *)(ws + ws_grp(n_part)) + (size_t)seg * P_PAD + 4 * col;
+            uint64_t x[4];
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(g + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ok = ok && (uint32_t)(x[q] >> 32) == done_tag;
+                if (ok) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            // (0 + G: the accumulator of the ungrouped paths starts at zero and adds its rows to it; x + 0 = x exactly, also for -0 since the sum of
+            // the group's rows was itself formed as 0 + ...)
+            acc = make_float4(__uint_as_float((uint32_t)x[0]), __uint_as_float((uint32_t)x[1]), __uint_as_float((uint32_t)x[2]), __uint_as_float((uint32_t)x[3]));
+        }
+    } else {
+    // Third role, ungrouped: the rows were written (through, at agent scope) by workgroups of this launch on other XCDs, and this XCD's L2 may still
+    // hold last step's copies of them.  They are read with agent-scope (sc1) loads, which do not hit such lines -- not behind an acquire fence:
+    // buffer_inv sc1 by 17 blocks per XCD, one after the other, cost 9 us of the first one-launch form.
     if (vb == 0 && tid < 256)
         for (int wq = tid; wq < n_part; wq += 256)
             lpart += done ? __hip_atomic_load(ws + ws_loss(n_part) + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ws[ws_loss(n_part) + wq];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
-        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
-        for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
+        for (int wb = seg; wb < n_part; wb += RED_SEG * RED_MAX_PER) {
             float4 t[RED_MAX_PER];
             if (done) {
 #pragma unroll
                 for (int u = 0; u < RED_MAX_PER; ++u)
-                    t[u] = wb + u < w1 ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((wb + u) * N_COLS + col) * 16, 0, 16))
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    t[u] = wb + RED_SEG * u < n_part ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((wb + RED_SEG * u) * N_COLS + col) * 16, 0, 16))
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
                 for (int u = 0; u < RED_MAX_PER; ++u)
-                    t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    t[u] = wb + RED_SEG * u < n_part ? src[(size_t)(wb + RED_SEG * u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < RED_MAX_PER; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
         }
     }
+    }
     red[seg][cx] = acc;
-    __syncthreads();
+    late = __syncthreads_or(late);      // (a bounded wait that ran out anywhere in the block poisons the block's output)
     PH3(2);
     if (seg == 0) {
         float4 s = red[0][cx];
@@ -803,12 +878,123 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
     (void)status;
 }
 
+// One-launch step, XCD-grouped (StepTail::hier): the local workgroups of group x = the rows w = x (mod 8) = the workgroups the dispatcher put on XCD x.
+// After its own row is complete a workgroup waits for the rows of its group, takes an equal share of the 8 947 16-byte columns and sums the group's
+// rows for them in ascending row order -- reading through the XCD's own L2 (sc0 loads: past this CU's vector cache, served by the L2 that acknowledged
+// the writers' stores) -- and writes that piece of the group row to ws_grp as self-tagged granules {step tag, value}, through to memory, where the
+// reduction + Adam blocks of every XCD poll them: the data is the flag.  18 MB of partial gradients never leave the L2s; 2.3 MB of granules do.
+// "Row complete" travels twice: as a word in memory (agent scope, with the "written through" flag), and -- from workgroups that are where they should
+// be -- as a word in the XCD's L2 (ordinary store, sc0 load), which is what the group normally sees first.  A row whose workgroup was NOT on XCD x was
+// written through and is read with sc1 loads; such a workgroup takes no share (it cannot see the others' rows) unless the whole group is like that.
+// The arithmetic does not depend on any of this.
+__device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part, int part, uint32_t tag, int tid) {
+    static_assert(RED_SEG == 8, "one segment per XCD");
+    __shared__ unsigned long long s_mis;
+    __shared__ int s_late;
+    const int x = part & 7, gi = part >> 3, gsz = n_part >> 3;      // n_part % 8 == 0, gsz <= 64 (MAX_BATCH / BE / 8)
+    const gu64 *done = (const gu64 *)(ws + ws_done(n_part));
+    if (tid < 64) {
+        bool have = tid >= gsz, mis_row = false, late = false;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        for (int it = 0;; ++it) {
+            if (!have) {
+#ifndef MN_LFLAG_POLL
+#define MN_LFLAG_POLL 2
+#endif
+#if MN_LFLAG_POLL == 0
+                const uint32_t lf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(lflag, 4 * tid, 0, 1);       // sc0
+#elif MN_LFLAG_POLL == 1
+                const uint32_t lf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(lflag, 4 * tid, 0, 16);      // sc1
+#else
+                uint32_t lf;      // an atomic OR of 0 with return: executed by the L2, whatever this CU's vector cache holds
+                {
+                    uint32_t *lp = reinterpret_cast<uint32_t *>(ws + ws_lflag(n_part) + 64 * x) + tid;
+                    const uint32_t zero = 0;
+                    asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(lf) : "v"(lp), "v"(zero) : "memory");
+                }
+#endif
+                if (lf == tag) have = true;
+                else if ((it & 3) == 3) {                                                                           // every fourth look: the word in memory
+                    const uint64_t v = __hip_atomic_load(done + x + 8 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(v >> 32) == tag) { have = true; mis_row = (v & 1u) != 0; }
+                }
+            }
+            if (__all(have)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long mis = __ballot(mis_row);
+        if (tid == 0) { s_mis = mis; s_late = late; }
+    }
+    __syncthreads();
+#ifdef MN_TRAIN_PHASES
+    if (threadIdx.x == 0) g_wgt[blockIdx.x][3] = wall_clock64();
+#endif
+    const unsigned long long all = gsz == 64 ? ~0ull : ((1ull << gsz) - 1ull), mis = s_mis & all, well = ~mis & all;
+    const unsigned long long takers = well ? well : all;      // nobody where it should be: every row is in memory, everybody can read them
+    if (!((takers >> gi) & 1ull)) return;
+    const int rank = __popcll(takers & ((1ull << gi) - 1ull)), n_takers = __popcll(takers);
+    const int per = (N_COLS + n_takers - 1) / n_takers, c0 = rank * per, c1 = min(N_COLS, c0 + per);
+    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)x * P_PAD, 0, P_PAD * 8, 0x00020000);
+    const bool poison = s_late != 0;      // a row never arrived (bounded wait): the step must not look valid
+    auto put = [&](int c, float4 acc) {      // column c of the group row: four self-tagged granules, two per 16-byte store, written through (sc1)
+        if (poison) acc.x = __builtin_nanf("");
+        const u32x4s lo = {__float_as_uint(acc.x), tag, __float_as_uint(acc.y), tag}, hi = {__float_as_uint(acc.z), tag, __float_as_uint(acc.w), tag};
+        __builtin_amdgcn_raw_buffer_store_b128(lo, grp, c * 32, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, grp, c * 32 + 16, 0, 16);
+    };
+#ifndef MN_GROUP_FAST
+#define MN_GROUP_FAST 1
+#endif
+    if (MN_GROUP_FAST && mis == 0 && gsz == 16) {
+        // The case that runs (batch 256, every workgroup on its XCD): straight-line code, all of a thread's loads in flight before its first add.  With 16
+        // takers a share is 560 columns -- 48 threads have a second one (the others all read column c0 again and drop it: no branch between the loads, which
+        // would make the compiler wait for each load on its own, as it does in the general loop below).
+        const int ca = c0 + tid, cb = c0 + THREADS + tid, cb_eff = cb < c1 ? cb : c0;      // (c0 for all of them: one request per wave)
+        float4 t[2][16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[0][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, 1));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[1][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + cb_eff) * 16, 0, 1));
+        float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { acc[h].x += t[h][u].x; acc[h].y += t[h][u].y; acc[h].z += t[h][u].z; acc[h].w += t[h][u].w; }
+        if (ca < c1) put(ca, acc[0]);
+        if (cb < c1) put(cb, acc[1]);
+        for (int c = c0 + 2 * THREADS + tid; c < c1; c += THREADS) {      // (never with 16 takers)
+            float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < 16; ++u) {
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + c) * 16, 0, 1));
+                a2.x += v.x; a2.y += v.y; a2.z += v.z; a2.w += v.w;
+            }
+            put(c, a2);
+        }
+        return;
+    }
+    for (int c = c0 + tid; c < c1; c += THREADS) {      // any group size, any mix of rows in this L2 (sc0) and rows in memory (sc1)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < gsz; ++i) {
+            const int off = ((x + 8 * i) * N_COLS + c) * 16;
+            const float4 v = (mis >> i) & 1ull ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, off, 0, 16))
+                                               : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, off, 0, 1));
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        put(c, acc);
+    }
+}
+
 // The rest of the step as a THIRD ROLE of the forward / backward launch (n_wg > 0; round 4: one launch per gradient step): workgroups
 // [n_fwd, n_fwd + n_wg) are reduction + Adam blocks (reduce_adam_body).  They are dispatched after every forward / backward workgroup (higher
 // block indices), land on the CUs the target workgroups vacate half way through the launch, and wait there for the "row complete" words the local
 // workgroups write after their last partial-gradient store -- no launch boundary between the backward pass and the optimizer step.
 struct StepTail {
-    int n_wg;
+    int n_wg;           // reduction + Adam blocks launched behind the forward / backward workgroups
+    int n_virtual;      // ... of N_ADAM: the rest (when they would not all find a free CU before the local workgroups end) is run by the first local workgroups, after their own work
+    int hier;           // the rows of an XCD's workgroups are summed inside that XCD before anything crosses to the others (n_part % 8 == 0)
+    int misplace;       // test hook: pretend these local workgroups did not land on XCD (block index % 8): 1 = every fifth, 2 = all, 3 = all of group 3
     int prefetch_next;
     float *grad, *loss_out, *params, *m, *v;
     int32_t *step;
@@ -824,13 +1010,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int n_part = batch / BE;
     const bool two_roles = mode == MODE_TWO_ROLES;
-    if (tail.n_wg) {
+    if (tail.n_virtual) {
         const int n_fwd = two_roles ? 2 * n_part : n_part;
         if ((int)blockIdx.x >= n_fwd) {
             const uint32_t dtag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;      // = the hand-off tag below
-            reduce_adam_body((int)blockIdx.x - n_fwd, tail.n_wg, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
+            reduce_adam_body((int)blockIdx.x - n_fwd, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
                              tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm,
-                             reinterpret_cast<const uint32_t *>(ws + ws_done(n_part)), dtag);
+                             reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part)), dtag, nullptr, 1, 1.0f, tail.hier != 0);
             return;
         }
     }
@@ -846,6 +1032,11 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     // hand-off tag of this launch: never 0 (the workspace starts zero-filled), different from the previous launches' tags;
     // the epoch word is advanced by iqn_grad_reduce, i.e. between two launches of this kernel
     const uint32_t tag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;
+    if (tail.n_virtual && tail.hier && !is_target && tid == 0) {      // XCD-grouped one-launch step: where this local workgroup runs (see "local workgroup" below)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store((gu64 *)(ws + ws_xcc(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)(xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- The first requests of the kernel: (a) this workgroup's two batch slots as the previous step's reduction kernel STAGED them
     // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
@@ -959,6 +1150,17 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
 
     // ---- local workgroup
+    // XCD-grouped one-launch step: the rows w = x (mod 8) are summed inside one XCD's L2, so their workgroups have to share an XCD.  The dispatcher deals
+    // workgroups out to the XCDs round-robin (scripts/probes/xcc_placement.hip) -- from XCD 0 in a fresh process, from another one after other streams were
+    // in use -- so block index % 8 names a set of workgroups on ONE XCD, not which.  Each local workgroup publishes the XCD it runs on; a group's XCD is
+    // that of its first workgroup, whose word the others read here (long before they need it, behind the TD targets).
+    uint64_t lead_word = 0;
+    unsigned my_xcc = 0;
+    if (tail.n_virtual && tail.hier) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        my_xcc &= 15u;
+        if (tid == 0 && (part >> 3) != 0) lead_word = __hip_atomic_load((const gu64 *)(ws + ws_xcc(n_part)) + (part & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- TD targets: from the target workgroup of the same two batch elements (ready by now -- it ran the same forward at the same
     // time on another CU), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
     // dispatch makes impossible -- kept so that a wait can never hang the device)
@@ -1014,7 +1216,34 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
     float *out = ws + (size_t)part * P_PAD;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
-    const bool wt = tail.n_wg != 0;      // one-launch step: every store of the row goes through to memory (agent scope)
+    // One-launch step: the row is read by other workgroups of THIS launch.  XCD-grouped (tail.hier): by the workgroups of its group (block index % 8),
+    // which share an XCD, through that XCD's L2: ordinary stores.  A workgroup that is NOT on its group's XCD (never observed), and every workgroup
+    // of the ungrouped form, writes its row through to memory.
+    bool wellplaced = false;
+    if (tail.n_virtual && tail.hier) {
+        __shared__ int s_well;
+        if (tid == 0) {
+            const gu64 *lw = (const gu64 *)(ws + ws_xcc(n_part)) + (part & 7);
+            bool well = (part >> 3) == 0;      // the group's first workgroup is where the group is
+            if (!well) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while ((uint32_t)(lead_word >> 32) != tag && __builtin_amdgcn_s_memrealtime() - t0 < 100000ull)      // (1 ms; then: not with the group)
+                    lead_word = __hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                well = (uint32_t)(lead_word >> 32) == tag && (unsigned)(lead_word & 15u) == my_xcc;
+            }
+            const int gi = part >> 3;
+            if (tail.misplace == 1 && gi % 5 == 0 && gi) well = false;
+            if ((tail.misplace == 2 && gi) || (tail.misplace == 3 && (part & 7) == 3 && gi)) well = false;
+            s_well = well ? 1 : 0;
+        }
+        __syncthreads();
+        wellplaced = s_well != 0;
+    }
+    if (tail.n_virtual && tail.hier && !wellplaced && tid == 0)      // epoch block word [9]: local workgroups that found themselves on another XCD, ever (diagnostic)
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool wt = tail.n_virtual != 0 && !wellplaced;
+    const bool keep = tail.n_virtual != 0 && wellplaced;
+    const bool wt_loss = tail.n_virtual != 0;      // the loss partials are read by one block of the tail, wherever it runs
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int t = tid + THREADS * e, r = t >> 6, k = t & 63, be = r >> 3;
@@ -1042,7 +1271,9 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     if (tid == 0) {
         float l = 0.f;
         for (int r = 0; r < ROWS; ++r) l += S[S_MISC + 2 * BE + r];
-        pstore1(ws + ws_loss(n_part) + part, l, wt);
+        if (tail.n_virtual && tail.hier)      // grouped one-launch step: self-tagged, polled by the tail's block 0
+            __hip_atomic_store((gu64 *)(ws + ws_lossq(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else pstore1(ws + ws_loss(n_part) + part, l, wt_loss);
     }
 
     // ---- backward (all 8 waves)
@@ -1060,7 +1291,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // ends up with four consecutive input columns per lane and tile
         const int mo = wave - 4;
         rows_gemm_fixed_b<4>(S + S_H2, LDC, S + S_DH3 + mo * 16, LDC, 0, 1, 4, [&](int nk, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W3 + (mo * 16 + i) * H + nk * 16 + 4 * g, acc, wt);
+            pstore4(out, out_rsrc, O_W3 + (mo * 16 + i) * H + nk * 16 + 4 * g, acc, wt, keep);
         });
     }
     for (int e = tid; e < NA * H + NA + H; e += THREADS) {   // dW4, db4, db3
@@ -1099,7 +1330,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // acc[r] = dW2[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int mo = wave & 3;
         rows_gemm_fixed_b<7>(S + S_X, LDF, S + S_DH2 + mo * 16, LDC, wave >> 2, 2, NT1, [&](int nk, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W2 + (mo * 16 + i) * F + nk * 16 + 4 * g, acc, wt);
+            pstore4(out, out_rsrc, O_W2 + (mo * 16 + i) * F + nk * 16 + 4 * g, acc, wt, keep);
         });
     }
     if (tid < H) {
@@ -1129,7 +1360,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         // acc[r] = dW1[16 mo + i][16 nk + 4 g + r] -> one 16-byte store per lane and tile
         const int nk = wave & 3;
         rows_gemm_fixed_a<7>(S + S_C + nk * 16, LDC, S + S_DX, LDF, wave >> 2, 2, NT1, [&](int mo, const f32x4 &acc) {
-            pstore4(out, out_rsrc, O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g, acc, wt);
+            pstore4(out, out_rsrc, O_W1 + (mo * 16 + i) * NC + nk * 16 + 4 * g, acc, wt, keep);
         });
     }
     if (tid < F) {
@@ -1161,19 +1392,36 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
                 const int e = 4 * q + c, o = 32 + e / 22, k = e % 22;
                 v[c] = S[S_DF + o] * x0[4 + k] + S[S_DF + F + o] * x1[4 + k];
             }
-            pstore4(out, out_rsrc, O_SW + 4 * q, v, wt);
+            pstore4(out, out_rsrc, O_SW + 4 * q, v, wt, keep);
         }
     }
     if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
     if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
-    if (tail.n_wg) {      // one-launch step: this workgroup's row (and loss partial) is final -- tell the reduction blocks of this launch
-        // every store of the row was a write-through one: once they are acknowledged the row is in memory, and nothing of it sits dirty in
-        // this XCD's L2 -- no __threadfence() (= an L2 write-back per workgroup, which made the first one-launch form 2.5 x slower)
+    if (tail.n_virtual) {      // one-launch step: this workgroup's row (and loss partial) is final
+        // Its stores are acknowledged -- by memory if they were write-through ones, by this XCD's L2 otherwise -- once vmcnt is 0; nothing of a
+        // written-through row sits dirty in an L2: no __threadfence() (= an L2 write-back per workgroup, which made the first one-launch form 2.5 x slower)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         PH(17);
-        if (tid == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_done(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MN_TRAIN_PHASES
+        if (threadIdx.x == 0) g_wgt[blockIdx.x][2] = wall_clock64();
+#endif
+        if (tail.hier) {
+            if (tid == 0) {
+                if (wellplaced) *reinterpret_cast<volatile uint32_t *>(ws + ws_lflag(n_part) + 64 * (part & 7) + (part >> 3)) = tag;      // for this XCD's L2
+                __hip_atomic_store((gu64 *)(ws + ws_done(n_part)) + part, ((uint64_t)tag << 32) | (wellplaced ? 0u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to publish behind it)
+            PH(18);
+            // (MN_TAIL_EXTRA, measured 0.5 us per step slower, off: launch only as many reduction + Adam blocks as there are CUs before the local workgroups
+            // end, and let the first local workgroups run the rest here instead of leaving them to be dispatched behind them)
+            if (part < tail.n_virtual - tail.n_wg)
+                reduce_adam_body(tail.n_wg + part, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next, tail.params, tail.m,
+                                 tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, nullptr, tag, nullptr, 1, 1.0f, true);
+        } else if (tid == 0) {
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_gdone(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what the reduction + Adam blocks wait for
+        }
     }
 #ifdef MN_TRAIN_PHASES
     __builtin_amdgcn_s_waitcnt(0);
@@ -1227,15 +1475,14 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
         else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
     }
-    const int per = (n_part + RED_SEG - 1) / RED_SEG, w0 = seg * per, w1 = min(n_part, w0 + per);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // segment seg = the rows w = seg (mod RED_SEG), ascending (see reduce_adam_body)
     if (col < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
-        for (int wb = w0; wb < w1; wb += RED_MAX_PER) {
+        for (int wb = seg; wb < n_part; wb += RED_SEG * RED_MAX_PER) {
             float4 t[RED_MAX_PER];
 #pragma unroll
             for (int u = 0; u < RED_MAX_PER; ++u)
-                t[u] = wb + u < w1 ? src[(size_t)(wb + u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
+                t[u] = wb + RED_SEG * u < n_part ? src[(size_t)(wb + RED_SEG * u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < RED_MAX_PER; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
         }
@@ -1564,7 +1811,7 @@ extern "C" int mn_iqn_train_debug_phases(unsigned long long *out_host) {   // [2
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 extern "C" int mn_iqn_train_debug_wgt(unsigned long long *out_host) {   // [1024][2]: start, end of every forward / backward workgroup
-    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wgt), sizeof(unsigned long long) * 2048) == hipSuccess ? MN_OK : MN_ERR_HIP;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_wgt), sizeof(unsigned long long) * 4096) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
 extern "C" int mn_iqn_train_debug_phases3(unsigned long long *out_host) {   // [first, middle, last reduction + Adam block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase3), sizeof(unsigned long long) * 24) == hipSuccess ? MN_OK : MN_ERR_HIP;
@@ -1587,6 +1834,14 @@ extern "C" int mn_iqn_sample(int64_t ring_size, int32_t batch, uint64_t *rng_sta
     hipLaunchKernelGGL(iqn_sample_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ring_size, batch, rng_state_dev, idx_out,
                        taus_out, n_taus_total);
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+// float index, inside the workspace, of the u32 count of local workgroups of XCD-grouped one-launch steps that did not run on XCD (block index % 8)
+// as the first workgroup of its group (block index % 8) (0 on every launch observed: the dispatcher deals workgroups out round-robin; such a workgroup's row
+// takes the slow way through memory)
+extern "C" int64_t mn_iqn_train_workspace_misplaced_word(int32_t batch) {
+    if (batch <= 0 || batch > MAX_BATCH || batch % BE) return -1;
+    return ws_epoch(batch / BE) + 9;
 }
 
 extern "C" int64_t mn_iqn_train_workspace_floats(int32_t batch) {
@@ -1649,10 +1904,17 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
     const int n_fwd = mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
-    if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH)) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
-        const StepTail tail = {N_ADAM, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
+    // one launch: only while every forward / backward workgroup has a CU of its own (they wait for each other), i.e. batch <= 256; otherwise two launches
+    if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH) && n_fwd <= 256) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
+        const int hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
+        // grouped: all reduction + Adam blocks that find a CU while the local workgroups run (those the target workgroups vacate + those never used); ungrouped: all
+#ifndef MN_TAIL_EXTRA
+#define MN_TAIL_EXTRA 0
+#endif
+        const int n_tail = hier && MN_TAIL_EXTRA ? std::max(N_ADAM - n_part, std::min(N_ADAM, 256 - n_part)) : N_ADAM;
+        const StepTail tail = {n_tail, N_ADAM, hier, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
                                adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm};
-        hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + N_ADAM), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+        hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
                            mode, use_staged, tail);
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }

@@ -11,6 +11,7 @@ the agent switches between the HIP and the PyTorch gradient step (`sync_to_optim
 optimizer state, whichever path runs.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -168,7 +169,7 @@ class FusedTrainer:
             key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr() if self._ws is not None else 0)
             flags = 2 | (1 if key == self._staged_key else 0)
         if self._two_launches():      # forward / backward, then reduction + clip + Adam in ONE launch (mn_iqn_train_step): bit-identical
-            flags |= 4 if getattr(ag, "one_launch_step", False) else 0      # MN_TRAIN_ONE_LAUNCH: ... as a third role of the SAME launch
+            flags |= self._one_launch_flags()      # MN_TRAIN_ONE_LAUNCH: ... as a third role of the SAME launch
             rc = self._step_call((states, next_states, actions, rewards, dones), ring_size, self.rng_state, None, None, None, self._idx[batch],
                                  self._taus[batch], batch, flags, stream)
         else:
@@ -183,6 +184,20 @@ class FusedTrainer:
             weights_changed(ag.qnetwork_local)
             return self.loss[0]
         return self._finish_step(batch)
+
+    def xcd_misplaced(self, batch=None):
+        """Diagnostic of the one-launch step: local workgroups that did not run on XCD (block index % 8) since the workspace was made (0 expected)."""
+        batch = self.agent.BATCH_SIZE if batch is None else batch
+        i = _capi.lib().mn_iqn_train_workspace_misplaced_word(batch)
+        return int(self._workspace(batch)[i:i + 1].view(torch.int32).item())
+
+    def _one_launch_flags(self):
+        """MN_TRAIN_ONE_LAUNCH (IQNAgent.one_launch_step) [| MN_TRAIN_UNGROUPED (one_launch_ungrouped: every partial row through memory instead of
+        summed inside its XCD) | MN_TRAIN_TEST_MISPLACE(k) (test hook `_test_misplace`)]."""
+        ag = self.agent
+        if not getattr(ag, "one_launch_step", os.environ.get("MN_ONE_LAUNCH", "1") != "0"):      # (MN_ONE_LAUNCH=0: two launches, for A / B runs of whole programs)
+            return 0
+        return 4 | (8 if getattr(ag, "one_launch_ungrouped", False) else 0) | (int(getattr(ag, "_test_misplace", 0)) << 4)
 
     def _two_launches(self):
         """A single learner's step is two launches (mn_iqn_train_step); so is a shared learner's with the mailbox exchange (the exchange happens
@@ -268,7 +283,7 @@ class FusedTrainer:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if self._two_launches():
             rc = self._step_call((states, next_states, actions, rewards, dones), 0, None, idx, tt, tl, None, None, B,
-                                 4 if getattr(ag, "one_launch_step", False) else 0, stream)
+                                 self._one_launch_flags(), stream)
             if rc:
                 raise _capi.MarineNavHipError(f"mn_iqn_train_step failed ({rc})")
             weights_changed(ag.qnetwork_local)

@@ -393,6 +393,10 @@ int mn_iqn_train_step(const float *ring_states, const float *ring_next_states, c
                       float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, int32_t batch,
                       int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
+/* Diagnostic: float index inside the workspace of a u32 counter -- local workgroups of one-launch steps that did not run on the XCD of the first
+ * workgroup of their group (block index % 8) since mn_iqn_train_workspace_init (their partial-gradient rows go through memory instead of staying in the
+ * XCD's L2: correct, slower; the dispatcher deals workgroups out to the XCDs round-robin, so 0 is expected). */
+int64_t mn_iqn_train_workspace_misplaced_word(int32_t batch);
 int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
 
 /* ---- One-shot gradient exchange of a shared learner (BASELINE configs[4]; SURVEY 8e: one flat 143 KB bucket per gradient step, latency-
@@ -473,6 +477,9 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
 #define MN_TRAIN_USE_STAGED 1
 #define MN_TRAIN_STAGE_NEXT 2
 #define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step only: the reduction + clip + Adam blocks ride in the forward / backward launch (third role) */
+#define MN_TRAIN_UNGROUPED 8       /* with MN_TRAIN_ONE_LAUNCH: every partial-gradient row goes through to memory (the form before the XCD-grouped one; batches whose
+                                    * half is not a multiple of 8 always use it).  Default: the rows of the workgroups of one XCD are summed inside that XCD's L2 */
+#define MN_TRAIN_TEST_MISPLACE(k) ((k) << 4)   /* test hook, k = 1..3, with MN_TRAIN_ONE_LAUNCH: treat some workgroups as if they had landed on another XCD */
 int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                               const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,
                               int64_t *idx_out, float *taus_out, const float *params_local, const float *params_target,

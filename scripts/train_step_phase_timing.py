@@ -16,7 +16,7 @@ B = 256
 so = "/tmp/libtrainph.so"
 if not os.path.exists(so) or os.environ.get("REBUILD", "1") == "1":
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include",
-                           "-DMN_TRAIN_PHASES", "-shared", f"{ROOT}/distributional_rl_navigation_amd/csrc/iqn_train.hip", "-o", so])
+                           "-DMN_TRAIN_PHASES", *os.environ.get("MN_EXTRA_DEFS", "").split(), "-shared", f"{ROOT}/distributional_rl_navigation_amd/csrc/iqn_train.hip", "-o", so])
 L = C.CDLL(so)
 L.mn_iqn_train_workspace_floats.restype = C.c_int64
 dev = "cuda:0"
@@ -34,8 +34,8 @@ grad = torch.zeros(P, device=dev); m = torch.zeros(P, device=dev); v = torch.zer
 step = torch.zeros(1, dtype=torch.int32, device=dev); loss = torch.zeros(1, device=dev)
 rng = torch.tensor([12345, 0], dtype=torch.int64, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr())
-flags = 3 | (4 if launches == 1 else 0)
-acc1 = np.zeros((2, 32)); acc3 = np.zeros((3, 8)); accw = np.zeros((256, 2)); cnt = 0
+flags = 3 | (4 if launches == 1 else 0) | int(os.environ.get("MN_STEP_FLAGS", "0"))      # 8 = ungrouped rows (MN_TRAIN_UNGROUPED)
+acc1 = np.zeros((2, 32)); acc3 = np.zeros((3, 8)); accw = np.zeros((256, 4)); cnt = 0
 for it in range(reps + 20):
     rc = L.mn_iqn_train_step(p(ring[0]), p(ring[1]), p(ring[2]), p(ring[3]), p(ring[4]), C.c_int64(n), p(rng), None, None, None, None, None,
                              p(local), p(target), p(ws), p(grad), p(loss), p(m), p(v), p(step), B, 8, C.c_float(0.99), flags,
@@ -48,19 +48,21 @@ for it in range(reps + 20):
         a1 = np.array(o1[:], dtype=np.float64).reshape(2, 32); a3 = np.array(o3[:], dtype=np.float64).reshape(3, 8)
         t0 = min(a1[0, 0], a1[1, 0])
         acc1 += np.where(a1 > 0, (a1 - t0) * 0.01, 0.0); acc3 += np.where(a3 > 0, (a3 - t0) * 0.01, 0.0); cnt += 1
-        ow = (C.c_ulonglong * 2048)()
+        ow = (C.c_ulonglong * 4096)()
         assert L.mn_iqn_train_debug_wgt(ow) == 0
-        accw += (np.array(ow[:512], dtype=np.float64).reshape(256, 2) - t0) * 0.01
+        accw += (np.array(ow[:1024], dtype=np.float64).reshape(256, 4) - t0) * 0.01
 acc1 /= cnt; acc3 /= cnt; accw /= cnt
 print(f"{launches} launch(es) per step, mean over {cnt} steps, microseconds since the first forward / backward workgroup's start (loss {float(loss):.4f})")
 print(f"  target workgroup 0: start {acc1[0, 0]:6.2f}   TD targets published {acc1[0, 7]:6.2f}")
 print(f"  local workgroup {B // 2}: start {acc1[1, 0]:6.2f}   TD targets in LDS {acc1[1, 8]:6.2f}   last gradient store issued {acc1[1, 13]:6.2f}"
-      + (f"   stores acknowledged {acc1[1, 17]:6.2f}" if launches == 1 else ""))
+      + (f"   stores acknowledged {acc1[1, 17]:6.2f}   group share done {acc1[1, 18]:6.2f}" if launches == 1 else ""))
 for b, lab in enumerate(("first", "middle", "last")):
     t = acc3[b]
     print(f"  {lab:6s} reduction + Adam block: start {t[0]:6.2f}   rows complete {t[1]:6.2f}   column sums formed {t[2]:6.2f}   norm partials in {t[3]:6.2f}   Adam done {t[4]:6.2f}")
 q = lambda x: "min %.2f  median %.2f  p90 %.2f  max %.2f" % (x.min(), np.median(x), np.percentile(x, 90), x.max())
 print("  target workgroups: start " + q(accw[:128, 0]) + " | end " + q(accw[:128, 1]))
-print("  local  workgroups: start " + q(accw[128:, 0]) + " | end (stores acknowledged) " + q(accw[128:, 1]))
+print("  local  workgroups: start " + q(accw[128:, 0]) + " | end " + q(accw[128:, 1]))
+if launches == 1:
+    print("  local  workgroups: row acknowledged " + q(accw[128:, 2]) + " | group's rows seen " + q(accw[128:, 3]))
 late = np.argsort(accw[128:, 1])[-8:]
 print("  the eight local workgroups that end last: " + ", ".join(f"{128 + i} ({accw[128 + i, 1]:.2f})" for i in late))

@@ -293,7 +293,9 @@ def test_iqn_c_abi_argument_checks(torch):
     L = _capi.lib()
     # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
     # staging tag / magic word + the staged next batch (256 slots of 72 floats)
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + 128 + 256 * 72      # (+ the 280 tagged norm partials and 128 row-complete words of the two- / one-launch step)
+    # + the 280 tagged norm partials of the two-launch step; in brackets the one-launch step's 128 8-byte row-complete words, 128 row-complete words of its ungrouped
+    # form, 8 x 64 XCD-local row-complete words, 128 tagged loss partials, 128 "which XCD" words and the eight XCD group rows as 8-byte granules
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + (2 * 128 + 128 + 512 + 2 * 128 + 2 * 128 + 16 * 35788) + 256 * 72
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -584,16 +586,20 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
     gradients and exchanges the norm partials as self-tagged granules (two launches per step), or as a third workgroup role of the forward /
     backward launch itself (MN_TRAIN_ONE_LAUNCH: one launch per step) -- against `mn_iqn_train_grad*` + `mn_iqn_train_adam` (three launches):
     losses, clipped gradients, parameters, moments, Adam step, generator state bit-identical over sampled steps (staged batches incl.), a ring
-    write in between, given-batch steps with injected taus, a captured 8-step hipGraph, and in the local-only workgroup mode."""
+    write in between, given-batch steps with injected taus (batch 64: 32 rows, 4 per XCD group), a captured 8-step hipGraph, and in the local-only
+    workgroup mode.  The one-launch step in its XCD-grouped form (default), ungrouped (every row through memory), and grouped with workgroups that
+    pretend to have landed on another XCD (every fifth / all / all of one group: their rows go through memory, they take no share of the group sum)."""
     from distributional_rl_navigation_amd import _capi
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev = "cuda:0"
     runs = []
-    for two, one in ((True, True), (True, False), (False, False), (True, True)):
+    # (two launches, one launch, ungrouped rows, pretended XCD misplacement 0..3, local-only workgroup mode)
+    cases = ((True, True, False, 0, 0), (True, False, False, 0, 0), (False, False, False, 0, 0), (True, True, False, 0, 1), (True, True, True, 0, 0),
+             (True, True, False, 1, 0), (True, True, False, 2, 0), (True, True, False, 3, 1))
+    for two, one, ungrouped, misplace, mode in cases:
         ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
-        ag.two_launch_step, ag.one_launch_step = two, one
-        if len(runs) == 3:
-            _capi.lib().mn_iqn_train_set_mode(1)      # every workgroup computes its own TD targets: no target role in the launch
+        ag.two_launch_step, ag.one_launch_step, ag.one_launch_ungrouped, ag._test_misplace = two, one, ungrouped, misplace
+        _capi.lib().mn_iqn_train_set_mode(mode)      # 1: every workgroup computes its own TD targets, no target role in the launch
         g = torch.Generator(device=dev); g.manual_seed(5)
         ag.memory.add_batch(*_random_batch(torch, 2048, g))
         losses = [float(ag.train_from_memory()) for _ in range(12)]
@@ -612,7 +618,7 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
     _capi.lib().mn_iqn_train_set_mode(0)
     ref = runs[2]      # three launches
     assert all(np.isfinite(ref[0]))
-    for r in (runs[0], runs[1], runs[3]):
+    for r in runs[:2] + runs[3:]:
         assert r[0] == ref[0]
         for x, y in zip(r[1:5], ref[1:5]):
             assert torch.equal(x, y)
