@@ -599,18 +599,30 @@ static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "
 // `vb` of `nvb` = the block's index among the reduction blocks (the stand-alone launch: vb; as the third role of the forward / backward
 // launch: vb - its workgroups).  `done` != NULL (third role): the partial gradients are being written by workgroups of the SAME launch;
 // done[w] == done_tag says workgroup w's partial row and loss partial are complete -- each wave waits for the 16 rows of its segment.
-__device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, float *__restrict__ ws, int n_part, float *__restrict__ grad,
+// Physical block `pb` of `n_phys` runs the virtual blocks vb = pb, pb + n_phys, ... < nvb (at most VPB of them; VPB = 1 and n_phys = nvb everywhere but in the
+// XCD-grouped one-launch step, whose 128 resident blocks cover the 140 virtual ones -- a block dispatched later than the others holds everybody's Adam up).
+template <int VPB = 1>
+__device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys, const int nvb, float *__restrict__ ws, int n_part, float *__restrict__ grad,
                                                  float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
                                                  float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
                                                  double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag,
                                                  const XchgPeers *peers = nullptr, int world = 1, float grad_scale = 1.0f, bool grouped = false) {
-    __shared__ float4 red[RED_SEG][RA_COLS];
-    __shared__ float sq[RA_COLS];
-    __shared__ float gsh[4 * RA_COLS];
+    __shared__ float4 red[VPB][RED_SEG][RA_COLS];
+    __shared__ float sq[VPB][RA_COLS];
+    __shared__ float gsh[VPB][4 * RA_COLS];
     __shared__ float nred[4];
     __shared__ float s_bc[2];
     const int tid = threadIdx.x, cx = tid % RA_COLS, seg = tid / RA_COLS;
-    const int col = vb * RA_COLS + cx;
+    const int vb = pb;      // (block 0 = virtual block 0: the loss; PH3 stamps)
+    int vbs[VPB], col[VPB], p[VPB];
+    bool on[VPB];
+#pragma unroll
+    for (int j = 0; j < VPB; ++j) {
+        vbs[j] = pb + j * n_phys;
+        on[j] = vbs[j] < nvb;
+        col[j] = vbs[j] * RA_COLS + cx;
+        p[j] = vbs[j] * 256 + tid;
+    }
     if (*reinterpret_cast<const uint32_t *>(ws + ws_epoch(n_part) + 8) != WS_MAGIC) {      // see iqn_grad_reduce
         if (vb == 0 && tid == 0) loss_out[0] = __builtin_nanf("");
         return;
@@ -618,9 +630,12 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     PH3(0);
     const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);      // the epoch this step ends with
     // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
-    const int p = vb * 256 + tid;
-    float mp = 0.f, vp = 0.f, pp = 0.f;
-    if (tid < 256 && p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
+    float mp[VPB], vp[VPB], pp[VPB];
+#pragma unroll
+    for (int j = 0; j < VPB; ++j) {
+        mp[j] = vp[j] = pp[j] = 0.f;
+        if (on[j] && tid < 256 && p[j] < P_TOTAL) { mp[j] = m[p[j]]; vp[j] = v[p[j]]; pp[j] = params[p[j]]; }
+    }
     int t_step = 0;
     if (tid == RA_BT - 1) t_step = *step + 1;
     // staging of the NEXT step's batch (see iqn_grad_reduce): a pure copy, any thread mapping does
@@ -631,7 +646,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     if (prefetch_next && rng_state && vb >= 1) {
         const int t_slot = tid / STG;
         st_e = tid % STG;
-        for (int j = vb - 1; j * SPB < batch; j += nvb - 1)
+        for (int j = vb - 1; j * SPB < batch; j += n_phys - 1)
             if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
     }
     if (st_slot >= 0) {
@@ -664,7 +679,9 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     }
     PH3(1);
     float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[VPB];
+#pragma unroll
+    for (int j = 0; j < VPB; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grouped) {
         // XCD-grouped one-launch step: the eight segment sums arrive as self-tagged granules (group_reduce) -- thread (cx, seg) polls the four of
         // column `col` of group row `seg`, block 0 the n_part loss partials.  No flag, no fence: the data is the flag.  (MN_TAIL_PREPOLL: one wavefront per
@@ -697,22 +714,35 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
                 lpart += __uint_as_float((uint32_t)x);
             }
         }
-        if (col < N_COLS) {
-            const gu64 *g = (const gu64 *)(ws + ws_grp(n_part)) + (size_t)seg * P_PAD + 4 * col;
-            uint64_t x[4];
+        {
+            const gu64 *g[VPB];
+            bool want[VPB];
+            uint64_t x[VPB][4];
+#pragma unroll
+            for (int j = 0; j < VPB; ++j) {
+                want[j] = on[j] && col[j] < N_COLS;
+                g[j] = (const gu64 *)(ws + ws_grp(n_part)) + (size_t)seg * P_PAD + 4 * (want[j] ? col[j] : 0);
+            }
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(g + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < VPB; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ok = ok && (uint32_t)(x[q] >> 32) == done_tag;
+                    for (int q = 0; q < 4; ++q) x[j][q] = __hip_atomic_load(g[j] + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < VPB; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ok = ok && (!want[j] || (uint32_t)(x[j][q] >> 32) == done_tag);
                 if (ok) break;
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
                 __builtin_amdgcn_s_sleep(4);
             }
             // (0 + G: the accumulator of the ungrouped paths starts at zero and adds its rows to it; x + 0 = x exactly, also for -0 since the sum of
             // the group's rows was itself formed as 0 + ...)
-            acc = make_float4(__uint_as_float((uint32_t)x[0]), __uint_as_float((uint32_t)x[1]), __uint_as_float((uint32_t)x[2]), __uint_as_float((uint32_t)x[3]));
+#pragma unroll
+            for (int j = 0; j < VPB; ++j)
+                if (want[j])
+                    acc[j] = make_float4(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]), __uint_as_float((uint32_t)x[j][2]), __uint_as_float((uint32_t)x[j][3]));
         }
     } else {
     // Third role, ungrouped: the rows were written (through, at agent scope) by workgroups of this launch on other XCDs, and this XCD's L2 may still
@@ -721,15 +751,17 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     if (vb == 0 && tid < 256)
         for (int wq = tid; wq < n_part; wq += 256)
             lpart += done ? __hip_atomic_load(ws + ws_loss(n_part) + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ws[ws_loss(n_part) + wq];
-    if (col < N_COLS) {
-        const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
+#pragma unroll
+    for (int j = 0; j < VPB; ++j)
+    if (on[j] && col[j] < N_COLS) {
+        const float4 *src = reinterpret_cast<const float4 *>(ws) + col[j];
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
         for (int wb = seg; wb < n_part; wb += RED_SEG * RED_MAX_PER) {
             float4 t[RED_MAX_PER];
             if (done) {
 #pragma unroll
                 for (int u = 0; u < RED_MAX_PER; ++u)
-                    t[u] = wb + RED_SEG * u < n_part ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((wb + RED_SEG * u) * N_COLS + col) * 16, 0, 16))
+                    t[u] = wb + RED_SEG * u < n_part ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((wb + RED_SEG * u) * N_COLS + col[j]) * 16, 0, 16))
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
@@ -737,51 +769,57 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
                     t[u] = wb + RED_SEG * u < n_part ? src[(size_t)(wb + RED_SEG * u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int u = 0; u < RED_MAX_PER; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+            for (int u = 0; u < RED_MAX_PER; ++u) { acc[j].x += t[u].x; acc[j].y += t[u].y; acc[j].z += t[u].z; acc[j].w += t[u].w; }
         }
     }
     }
-    red[seg][cx] = acc;
+#pragma unroll
+    for (int j = 0; j < VPB; ++j) red[j][seg][cx] = acc[j];
     late = __syncthreads_or(late);      // (a bounded wait that ran out anywhere in the block poisons the block's output)
     PH3(2);
-    if (seg == 0) {
-        float4 s = red[0][cx];
+    if (seg == 0)
 #pragma unroll
-        for (int q = 1; q < RED_SEG; ++q) { s.x += red[q][cx].x; s.y += red[q][cx].y; s.z += red[q][cx].z; s.w += red[q][cx].w; }
+    for (int j = 0; j < VPB; ++j) {
+        float4 s = red[j][0][cx];
+#pragma unroll
+        for (int q = 1; q < RED_SEG; ++q) { s.x += red[j][q][cx].x; s.y += red[j][q][cx].y; s.z += red[j][q][cx].z; s.w += red[j][q][cx].w; }
         float ss = 0.f;
         float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (col < N_COLS) {
+        if (on[j] && col[j] < N_COLS) {
             e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
             ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
         }
         if (peers) {      // shared learner, one-shot exchange IN this launch (mn_iqn_train_step_xchg): publish this rank's columns, gather every rank's
-            if (col < N_COLS) {
-                gu64 *dst = (gu64 *)peers->mb[world] + (size_t)(tag & 1u) * P_PAD + 4 * col;      // mb[world] = this rank's own mailbox (writable alias)
+            if (on[j] && col[j] < N_COLS) {
+                gu64 *dst = (gu64 *)peers->mb[world] + (size_t)(tag & 1u) * P_PAD + 4 * col[j];      // mb[world] = this rank's own mailbox (writable alias)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     __hip_atomic_store(dst + k, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(e[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                late = xchg_gather4(*peers, world, tag, 4 * col, e) || late;
+                late = xchg_gather4(*peers, world, tag, 4 * col[j], e) || late;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (4 * col + k >= P_TOTAL) e[k] = 0.f;
+                    if (4 * col[j] + k >= P_TOTAL) e[k] = 0.f;
             }
             float sc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) sc[k] = e[k] * grad_scale;
             ss = ((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]) + sc[3] * sc[3];      // iqn_grad_sumsq's / iqn_adam_xchg's expression
         }
-        sq[cx] = ss;
+        sq[j][cx] = ss;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gsh[4 * cx + k] = e[k];
+        for (int k = 0; k < 4; ++k) gsh[j][4 * cx + k] = e[k];
     }
     __syncthreads();
     gu64 *xsq = (gu64 *)(ws + ws_xsq(n_part));
-    if (tid == 0 || tid == RED_COLS) {
-        float t = 0.f;
-        for (int k = 0; k < RED_COLS; ++k) t += sq[tid + k];
-        ws[ws_sq(n_part) + 2 * vb + (tid >> 5)] = t;      // (also where the three-launch path keeps them)
-        __hip_atomic_store(xsq + 2 * vb + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0 || tid == RED_COLS)
+#pragma unroll
+        for (int j = 0; j < VPB; ++j) {
+            if (!on[j]) continue;
+            float t = 0.f;
+            for (int k = 0; k < RED_COLS; ++k) t += sq[j][tid + k];
+            ws[ws_sq(n_part) + 2 * vbs[j] + (tid >> 5)] = t;      // (also where the three-launch path keeps them)
+            __hip_atomic_store(xsq + 2 * vbs[j] + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     if (vb == 0) {      // the loss, in iqn_grad_reduce's order
         __shared__ float lw[4];
         float l = lpart;
@@ -826,15 +864,17 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
     const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
     const float wm = (float)(1.0 - b1), b2f = (float)b2, wv = (float)(1.0 - b2), eps = (float)eps_d;
-    if (tid < 256 && p < P_TOTAL) {
-        float gq = gsh[tid] * grad_scale;
+#pragma unroll
+    for (int j = 0; j < VPB; ++j)
+    if (on[j] && tid < 256 && p[j] < P_TOTAL) {
+        float gq = gsh[j][tid] * grad_scale;
         gq *= coef;
-        grad[p] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
-        const float mm = mp + (gq - mp) * wm;
-        const float vv = vp * b2f + wv * (gq * gq);
-        m[p] = mm;
-        v[p] = vv;
-        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        grad[p[j]] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
+        const float mm = mp[j] + (gq - mp[j]) * wm;
+        const float vv = vp[j] * b2f + wv * (gq * gq);
+        m[p[j]] = mm;
+        v[p[j]] = vv;
+        params[p[j]] = pp[j] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
     // the block that finishes LAST advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
     // (every block read all of them before taking its ticket)
@@ -843,7 +883,7 @@ __device__ __forceinline__ void reduce_adam_body(const int vb, const int nvb, fl
     if (tid == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
         const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == nvb - 1) {
+        if (old == n_phys - 1) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
             *step = *step + 1;
@@ -864,7 +904,7 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict_
                                                               uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
                                                               float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                               int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
-    reduce_adam_body(blockIdx.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u);
+    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u);
 }
 
 // ... and with the shared learner's one-shot gradient exchange inside (mn_iqn_train_step_xchg): two launches per step for a shared learner too
@@ -873,8 +913,8 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
                                                                    float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                                    int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d,
                                                                    XchgPeers peers, int world, float grad_scale, unsigned *__restrict__ status) {
-    reduce_adam_body(blockIdx.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u,
-                     &peers, world, grad_scale);
+    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u,
+                        &peers, world, grad_scale);
     (void)status;
 }
 
@@ -991,8 +1031,8 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
 // block indices), land on the CUs the target workgroups vacate half way through the launch, and wait there for the "row complete" words the local
 // workgroups write after their last partial-gradient store -- no launch boundary between the backward pass and the optimizer step.
 struct StepTail {
-    int n_wg;           // reduction + Adam blocks launched behind the forward / backward workgroups
-    int n_virtual;      // ... of N_ADAM: the rest (when they would not all find a free CU before the local workgroups end) is run by the first local workgroups, after their own work
+    int n_wg;           // reduction + Adam blocks launched behind the forward / backward workgroups, running
+    int n_virtual;      // ... the N_ADAM virtual blocks (XCD-grouped: up to two each, when they would not all find a free CU before the local workgroups end)
     int hier;           // the rows of an XCD's workgroups are summed inside that XCD before anything crosses to the others (n_part % 8 == 0)
     int misplace;       // test hook: pretend these local workgroups did not land on XCD (block index % 8): 1 = every fifth, 2 = all, 3 = all of group 3
     int prefetch_next;
@@ -1014,9 +1054,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         const int n_fwd = two_roles ? 2 * n_part : n_part;
         if ((int)blockIdx.x >= n_fwd) {
             const uint32_t dtag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;      // = the hand-off tag below
-            reduce_adam_body((int)blockIdx.x - n_fwd, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
-                             tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm,
-                             reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part)), dtag, nullptr, 1, 1.0f, tail.hier != 0);
+            const uint32_t *gd = reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part));
+            if (tail.hier)      // XCD-grouped: tail.n_wg (>= half of them) blocks run the tail.n_virtual virtual ones
+                reduce_adam_body<2>((int)blockIdx.x - n_fwd, tail.n_wg, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
+                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, nullptr, 1, 1.0f, true);
+            else
+                reduce_adam_body<1>((int)blockIdx.x - n_fwd, tail.n_virtual, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
+                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, nullptr, 1, 1.0f, false);
             return;
         }
     }
@@ -1414,11 +1458,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             }
             group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to publish behind it)
             PH(18);
-            // (MN_TAIL_EXTRA, measured 0.5 us per step slower, off: launch only as many reduction + Adam blocks as there are CUs before the local workgroups
-            // end, and let the first local workgroups run the rest here instead of leaving them to be dispatched behind them)
-            if (part < tail.n_virtual - tail.n_wg)
-                reduce_adam_body(tail.n_wg + part, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next, tail.params, tail.m,
-                                 tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, nullptr, tag, nullptr, 1, 1.0f, true);
         } else if (tid == 0) {
             __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_gdone(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what the reduction + Adam blocks wait for
         }
@@ -1908,10 +1947,10 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH) && n_fwd <= 256) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
         const int hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
         // grouped: all reduction + Adam blocks that find a CU while the local workgroups run (those the target workgroups vacate + those never used); ungrouped: all
-#ifndef MN_TAIL_EXTRA
-#define MN_TAIL_EXTRA 0
-#endif
-        const int n_tail = hier && MN_TAIL_EXTRA ? std::max(N_ADAM - n_part, std::min(N_ADAM, 256 - n_part)) : N_ADAM;
+        // grouped: only as many reduction + Adam blocks as find a CU while the local workgroups run (those the target workgroups vacate + those never used),
+        // each running up to two of the N_ADAM virtual blocks -- a block dispatched behind the local workgroups starts ~2 us late and everybody's Adam waits
+        // for its norm partials; ungrouped: all N_ADAM
+        const int n_tail = hier ? std::max((N_ADAM + 1) / 2, std::min(N_ADAM, 256 - n_part)) : N_ADAM;
         const StepTail tail = {n_tail, N_ADAM, hier, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
                                adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm};
         hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
