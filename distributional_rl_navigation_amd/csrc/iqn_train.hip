@@ -684,23 +684,10 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     for (int j = 0; j < VPB; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grouped) {
         // XCD-grouped one-launch step: the eight segment sums arrive as self-tagged granules (group_reduce) -- thread (cx, seg) polls the four of
-        // column `col` of group row `seg`, block 0 the n_part loss partials.  No flag, no fence: the data is the flag.  (MN_TAIL_PREPOLL: one wavefront per
-        // block first watches the "row complete" words and only then does everybody look for the granules -- measured 0.6 us per step slower, off.)
+        // column `col` of group row `seg`, block 0 the n_part loss partials.  No flag, no fence: the data is the flag.
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-#ifndef MN_TAIL_PREPOLL
-#define MN_TAIL_PREPOLL 0
-#endif
-        if (MN_TAIL_PREPOLL && tid < 64) {
-            const gu64 *rc = (const gu64 *)(ws + ws_done(n_part));
-            for (;;) {
-                bool ok = true;
-                for (int w = tid; w < n_part; w += 64) ok = ok && (uint32_t)(__hip_atomic_load(rc + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == done_tag;
-                if (__all(ok)) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;      // (the granule polls below run into their own bound)
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        __syncthreads();
+        // (Measured and dropped, +0.6 .. +0.9 us per step each: one wavefront per block first watching the "row complete" words, or "share issued" hints
+        // stored behind the granule stores, before everybody looks for the granules.)
         if (vb == 0 && tid < 256) {
             const gu64 *lq = (const gu64 *)(ws + ws_lossq(n_part));
             for (int wq = tid; wq < n_part; wq += 256) {
@@ -1456,7 +1443,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
                 if (wellplaced) *reinterpret_cast<volatile uint32_t *>(ws + ws_lflag(n_part) + 64 * (part & 7) + (part >> 3)) = tag;      // for this XCD's L2
                 __hip_atomic_store((gu64 *)(ws + ws_done(n_part)) + part, ((uint64_t)tag << 32) | (wellplaced ? 0u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to publish behind it)
+            group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to wait for behind it)
             PH(18);
         } else if (tid == 0) {
             __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_gdone(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what the reduction + Adam blocks wait for
