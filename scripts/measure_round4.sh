@@ -1,7 +1,7 @@
 # Round-4 measurements (run on the GPU box from the repo root): the bench line, rocprofv3 kernel stats of the headline loop with per-env and with
 # launch-shared taus, of the training cadence, PMC passes (HBM traffic of the env kernels now that the float64 copies are opt-in, instruction mix of the
 # act kernels), the learner alone, the experiment sweep with the classical baselines / DQN on their kernels.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/m4; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${MEASURE_DIR:-m4}; mkdir -p $O; rm -f $O/pmc_summary.txt $O/pmc_shared_summary.txt
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --shared-taus --cpu-steps 0 --no-also --no-learner-only > $O/bench_shared_taus.json 2> $O/bench_shared_taus.err
