@@ -329,6 +329,7 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
         sl["nccl_ws1_allreduce_graphed_16_step_events"] = graphed_rate()
         agent.distributed = False
         sl["no_group_graphed_16_step_events"] = graphed_rate()
+        sl["xcd_misplaced_workgroups"] = agent._fused.xcd_misplaced()
         agent.distributed = True
         sl["allreduce_overhead_us_per_step_graphed"] = 1e6 * (1.0 / sl["nccl_ws1_allreduce_graphed_16_step_events"] - 1.0 / sl["no_group_graphed_16_step_events"])
         # the one-shot exchange over IPC-mapped mailboxes instead of the RCCL all-reduce (iqn/mailbox.py; one rank: its own mailbox only)

@@ -237,7 +237,7 @@ class FusedTrainer:
         states = ring[0]
         # everything the captured launches hold a raw pointer to is part of the key
         key = (states.data_ptr(), int(ring_size), batch, int(n_steps), bool(self.agent.distributed), self._workspace(batch).data_ptr(),
-               self.local.data_ptr(), self.target.data_ptr(), self.grad.data_ptr())
+               self.local.data_ptr(), self.target.data_ptr(), self.grad.data_ptr(), self._two_launches(), self._one_launch_flags())
         if self._graph_key != key:
             self._graph = None
             torch.cuda.synchronize(self.device)
