@@ -1,7 +1,7 @@
-"""Copy the summaries scripts/measure_round4.sh left under gpurun_out/m4 into profiles/r04_* with headers."""
+"""Copy the summaries scripts/measure_round4.sh left under gpurun_out/m5 into profiles/r04_* with headers."""
 import json, os, re, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-M, P = R + '/gpurun_out/m4/', R + '/profiles/'
+M, P = R + '/gpurun_out/m5/', R + '/profiles/'
 body = lambda f: open(M + f).read()
 pm = body('pmc_summary.txt')
 def mean(txt, k, c):
@@ -9,7 +9,7 @@ def mean(txt, k, c):
     return float(m.group(1)) / 1e3 if m else float('nan')
 hdr = ("# r04: bench.py --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also --no-clock-probe under rocprofv3 --kernel-trace --stats (MI355X, 1 GPU; scripts/measure_round4.sh):\n"
        "# BASELINE configs[2] -- 65 536 envs + IQN training, 1 gradient step every 4 vector steps, float64 env kernels, per-env taus (the default), one batch / one stream.\n"
-       "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is TWO launches since round 4 (iqn_train_fwdbwd, iqn_grad_reduce_adam).\n")
+       "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is ONE launch since round 4 (iqn_train_fwdbwd with the reduction + clip + Adam blocks as its third workgroup role, XCD-grouped).\n")
 out = hdr + body('prof_loop_summary.txt').rstrip() + '\n\n'
 out += ("# PMC passes (separate runs, one counter each: rocprofv3 --kernel-trace --pmc <counter>; the same command with --steps 24 --warmup 8 --update-every 1 --grad-steps 4),\n"
         "# mean per launch; FETCH_SIZE / WRITE_SIZE in KB of 1000 B; HBM bytes = 2 x FETCH_SIZE (gfx950 correction, profiles/r01_pmc_calibration.txt) + WRITE_SIZE\n")
@@ -32,7 +32,7 @@ out += ('# derived: %.2f M MFMA-busy cycles (216 x 16 x 65 536 = 226.5 M + the e
     mean(ps, 'act', 'WRITE_SIZE'), mean(ps, 'act', 'FETCH_SIZE'))
 open(P + 'r04_shared_taus_loop_kernel_stats.txt', 'w').write(out)
 out = ("# r04: the cadence that trains -- bench.py --update-every 1 --grad-steps 16 --eps 0.05 (16 gradient steps per vector step) under rocprofv3 --kernel-trace --stats.\n"
-       "# Kernel durations include the launch boundary.  A gradient step = iqn_train_fwdbwd + iqn_grad_reduce_adam (r03: + iqn_grad_reduce, iqn_adam as two launches).\n")
+       "# Kernel durations include the launch boundary.  A gradient step = ONE launch of iqn_train_fwdbwd (reduction + clip + Adam inside, XCD-grouped; r03: iqn_train_fwdbwd, iqn_grad_reduce, iqn_adam).\n")
 out += body('prof_g16_summary.txt').rstrip() + '\n'
 open(P + 'r04_train_cadence_kernel_stats.txt', 'w').write(out)
 shutil.copy(M + 'bench_default.json', P + 'r04_bench_default.json')
