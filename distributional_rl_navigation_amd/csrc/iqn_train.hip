@@ -702,20 +702,33 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             }
         }
         {
-            const gu64 *g[VPB];
+#ifndef MN_TAIL_NAP
+#define MN_TAIL_NAP 700
+#endif
+            // Nothing can arrive for a while: these blocks start when the target workgroups end, i.e. when the TD targets are out, and the backward pass behind
+            // those takes >= 9 us.  65 000 threads polling 2.3 MB of granules through that time is memory traffic next to the backward pass (on this chip it
+            // costs the step nothing measurable -- 33.4-33.6 us with naps of 0 / 5 / 7 / 9 us -- but it is traffic other streams' kernels would see).
+            if (done)
+                while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)MN_TAIL_NAP) __builtin_amdgcn_s_sleep(32);
             bool want[VPB];
             uint64_t x[VPB][4];
+            const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)seg * P_PAD, 0, P_PAD * 8, 0x00020000);
 #pragma unroll
             for (int j = 0; j < VPB; ++j) {
                 want[j] = on[j] && col[j] < N_COLS;
-                g[j] = (const gu64 *)(ws + ws_grp(n_part)) + (size_t)seg * P_PAD + 4 * (want[j] ? col[j] : 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[j][q] = 0;
             }
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < VPB; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[j][q] = __hip_atomic_load(g[j] + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (on[j]) {      // (block-uniform) two granules per 16-byte sc1 load; each granule vouches for itself
+                        const int c = want[j] ? col[j] : 0;
+                        const u32x4s lo = __builtin_amdgcn_raw_buffer_load_b128(grp, c * 32, 0, 16), hi = __builtin_amdgcn_raw_buffer_load_b128(grp, c * 32 + 16, 0, 16);
+                        x[j][0] = ((uint64_t)lo[1] << 32) | lo[0]; x[j][1] = ((uint64_t)lo[3] << 32) | lo[2];
+                        x[j][2] = ((uint64_t)hi[1] << 32) | hi[0]; x[j][3] = ((uint64_t)hi[3] << 32) | hi[2];
+                    }
 #pragma unroll
                 for (int j = 0; j < VPB; ++j)
 #pragma unroll
