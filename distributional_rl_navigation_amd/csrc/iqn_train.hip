@@ -643,22 +643,23 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     const int batch = n_part * BE;
     int st_slot = -1, st_e = 0;
     float st_v = 0.f;
-    if (prefetch_next && rng_state && vb >= 1) {
-        const int t_slot = tid / STG;
+    auto staged_value = [&](uint64_t base_n, int slot, int e) -> float {
+        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)slot);
+        if (e < OBS) return ba.ring_s[row * OBS + e];
+        if (e < 2 * OBS) return ba.ring_ns[row * OBS + e - OBS];
+        if (e == 2 * OBS) return (float)ba.ring_a[row];
+        if (e == 2 * OBS + 1) return ba.ring_r[row];
+        if (e == 2 * OBS + 2) return ba.ring_d[row];
+        if (e >= 56) return sample_tau(base_n, (e < 64 ? 0 : batch * NQ) + slot * NQ + (e & 7));
+        return 0.f;
+    };
+    const bool stager = prefetch_next && rng_state && vb >= 1 && tid / STG < SPB;
+    if (stager) {      // this block's first SPB slots, requested now (blocks 1 .. n_phys - 1 share the batch; more passes, if any, further down)
         st_e = tid % STG;
-        for (int j = vb - 1; j * SPB < batch; j += n_phys - 1)
-            if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
+        const int slot = (vb - 1) * SPB + tid / STG;
+        if (slot < batch) st_slot = slot;
     }
-    if (st_slot >= 0) {
-        const uint64_t base_n = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2));
-        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)st_slot);
-        if (st_e < OBS) st_v = ba.ring_s[row * OBS + st_e];
-        else if (st_e < 2 * OBS) st_v = ba.ring_ns[row * OBS + st_e - OBS];
-        else if (st_e == 2 * OBS) st_v = (float)ba.ring_a[row];
-        else if (st_e == 2 * OBS + 1) st_v = ba.ring_r[row];
-        else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
-        else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
-    }
+    if (st_slot >= 0) st_v = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), st_slot, st_e);
     // Segment `seg` of a column = the rows w = seg (mod RED_SEG), ascending (round 4; was: RED_SEG contiguous blocks of rows) -- the rows whose
     // workgroups share an XCD (block index % 8), which is what lets the one-launch step sum a segment inside that XCD's L2 (`grouped`: the eight
     // segment sums are already formed, in ws_grp; one row per segment is left to read).  Same order in every path: all of them stay bit-identical.
@@ -834,6 +835,12 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         }
     }
     if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
+    if (stager && n_phys > 1)      // batches with more slots than one pass of the blocks covers (few blocks: the one-launch step's 70 for batch 512)
+        for (int j = vb - 1 + (n_phys - 1); j * SPB < batch; j += n_phys - 1) {
+            const int slot = j * SPB + tid / STG;
+            if (slot < batch)
+                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), slot, st_e);
+        }
     // Adam's bias corrections (two float64 pow: ~500 instructions) by a thread of the last wave, which has nothing else to do while waves 0-3 poll the
     // norm partials -- not behind the poll, and not in front of the barrier the partials are published behind; read after the barrier that follows the poll
     if (tid == RA_BT - 1) {
@@ -1498,22 +1505,23 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     const int batch = n_part * BE;
     int st_slot = -1, st_e = 0;
     float st_v = 0.f;
-    if (prefetch_next && rng_state && blockIdx.x >= 1) {
-        const int t_slot = threadIdx.x / STG;
+    auto staged_value = [&](uint64_t base_n, int slot, int e) -> float {
+        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)slot);
+        if (e < OBS) return ba.ring_s[row * OBS + e];
+        if (e < 2 * OBS) return ba.ring_ns[row * OBS + e - OBS];
+        if (e == 2 * OBS) return (float)ba.ring_a[row];
+        if (e == 2 * OBS + 1) return ba.ring_r[row];
+        if (e == 2 * OBS + 2) return ba.ring_d[row];
+        if (e >= 56) return sample_tau(base_n, (e < 64 ? 0 : batch * NQ) + slot * NQ + (e & 7));
+        return 0.f;
+    };
+    const bool stager = prefetch_next && rng_state && blockIdx.x >= 1 && (int)threadIdx.x / STG < SPB;
+    if (stager) {      // this block's first SPB slots, requested now (more passes, for batches > 837, at the store below)
         st_e = threadIdx.x % STG;
-        for (int j = blockIdx.x - 1; j * SPB < batch; j += gridDim.x - 1)      // one pass unless the grid is tiny
-            if (t_slot < SPB && j * SPB + t_slot < batch) st_slot = j * SPB + t_slot;
+        const int slot = ((int)blockIdx.x - 1) * SPB + threadIdx.x / STG;
+        if (slot < batch) st_slot = slot;
     }
-    if (st_slot >= 0) {
-        const uint64_t base_n = mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2));   // = sample_base after this step's increment
-        const int64_t row = perm_row(base_n, (uint32_t)ba.ring_n, (uint32_t)st_slot);
-        if (st_e < OBS) st_v = ba.ring_s[row * OBS + st_e];
-        else if (st_e < 2 * OBS) st_v = ba.ring_ns[row * OBS + st_e - OBS];
-        else if (st_e == 2 * OBS) st_v = (float)ba.ring_a[row];
-        else if (st_e == 2 * OBS + 1) st_v = ba.ring_r[row];
-        else if (st_e == 2 * OBS + 2) st_v = ba.ring_d[row];
-        else if (st_e >= 56) st_v = sample_tau(base_n, (st_e < 64 ? 0 : batch * NQ) + st_slot * NQ + (st_e & 7));
-    }
+    if (st_slot >= 0) st_v = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), st_slot, st_e);   // base = sample_base after this step's increment
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // segment seg = the rows w = seg (mod RED_SEG), ascending (see reduce_adam_body)
     if (col < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
@@ -1579,6 +1587,12 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     }
     PH2(0, 3);
     if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
+    if (stager && gridDim.x > 1)
+        for (int j = (int)blockIdx.x - 1 + ((int)gridDim.x - 1); j * SPB < batch; j += (int)gridDim.x - 1) {
+            const int slot = j * SPB + threadIdx.x / STG;
+            if (slot < batch)
+                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), slot, st_e);
+        }
     // the block that finishes LAST advances the generator's call counter (the batch of this step was drawn by iqn_train_fwdbwd; the
     // staging blocks above read the old value) and the hand-off epoch, and tags the staged batch
     __syncthreads();

@@ -623,3 +623,29 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
         for x, y in zip(r[1:5], ref[1:5]):
             assert torch.equal(x, y)
         assert r[5] == ref[5] == 12 + 5 + 3 + 16 and torch.equal(r[6], ref[6]) and r[7] == ref[7]
+
+
+@pytest.mark.parametrize("batch", [16, 48, 100, 128, 384, 512, 1024])
+def test_one_launch_step_at_other_batch_sizes(torch, batch):
+    """The one-launch step away from batch 256: 16 (one row per XCD group), 48 (three), 128 (eight; every reduction + Adam block finds a CU at once), 100 (its half
+    is no multiple of 8: the ungrouped form), 384 / 512 (every workgroup computes its own TD targets; 24 / 32 rows per group, 70 reduction + Adam blocks that
+    run two virtual blocks each and stage the next batch in several passes; at 512 they only find a CU once local workgroups end), 1024 (more forward /
+    backward workgroups than CUs: mn_iqn_train_step falls back to two launches) -- bit-identical to the three-launch path over sampled steps incl. staged
+    batches, and no workgroup away from its group's XCD."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    runs = []
+    for one in (True, False):
+        ag = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=4096, device=dev, seed=3)
+        ag.two_launch_step, ag.one_launch_step = one, one
+        g = torch.Generator(device=dev); g.manual_seed(9)
+        ag.memory.add_batch(*_random_batch(torch, 4096, g))
+        losses = [float(ag.train_from_memory()) for _ in range(10)]
+        ft = ag._fused
+        if one:
+            assert ft.xcd_misplaced(batch) == 0
+        runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone()))
+    a, b = runs
+    assert all(np.isfinite(a[0])) and a[0] == b[0] and a[4] == b[4] == 10
+    for x, y in ((a[1], b[1]), (a[2], b[2]), (a[3], b[3]), (a[5], b[5])):
+        assert torch.equal(x, y)
