@@ -1957,7 +1957,7 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
     const int n_fwd = mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
-    // one launch: only while every forward / backward workgroup has a CU of its own (they wait for each other), i.e. batch <= 256; otherwise two launches
+    // one launch: only while every forward / backward workgroup has a CU of its own (they wait for each other), i.e. batch <= 512 (256 with two workgroup roles); otherwise two launches
     if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH) && n_fwd <= 256) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
         const int hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
         // grouped: all reduction + Adam blocks that find a CU while the local workgroups run (those the target workgroups vacate + those never used); ungrouped: all

@@ -381,7 +381,7 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 /* The whole gradient step of a single learner -- IQNAgent.train (agent.py:269-304) incl. clip_grad_norm_ and optimizer.step() -- as TWO
  * launches: forward / backward, then a launch in which every block reduces the partial gradients of its own 256 parameters, exchanges the norm
- * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4) -- or, with MN_TRAIN_ONE_LAUNCH in `flags` (batch <= 256;
+ * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4) -- or, with MN_TRAIN_ONE_LAUNCH in `flags` (batch <= 512: every forward / backward workgroup needs a CU of its own;
  * larger batches take two launches), as ONE launch: those blocks are a third workgroup role of the forward / backward launch, dispatched behind its
  * workgroups.  By default XCD-grouped: the partial-gradient rows of the workgroups that share an XCD (block index mod 8: the dispatcher deals
  * workgroups out round-robin) are summed inside that XCD's L2 and only the eight group rows cross to the other XCDs, as self-tagged granules the
