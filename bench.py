@@ -233,7 +233,7 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up, one_batch
     out["train_cadence"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                             "grad_steps_per_vector_step": 16, "eps": 0.05,
                             "grad_steps_per_sec": 16 * steps / dt, "grad_steps_counted": agent.grad_steps - g0 - 16 * 10,
-                            "launches_per_grad_step": 1 if getattr(agent, "one_launch_step", True) and getattr(agent, "two_launch_step", True) else 2,
+                            "launches_per_grad_step": (1 if agent._fused._one_launch_flags(agent.BATCH_SIZE) else 2) if getattr(agent, "_fused", None) is not None else None,
                             "xcd_misplaced_workgroups": agent._fused.xcd_misplaced() if getattr(agent, "_fused", None) is not None else None}
     dt, act_ms = shared_leg(lambda o: agent.vec_step(env, o, 0.05, args.cvar, train_every=1, per_iter=n)[0], steps, 10)
     out["train_cadence_shared_taus"] = {"value": n * steps / dt, "unit": "env steps/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,

@@ -1021,6 +1021,20 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         }
         return;
     }
+    if (MN_GROUP_FAST && mis == 0 && (gsz & 7) == 0) {      // batches 128, 384, 512, ...: eight rows' loads in flight at a time
+        for (int c = c0 + tid; c < c1; c += THREADS) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i0 = 0; i0 < gsz; i0 += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * (i0 + u)) * N_COLS + c) * 16, 0, 1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+            }
+            put(c, acc);
+        }
+        return;
+    }
     for (int c = c0 + tid; c < c1; c += THREADS) {      // any group size, any mix of rows in this L2 (sc0) and rows in memory (sc1)
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = 0; i < gsz; ++i) {
