@@ -6,10 +6,13 @@ import torch
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+grad_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # gradient steps per training event (16 = the cadence train_iqn runs)
+update_every = int(sys.argv[3]) if len(sys.argv) > 3 else 4    # vector steps between training events
 n = 65536
 sched = dict(timesteps=[0, 1000000, 2000000], num_cores=[4, 6, 8], num_obstacles=[6, 8, 10], min_start_goal_dis=[30.0, 35.0, 40.0])
 env = VecMarineNavEnv(n, seed=0, schedule=sched, timestep_scale=3e6 / (n * steps) * n, device="cuda:0")
-agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=100_000, device="cuda:0", seed=100, learning_starts=0)
+agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=100_000, device="cuda:0", seed=100, learning_starts=0, UPDATE_EVERY=update_every)
+agent.grad_steps_per_update = grad_steps
 obs = env.reset()
 total = n * steps
 t0 = time.time(); mem0 = None; done_total = 0
@@ -28,4 +31,7 @@ for it in range(steps):
               f"grad steps {agent.grad_steps}  loss {float(loss) if loss is not None else float('nan'):.3f}  "
               f"world sizes {sorted(set((x['n_cores'], x['n_obs']) for x in w))[-1]}", flush=True)
         assert mem <= mem0 * 1.05
+        assert loss is None or torch.isfinite(loss).all()
+        if getattr(agent, "_fused", None) is not None:      # the one-launch gradient step's placement diagnostic
+            assert agent._fused.xcd_misplaced() == 0
 print("soak ok")
