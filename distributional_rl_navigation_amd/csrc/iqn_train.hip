@@ -931,7 +931,8 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
 // the writers' stores) -- and writes that piece of the group row to ws_grp as self-tagged granules {step tag, value}, through to memory, where the
 // reduction + Adam blocks of every XCD poll them: the data is the flag.  18 MB of partial gradients never leave the L2s; 2.3 MB of granules do.
 // "Row complete" travels twice: as a word in memory (agent scope, with the "written through" flag), and -- from workgroups that are where they should
-// be -- as a word in the XCD's L2 (ordinary store, sc0 load), which is what the group normally sees first.  A row whose workgroup was NOT on XCD x was
+// be -- as a word in the XCD's L2 (ordinary store; read with an atomic OR of 0, which the L2 executes: an sc0 load may be served by this CU's own vector
+// cache, and was 0.8 us slower to notice), which is what the group normally sees first.  A row whose workgroup was NOT on XCD x was
 // written through and is read with sc1 loads; such a workgroup takes no share (it cannot see the others' rows) unless the whole group is like that.
 // The arithmetic does not depend on any of this.
 __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part, int part, uint32_t tag, int tid) {
