@@ -929,7 +929,8 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
 // After its own row is complete a workgroup waits for the rows of its group, takes an equal share of the 8 947 16-byte columns and sums the group's
 // rows for them in ascending row order -- reading through the XCD's own L2 (sc0 loads: past this CU's vector cache, served by the L2 that acknowledged
 // the writers' stores) -- and writes that piece of the group row to ws_grp as self-tagged granules {step tag, value}, through to memory, where the
-// reduction + Adam blocks of every XCD poll them: the data is the flag.  18 MB of partial gradients never leave the L2s; 2.3 MB of granules do.
+// reduction + Adam blocks of every XCD poll them: the data is the flag.  The 18 MB of partial gradients are read back from the L2 they were written to -- no other XCD waits for them; they drain to memory
+// when the launch ends, like any dirty line (PMC: 23 MB written per launch in either form) -- and 2.3 MB of granules cross.
 // "Row complete" travels twice: as a word in memory (agent scope, with the "written through" flag), and -- from workgroups that are where they should
 // be -- as a word in the XCD's L2 (ordinary store; read with an atomic OR of 0, which the L2 executes: an sc0 load may be served by this CU's own vector
 // cache, and was 0.8 us slower to notice), which is what the group normally sees first.  A row whose workgroup was NOT on XCD x was
