@@ -659,7 +659,8 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         const int slot = (vb - 1) * SPB + tid / STG;
         if (slot < batch) st_slot = slot;
     }
-    if (st_slot >= 0) st_v = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), st_slot, st_e);
+    const uint64_t base_n = stager ? mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)) : 0;      // (read once, here: the counter may move once every block has its ticket)
+    if (st_slot >= 0) st_v = staged_value(base_n, st_slot, st_e);
     // Segment `seg` of a column = the rows w = seg (mod RED_SEG), ascending (round 4; was: RED_SEG contiguous blocks of rows) -- the rows whose
     // workgroups share an XCD (block index % 8), which is what lets the one-launch step sum a segment inside that XCD's L2 (`grouped`: the eight
     // segment sums are already formed, in ws_grp; one row per segment is left to read).  Same order in every path: all of them stay bit-identical.
@@ -778,6 +779,10 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     for (int j = 0; j < VPB; ++j) red[j][seg][cx] = acc[j];
     late = __syncthreads_or(late);      // (a bounded wait that ran out anywhere in the block poisons the block's output)
     PH3(2);
+    // This block's ticket, taken HERE -- behind a barrier that every read of the epoch, the Adam step and the generator's counter above sits in front of -- and
+    // looked at only at the very end: the round trip of the atomic (~1 us) runs under the norm exchange instead of between Adam and the end of the launch.
+    unsigned ticket_old = 0;
+    if (tid == 0) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seg == 0)
 #pragma unroll
     for (int j = 0; j < VPB; ++j) {
@@ -839,7 +844,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         for (int j = vb - 1 + (n_phys - 1); j * SPB < batch; j += n_phys - 1) {
             const int slot = j * SPB + tid / STG;
             if (slot < batch)
-                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), slot, st_e);
+                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(base_n, slot, st_e);
         }
     // Adam's bias corrections (two float64 pow: ~500 instructions) by a thread of the last wave, which has nothing else to do while waves 0-3 poll the
     // norm partials -- not behind the poll, and not in front of the barrier the partials are published behind; read after the barrier that follows the poll
@@ -883,14 +888,12 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         v[p[j]] = vv;
         params[p[j]] = pp[j] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
-    // the block that finishes LAST advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
-    // (every block read all of them before taking its ticket)
-    __syncthreads();
+    // the block that took the LAST ticket advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
+    // (every block read all of them before taking its ticket; nothing in this launch reads them after that)
     PH3(4);
     if (tid == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == n_phys - 1) {
+        if (ticket_old == (unsigned)n_phys - 1u) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
             *step = *step + 1;
