@@ -1540,7 +1540,9 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         const int slot = ((int)blockIdx.x - 1) * SPB + threadIdx.x / STG;
         if (slot < batch) st_slot = slot;
     }
-    if (st_slot >= 0) st_v = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), st_slot, st_e);   // base = sample_base after this step's increment
+    const uint64_t base_n = stager ? mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)) : 0;   // = sample_base after this step's increment (read once: see the ticket)
+    const uint64_t epoch0 = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part));
+    if (st_slot >= 0) st_v = staged_value(base_n, st_slot, st_e);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // segment seg = the rows w = seg (mod RED_SEG), ascending (see reduce_adam_body)
     if (col < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col;
@@ -1557,6 +1559,9 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     red[seg][cx] = v;
     __syncthreads();
     PH2(0, 2);
+    // this block's ticket, behind a barrier that its reads of the epoch and the generator's counter sit in front of, looked at only at the end (see reduce_adam_body)
+    unsigned ticket_old = 0;
+    if (threadIdx.x == 0) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seg == 0) {
         float4 s = red[0][cx];
 #pragma unroll
@@ -1575,7 +1580,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
             // 8-byte granules {step tag, value}, system scope -- the peers' gather kernels poll them, the data is the flag
             const uint64_t mb = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 10);
             if (mb) {
-                const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);     // the epoch this step ends with
+                const uint32_t tag = xchg_tag(epoch0 + 1);     // the epoch this step ends with
                 gu64 *dst = reinterpret_cast<gu64 *>(mb) + (size_t)(tag & 1u) * P_PAD + p;
                 const float e[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
@@ -1610,17 +1615,15 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         for (int j = (int)blockIdx.x - 1 + ((int)gridDim.x - 1); j * SPB < batch; j += (int)gridDim.x - 1) {
             const int slot = j * SPB + threadIdx.x / STG;
             if (slot < batch)
-                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)), slot, st_e);
+                ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(base_n, slot, st_e);
         }
     // the block that finishes LAST advances the generator's call counter (the batch of this step was drawn by iqn_train_fwdbwd; the
     // staging blocks above read the old value) and the hand-off epoch, and tags the staged batch
-    __syncthreads();
     if (threadIdx.x == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
+        if (ticket_old == gridDim.x - 1) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
+            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) = epoch0 + 1;
             uint64_t *stg_tag = reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part) + 4);
             if (rng_state) {
                 const uint64_t c = rng_state[1] + 1;
@@ -1733,10 +1736,14 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     float part = 0.f;
     for (int c = threadIdx.x; c < N_RED; c += 256) part += blocksq[c];
     int t_step = 0;
+    unsigned ticket_old = 0;
     if (threadIdx.x == 255) {
         t_step = *step + 1;
         // python-float (double) scalars of torch's Adam, rounded to float32 where the tensor kernels consume them
         s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        // this block's ticket, taken once its read of the step counter has been consumed and looked at only at the end: the atomic's round trip (~1 us)
+        // runs under the second pow and the norm instead of behind the parameter stores
+        ticket_old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
     }
     // wave sums in a fixed order (DPP row / bank shuffles), then the four wave sums
@@ -1760,13 +1767,10 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
         params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
     PH2(1, 2);
-    // the block that finishes LAST stores the advanced counter: every block's thread 255 read it before taking its ticket
-    if (threadIdx.x == 255) {
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *step = t_step;
-        }
+    // the block with the LAST ticket stores the advanced counter: every block's thread 255 read it before taking its ticket
+    if (threadIdx.x == 255 && ticket_old == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *step = t_step;
     }
 }
 
@@ -1829,9 +1833,11 @@ __global__ __launch_bounds__(256) void iqn_adam_xchg(XchgPeers peers, int world,
     }
     if (late) atomicAdd(status, 1u);
     int t_step = 0;
+    unsigned ticket_old = 0;
     if (tid == 255) {
         t_step = *step + 1;
         s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
+        ticket_old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (see iqn_adam)
         s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
     }
 #pragma unroll
@@ -1853,12 +1859,9 @@ __global__ __launch_bounds__(256) void iqn_adam_xchg(XchgPeers peers, int world,
         v[p] = vv;
         params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
     }
-    if (tid == 255) {
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *step = t_step;
-        }
+    if (tid == 255 && ticket_old == gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *step = t_step;
     }
 }
 
