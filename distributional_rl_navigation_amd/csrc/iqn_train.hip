@@ -599,6 +599,11 @@ static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "
 // `vb` of `nvb` = the block's index among the reduction blocks (the stand-alone launch: vb; as the third role of the forward / backward
 // launch: vb - its workgroups).  `done` != NULL (third role): the partial gradients are being written by workgroups of the SAME launch;
 // done[w] == done_tag says workgroup w's partial row and loss partial are complete -- each wave waits for the 16 rows of its segment.
+// (defined with group_reduce below) wavefront 0 waits for the "row complete" news of the rows w = x (mod 8); returns the mask of rows that were written
+// through to memory instead of into this XCD's L2, *late = a bounded wait ran out
+__device__ __forceinline__ unsigned long long group_rows_wait(float *__restrict__ ws, int n_part, int x, uint32_t tag, int tid, bool *late);
+__device__ __forceinline__ void group_put(const __amdgpu_buffer_rsrc_t &grp, uint32_t tag, int c, float4 acc);
+
 // Physical block `pb` of `n_phys` runs the virtual blocks vb = pb, pb + n_phys, ... < nvb (at most VPB of them; VPB = 1 and n_phys = nvb everywhere but in the
 // XCD-grouped one-launch step, whose 128 resident blocks cover the 140 virtual ones -- a block dispatched later than the others holds everybody's Adam up).
 template <int VPB = 1>
@@ -688,6 +693,44 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         // XCD-grouped one-launch step: the eight segment sums arrive as self-tagged granules (group_reduce) -- thread (cx, seg) polls the four of
         // column `col` of group row `seg`, block 0 the n_part loss partials.  No flag, no fence: the data is the flag.
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        // The buddy: reduction block pb sits (like local workgroup pb of the launch) on XCD pb mod 8 with nothing to do until the granules arrive -- it takes the
+        // second half of local workgroup (pb mod 8) + 8 (pb / 8)'s share of its group's row sum, so that a CU moves 72 KB out of the L2 instead of 143 (the L2 ->
+        // CU path, 64 B per clock, is what a share takes).  Only when there is exactly one reduction block per local workgroup and 16 rows per group (batch
+        // 256), the block really is on its group's XCD, and no row of the group went through memory; it says so in ws_gdone (unused by the grouped form
+        // otherwise) when it starts, and the local workgroup halves its share only if it reads that.  A local workgroup that looked too early does the
+        // whole share: the same granules twice, bit for bit.
+        if (done && n_phys == n_part && n_part == 128) {
+            __shared__ int s_buddy;
+            const int bx = pb & 7;
+            if (tid == 0) {
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                const uint64_t lw = __hip_atomic_load((const gu64 *)(ws + ws_xcc(n_part)) + bx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (uint32_t)(lw >> 32) == done_tag && (unsigned)(lw & 15u) == (xcc & 15u);
+                if (ok) __hip_atomic_store(const_cast<uint32_t *>(done) + pb, done_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_buddy = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_buddy) {
+                bool glate = false;
+                const unsigned long long gmis = group_rows_wait(ws, n_part, bx, done_tag, tid, &glate);
+                if (gmis == 0 && !glate) {
+                    constexpr int PER = (N_COLS + 15) / 16, HALF = PER / 2;      // 560 columns per local workgroup, 280 of them here
+                    const int c = (pb >> 3) * PER + HALF + tid, c1 = min(N_COLS, (pb >> 3) * PER + PER);
+                    if (tid < PER - HALF && c < c1) {
+                        const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
+                        const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)bx * P_PAD, 0, P_PAD * 8, 0x00020000);
+                        float4 t[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((bx + 8 * u) * N_COLS + c) * 16, 0, 1));
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+                        group_put(grp, done_tag, c, a);
+                    }
+                }
+            }
+        }
         // (Measured and dropped, +0.6 .. +0.9 us per step each: one wavefront per block first watching the "row complete" words, or "share issued" hints
         // stored behind the granule stores, before everybody looks for the granules.)
         if (vb == 0 && tid < 256) {
@@ -939,32 +982,22 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
 // cache, and was 0.8 us slower to notice), which is what the group normally sees first.  A row whose workgroup was NOT on XCD x was
 // written through and is read with sc1 loads; such a workgroup takes no share (it cannot see the others' rows) unless the whole group is like that.
 // The arithmetic does not depend on any of this.
-__device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part, int part, uint32_t tag, int tid) {
-    static_assert(RED_SEG == 8, "one segment per XCD");
+__device__ __forceinline__ unsigned long long group_rows_wait(float *__restrict__ ws, int n_part, int x, uint32_t tag, int tid, bool *late_out) {
     __shared__ unsigned long long s_mis;
     __shared__ int s_late;
-    const int x = part & 7, gi = part >> 3, gsz = n_part >> 3;      // n_part % 8 == 0, gsz <= 64 (MAX_BATCH / BE / 8)
+    const int gsz = n_part >> 3;      // n_part % 8 == 0, gsz <= 64 (MAX_BATCH / BE / 8)
     const gu64 *done = (const gu64 *)(ws + ws_done(n_part));
     if (tid < 64) {
         bool have = tid >= gsz, mis_row = false, late = false;
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         for (int it = 0;; ++it) {
             if (!have) {
-#ifndef MN_LFLAG_POLL
-#define MN_LFLAG_POLL 2
-#endif
-#if MN_LFLAG_POLL == 0
-                const uint32_t lf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(lflag, 4 * tid, 0, 1);       // sc0
-#elif MN_LFLAG_POLL == 1
-                const uint32_t lf = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(lflag, 4 * tid, 0, 16);      // sc1
-#else
                 uint32_t lf;      // an atomic OR of 0 with return: executed by the L2, whatever this CU's vector cache holds
                 {
                     uint32_t *lp = reinterpret_cast<uint32_t *>(ws + ws_lflag(n_part) + 64 * x) + tid;
                     const uint32_t zero = 0;
                     asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(lf) : "v"(lp), "v"(zero) : "memory");
                 }
-#endif
                 if (lf == tag) have = true;
                 else if ((it & 3) == 3) {                                                                           // every fourth look: the word in memory
                     const uint64_t v = __hip_atomic_load(done + x + 8 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -979,6 +1012,26 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         if (tid == 0) { s_mis = mis; s_late = late; }
     }
     __syncthreads();
+    *late_out = s_late != 0;
+    return s_mis;
+}
+
+// column c of a group row: four self-tagged granules, two per 16-byte store, written through (sc1)
+__device__ __forceinline__ void group_put(const __amdgpu_buffer_rsrc_t &grp, uint32_t tag, int c, float4 acc) {
+    const u32x4s lo = {__float_as_uint(acc.x), tag, __float_as_uint(acc.y), tag}, hi = {__float_as_uint(acc.z), tag, __float_as_uint(acc.w), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(lo, grp, c * 32, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, grp, c * 32 + 16, 0, 16);
+}
+
+__device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part, int part, uint32_t tag, int tid) {
+    static_assert(RED_SEG == 8, "one segment per XCD");
+    const int x = part & 7, gi = part >> 3, gsz = n_part >> 3;
+    // the buddy's word (see reduce_adam_body), requested now, looked at behind the wait
+    uint32_t buddy_word = 0;
+    if (n_part == 128) buddy_word = __hip_atomic_load(reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part)) + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool late_w = false;
+    const unsigned long long s_mis = group_rows_wait(ws, n_part, x, tag, tid, &late_w);
+    const int s_late = late_w ? 1 : 0;
 #ifdef MN_TRAIN_PHASES
     if (threadIdx.x == 0) g_wgt[blockIdx.x][3] = wall_clock64();
 #endif
@@ -999,6 +1052,19 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
 #ifndef MN_GROUP_FAST
 #define MN_GROUP_FAST 1
 #endif
+    if (MN_GROUP_FAST && mis == 0 && gsz == 16 && buddy_word == tag) {
+        // ... and the XCD's reduction block number `part` has taken the second half of this share (reduce_adam_body): 280 columns, one per thread, one round of loads
+        constexpr int HALF = ((N_COLS + 15) / 16) / 2;
+        const int ca = c0 + (tid < HALF ? tid : 0);      // (threads beyond the half all read column c0 and drop it: no branch between the loads)
+        float4 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, 1));
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
+        if (tid < HALF && ca < c1) put(ca, a);
+        return;
+    }
     if (MN_GROUP_FAST && mis == 0 && gsz == 16) {
         // The case that runs (batch 256, every workgroup on its XCD): straight-line code, all of a thread's loads in flight before its first add.  With 16
         // takers a share is 560 columns -- 48 threads have a second one (the others all read column c0 again and drop it: no branch between the loads, which
