@@ -79,6 +79,7 @@ SIGNATURES = [
     ("mn_last_done_count", C.c_int, [_vp, _vp, _pi32]),
     ("mn_profile_begin", C.c_int, [_vp, _i32]),
     ("mn_profile_end", C.c_int, [_vp, _vp, _pd, _pi32]),
+    ("mn_profile_reset_end", C.c_int, [_vp, _vp, _pd, _pi32]),
     ("mn_iqn_create", C.c_int, [C.POINTER(_vp)]),
     ("mn_iqn_destroy", C.c_int, [_vp]),
     ("mn_iqn_weights_changed", C.c_int, [_vp]),
@@ -97,7 +98,11 @@ SIGNATURES = [
     ("mn_xchg_import", C.c_int, [_vp, _i32, _vp]),
     ("mn_xchg_attach", C.c_int, [_vp, _vp, _i32, _vp]),
     ("mn_iqn_train_exchange", C.c_int, [_vp, _vp, _vp, _i32, C.c_float, _vp]),
-    ("mn_iqn_train_exchange_adam", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_float, _vp]),
+    ("mn_xchg_memory_kind", C.c_int, [_vp]),
+    ("mn_xchg_set_timeout_ms", C.c_int, [_vp, _i64]),
+    ("mn_iqn_train_plan", C.c_int, [_i32, _i32, _i32]),
+    ("mn_iqn_train_set_cu_limit", C.c_int, [_i32]),
+    ("mn_iqn_train_workspace_status_word", C.c_int64, [_i32]),
     ("mn_iqn_train_step_xchg", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float,
                                          _i32, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_float, _vp]),
     ("mn_xchg_status", C.c_int, [_vp, _pi32]),

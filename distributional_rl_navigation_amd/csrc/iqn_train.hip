@@ -509,8 +509,11 @@ __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_par
 // [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] count of local workgroups of
 // XCD-grouped one-launch steps that did not run on the XCD of their group's first workgroup (u32, diagnostic: their rows took the slow way through memory),
 // [10..11] device pointer (u64) of this rank's gradient mailbox, 0 = none (mn_xchg_attach: the reduction kernel publishes into it)
-// [12 ..] N_RED self-tagged norm partials (u64) of the fused reduction + Adam launch (iqn_grad_reduce_adam)
-__host__ __device__ constexpr int64_t ws_xsq(int n_part) { return ws_epoch(n_part) + 12; }
+// [12] count (u32) of reduction + Adam blocks of which a bounded wait ran out, ever (hand-off inside the launch, or a peer's granules in the shared learner's
+// exchange): such a block leaves moments and parameters untouched and writes NaN into its piece of the gradient; the caller reads the word at its
+// evaluation points and raises (mn_iqn_train_workspace_status_word), [13..15] reserved
+// [16 ..] N_RED self-tagged norm partials (u64) of the fused reduction + Adam launch (iqn_grad_reduce_adam)
+__host__ __device__ constexpr int64_t ws_xsq(int n_part) { return ws_epoch(n_part) + 16; }
 // then, for the one-launch step:
 //   ws_done   n_part "row complete" words (u64 {step tag, flags}, agent scope: workgroup w's partial-gradient row is final; flag bit 0 = the row was written
 //             through to memory because the workgroup did not run on XCD (block index % 8))
@@ -551,11 +554,20 @@ constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
 constexpr int RED_MAX_PER = 128 / RED_SEG;   // covers batch <= 256 with every load in flight; larger batches loop
 
 constexpr int XCHG_MAX_RANKS = 8;
-struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS + 1]; };      // by rank; mb[world] = this rank's own mailbox once more (the alias the fused step writes through)
+struct XchgPeers { const gu64 *mb[XCHG_MAX_RANKS]; };      // by rank (this rank's own included)
+// the shared learner's exchange as the reduction + Adam blocks see it: a small record in DEVICE memory (mn_xchg keeps it current) that the kernels get a pointer
+// to -- as a by-value kernel argument its eleven pointers sat in scalar registers through the whole forward / backward kernel (126 spilled, scratch)
+struct XchgArgs {
+    XchgPeers peers;
+    gu64 *own;             // this rank's mailbox (writable; a field of its own: indexing peers.mb[] with a run-time rank would put the struct into scratch)
+    int world;
+    unsigned *status;      // device word: blocks whose gather ran into the bound
+    uint64_t bound;        // ticks of the 100 MHz counter a gather waits for a peer's granules
+};
 // e[0..3] = sum over ranks, IN RANK ORDER, of granules q .. q + 3 of the step tagged `tag`.  All ranks' granules are requested together
 // (independent system-scope loads in flight over the fabric at once, not one round trip per peer); a pass that finds a stale tag is repeated
-// as a whole.  Returns true if the bound (~2 s of the 100 MHz counter) was hit.
-__device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, uint32_t tag, int q, float (&e)[4]) {
+// as a whole.  Returns true if the bound (ticks of the 100 MHz counter: mn_xchg_set_timeout_ms) was hit.
+__device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, uint32_t tag, int q, float (&e)[4], uint64_t bound = 200000000ull) {
     uint64_t x[XCHG_MAX_RANKS][4];
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     bool late = false;
@@ -574,7 +586,7 @@ __device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ok = ok && (uint32_t)(x[r][k] >> 32) == tag;
         if (ok) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > bound) { late = true; break; }
         __builtin_amdgcn_s_sleep(8);
     }
 #pragma unroll
@@ -591,7 +603,7 @@ __device__ __forceinline__ bool xchg_gather4(const XchgPeers &peers, int world, 
 // segment seg of the partials of column 64 b + cx with every load in flight, the eight segment sums are combined in iqn_grad_reduce's order --
 // forms the two norm partials those columns make up (iqn_grad_reduce's blocks 2 b and 2 b + 1: same grouping, same order), publishes them as
 // self-tagged granules in the workspace, and runs iqn_adam's body for its 256 parameters on the 280 partials it polls: the partials are the
-// grid-wide dependency, no barrier, no third launch (the pattern of iqn_adam_xchg).  Loss, staging of the next batch, generator counter and
+// grid-wide dependency, no barrier, no third launch.  Loss, staging of the next batch, generator counter and
 // hand-off epoch as in iqn_grad_reduce.  Every sum in the order of the three-launch path: BIT-IDENTICAL to iqn_grad_reduce + iqn_adam.
 // All 140 blocks are resident together (the polls are bounded anyway: ~2 s, then the loss is NaN).
 constexpr int RA_COLS = 64, RA_BT = RA_COLS * RED_SEG;      // 512 threads: one wavefront per segment
@@ -611,7 +623,9 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
                                                  float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
                                                  float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
                                                  double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag,
-                                                 const XchgPeers *peers = nullptr, int world = 1, float grad_scale = 1.0f, bool grouped = false) {
+                                                 const XchgArgs *xa = nullptr, float grad_scale = 1.0f, bool grouped = false) {
+    const XchgPeers *peers = xa ? &xa->peers : nullptr;
+    const int world = xa ? xa->world : 1;
     __shared__ float4 red[VPB][RED_SEG][RA_COLS];
     __shared__ float sq[VPB][RA_COLS];
     __shared__ float gsh[VPB][4 * RA_COLS];
@@ -840,11 +854,14 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         }
         if (peers) {      // shared learner, one-shot exchange IN this launch (mn_iqn_train_step_xchg): publish this rank's columns, gather every rank's
             if (on[j] && col[j] < N_COLS) {
-                gu64 *dst = (gu64 *)peers->mb[world] + (size_t)(tag & 1u) * P_PAD + 4 * col[j];      // mb[world] = this rank's own mailbox (writable alias)
+                gu64 *dst = xa->own + (size_t)(tag & 1u) * P_PAD + 4 * col[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     __hip_atomic_store(dst + k, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(e[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                late = xchg_gather4(*peers, world, tag, 4 * col[j], e) || late;
+                if (xchg_gather4(*peers, world, tag, 4 * col[j], e, xa->bound)) {
+                    late = true;
+                    atomicAdd(xa->status, 1u);      // (mn_xchg_status: a peer's granules did not arrive)
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (4 * col[j] + k >= P_TOTAL) e[k] = 0.f;
@@ -852,13 +869,13 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             float sc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) sc[k] = e[k] * grad_scale;
-            ss = ((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]) + sc[3] * sc[3];      // iqn_grad_sumsq's / iqn_adam_xchg's expression
+            ss = ((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]) + sc[3] * sc[3];      // iqn_grad_sumsq's expression
         }
         sq[j][cx] = ss;
 #pragma unroll
         for (int k = 0; k < 4; ++k) gsh[j][4 * cx + k] = e[k];
     }
-    __syncthreads();
+    late = __syncthreads_or(late);      // (the exchange's gather may have run into its bound in some thread)
     gu64 *xsq = (gu64 *)(ws + ws_xsq(n_part));
     if (tid == 0 || tid == RED_COLS)
 #pragma unroll
@@ -913,18 +930,23 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (tid < 256 && (tid & 63) == 0) nred[tid >> 6] = part;
-    __syncthreads();
+    late = __syncthreads_or(late);
     const float sumsq = (nred[0] + nred[1]) + (nred[2] + nred[3]);
     const float norm = sqrtf(sumsq);
     const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
     const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
     const float wm = (float)(1.0 - b1), b2f = (float)b2, wv = (float)(1.0 - b2), eps = (float)eps_d;
+    // A bounded wait ran out somewhere in this block (a hand-off inside the launch, or a peer's granules): what it holds is not this step's gradient.
+    // Moments and parameters stay as they are, its piece of the gradient is NaN, and the workspace's status word counts the block -- the caller looks at
+    // the word at its evaluation points and raises (a shared learner's replicas would otherwise drift apart silently).
+    if (late && tid == 0) atomicAdd(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 12), 1u);
 #pragma unroll
     for (int j = 0; j < VPB; ++j)
     if (on[j] && tid < 256 && p[j] < P_TOTAL) {
         float gq = gsh[j][tid] * grad_scale;
         gq *= coef;
-        grad[p[j]] = late ? __builtin_nanf("") : gq;      // the (clipped) gradient, as iqn_adam leaves it
+        if (late) { grad[p[j]] = __builtin_nanf(""); continue; }
+        grad[p[j]] = gq;      // the (clipped) gradient, as iqn_adam leaves it
         const float mm = mp[j] + (gq - mp[j]) * wm;
         const float vv = vp[j] * b2f + wv * (gq * gq);
         m[p[j]] = mm;
@@ -965,10 +987,9 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
                                                                    uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
                                                                    float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                                    int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d,
-                                                                   XchgPeers peers, int world, float grad_scale, unsigned *__restrict__ status) {
+                                                                   const XchgArgs *__restrict__ xa, float grad_scale) {
     reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u,
-                        &peers, world, grad_scale);
-    (void)status;
+                        xa, grad_scale);
 }
 
 // One-launch step, XCD-grouped (StepTail::hier): the local workgroups of group x = the rows w = x (mod 8) = the workgroups the dispatcher put on XCD x.
@@ -1132,8 +1153,13 @@ struct StepTail {
     int32_t *step;
     uint64_t *rng_state;
     double lr, b1, b2, eps, max_norm;
+    const XchgArgs *xa; // shared learner (non-NULL): the one-shot gradient exchange inside the reduction + Adam role, of xa_scale x the sum over ranks
+    float xa_scale;
 };
 
+// XCHG: the instantiation whose reduction + Adam role carries the shared learner's exchange (mn_iqn_train_step_xchg with MN_TRAIN_ONE_LAUNCH); the single learner's
+// kernel is compiled without that code (its eight mailbox pointers cost 75 more spilled scalar registers in a kernel that has none to spare).
+template <bool XCHG>
 __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const float *__restrict__ PL, const float *__restrict__ PT,
                                                             float *__restrict__ ws, int batch, float gamma, int mode, int use_staged, StepTail tail) {
     extern __shared__ __align__(16) float S[];
@@ -1149,10 +1175,10 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             const uint32_t *gd = reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part));
             if (tail.hier)      // XCD-grouped: tail.n_wg (>= half of them) blocks run the tail.n_virtual virtual ones
                 reduce_adam_body<2>((int)blockIdx.x - n_fwd, tail.n_wg, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
-                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, nullptr, 1, 1.0f, true);
+                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f, true);
             else
                 reduce_adam_body<1>((int)blockIdx.x - n_fwd, tail.n_virtual, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
-                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, nullptr, 1, 1.0f, false);
+                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f, false);
             return;
         }
     }
@@ -1566,7 +1592,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
 // squares of the reduced gradient (iqn_adam's norm), the loss (block 0), the generator's call counter and the hand-off epoch.
 __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__restrict__ ws, int n_part, float *__restrict__ grad,
                                                                        float *__restrict__ loss_out, uint64_t *__restrict__ rng_state,
-                                                                       BatchArgs ba, int prefetch_next) {
+                                                                       BatchArgs ba, int prefetch_next, uint64_t mailbox) {
     __shared__ float4 red[RED_SEG][RED_COLS];
     __shared__ float sq[RED_COLS];
     const int cx = threadIdx.x % RED_COLS, seg = threadIdx.x / RED_COLS;
@@ -1644,7 +1670,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
             ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
             // one-shot exchange of a shared learner (mn_xchg_*): the reduced gradient also goes to this rank's mailbox as self-tagged
             // 8-byte granules {step tag, value}, system scope -- the peers' gather kernels poll them, the data is the flag
-            const uint64_t mb = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 10);
+            const uint64_t mb = mailbox ? mailbox : *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 10);      // (argument, or mn_xchg_attach's word)
             if (mb) {
                 const uint32_t tag = xchg_tag(epoch0 + 1);     // the epoch this step ends with
                 gu64 *dst = reinterpret_cast<gu64 *>(mb) + (size_t)(tag & 1u) * P_PAD + p;
@@ -1745,7 +1771,7 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restri
 // gather of step k + 1, which needed every peer's step k + 1, which every peer published after ITS gather of step k.
 __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int world, const float *__restrict__ ws, int n_part,
                                                             float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale,
-                                                            unsigned *__restrict__ status) {
+                                                            unsigned *__restrict__ status, uint64_t bound) {
     __shared__ float sq[RED_COLS];
     const int q = (blockIdx.x * RED_COLS + threadIdx.x) * 4;
     const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)));      // (the reduction kernel advanced the epoch)
@@ -1764,13 +1790,16 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int
                     ok = ok && (uint32_t)(x[k] >> 32) == tag;
                 }
                 if (ok) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > bound) { late = true; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) e[k] += __uint_as_float((uint32_t)x[k]);
         }
-        if (late) atomicAdd(status, 1u);
+        if (late) {      // a peer's granules never came: the step must not look valid (mn_xchg_status counts it; the gradient and with it the norm are NaN)
+            atomicAdd(status, 1u);
+            e[0] = __builtin_nanf("");
+        }
         if (q + 3 < P_TOTAL) *reinterpret_cast<float4 *>(grad + q) = make_float4(e[0], e[1], e[2], e[3]);
         else
             for (int k = 0; k < 4; ++k)
@@ -1823,7 +1852,10 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
     const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
     const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
-    if (p < P_TOTAL) {
+    const bool bad = !(sumsq == sumsq);      // NaN norm: the exchange in front of this launch timed out (iqn_grad_gather) -- nothing is updated, the status word counts it
+    if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ticket + 10, 1u);      // (ticket = epoch block + 2; + 10 = the workspace's status word)
+    if (p < P_TOTAL && bad) grad[p] = __builtin_nanf("");
+    if (p < P_TOTAL && !bad) {
         gq *= coef;
         grad[p] = gq;
         const float mm = mp + (gq - mp) * w1;                 // lerp, as torch's _single_tensor_adam
@@ -1835,97 +1867,6 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     PH2(1, 2);
     // the block with the LAST ticket stores the advanced counter: every block's thread 255 read it before taking its ticket
     if (threadIdx.x == 255 && ticket_old == gridDim.x - 1) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *step = t_step;
-    }
-}
-
-// The one-shot exchange AND the optimizer step in one launch (mn_iqn_train_exchange_adam): a shared learner's gradient step then has the
-// same three launches as an independent learner's.  Block b (of iqn_adam's 140) first gathers ITS 256 parameters' gradients from every
-// rank's mailbox -- threads 0..63, one float4 column each, exactly iqn_grad_gather's work for columns [64 b, 64 b + 64) -- and forms the two
-// norm partials those columns make up (iqn_grad_sumsq's blocks 2 b and 2 b + 1: same grouping, same order), publishes them as self-tagged
-// granules in this rank's private partial array, and then runs iqn_adam's own body, reading all 280 partials by polling their tags: the
-// partials ARE the grid-wide dependency, no barrier and no second launch.  Every sum is formed in the order the two-launch path forms it:
-// bit-identical to mn_iqn_train_exchange + mn_iqn_train_adam.  (All 140 blocks of 256 threads are resident together on any device this
-// library targets; the polls are bounded like iqn_grad_gather's.)
-__global__ __launch_bounds__(256) void iqn_adam_xchg(XchgPeers peers, int world, gu64 *__restrict__ xsq, const float *__restrict__ ws, int n_part,
-                                                     float *__restrict__ params, float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
-                                                     int32_t *__restrict__ step, unsigned *__restrict__ ticket, double lr, double b1, double b2,
-                                                     double eps_d, double max_norm_d, float grad_scale, unsigned *__restrict__ status) {
-    __shared__ float red[4];
-    __shared__ float s_bc[2];
-    __shared__ float sq[64];
-    __shared__ float gsh[256];
-    const int tid = threadIdx.x, p = blockIdx.x * 256 + tid;
-    if (ticket[6] != WS_MAGIC) return;
-    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)));
-    float mp = 0.f, vp = 0.f, pp = 0.f;
-    if (p < P_TOTAL) { mp = m[p]; vp = v[p]; pp = params[p]; }
-    bool late = false;
-    if (tid < 64) {
-        const int q = (blockIdx.x * 64 + tid) * 4;
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (q < P_PAD) {
-            late = xchg_gather4(peers, world, tag, q, e);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (q + k >= P_TOTAL) e[k] = 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gsh[4 * tid + k] = e[k];
-        float s[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = e[k] * grad_scale;
-        sq[tid] = ((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]) + s[3] * s[3];
-    }
-    __syncthreads();
-    if (tid == 0 || tid == 32) {
-        float t = 0.f;
-        for (int k = 0; k < RED_COLS; ++k) t += sq[tid + k];
-        __hip_atomic_store(xsq + 2 * blockIdx.x + (tid >> 5), ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    static_assert(RED_COLS == 32 && N_RED == 2 * N_ADAM, "an Adam block's 256 parameters are two norm partials of 32 float4 columns");
-    float part = 0.f;
-    for (int c = tid; c < N_RED; c += 256) {
-        uint64_t x;
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        for (;;) {
-            x = __hip_atomic_load(xsq + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(x >> 32) == tag) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        part += __uint_as_float((uint32_t)x);
-    }
-    if (late) atomicAdd(status, 1u);
-    int t_step = 0;
-    unsigned ticket_old = 0;
-    if (tid == 255) {
-        t_step = *step + 1;
-        s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
-        ticket_old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (see iqn_adam)
-        s_bc[1] = (float)sqrt(1.0 - pow(b2, (double)t_step));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    const float sumsq = (red[0] + red[1]) + (red[2] + red[3]);
-    const float norm = sqrtf(sumsq);
-    const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
-    const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
-    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
-    if (p < P_TOTAL) {
-        float gq = gsh[tid] * grad_scale;
-        gq *= coef;
-        grad[p] = gq;
-        const float mm = mp + (gq - mp) * w1;
-        const float vv = vp * b2f + w2 * (gq * gq);
-        m[p] = mm;
-        v[p] = vv;
-        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
-    }
-    if (tid == 255 && ticket_old == gridDim.x - 1) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *step = t_step;
     }
@@ -1985,6 +1926,13 @@ extern "C" int64_t mn_iqn_train_workspace_misplaced_word(int32_t batch) {
     return ws_epoch(batch / BE) + 9;
 }
 
+// float index of the u32 status word: reduction + Adam blocks of which a bounded wait ran out since mn_iqn_train_workspace_init (0 in a healthy run; such a block
+// skipped its update -- the caller must treat a non-zero count as an error)
+extern "C" int64_t mn_iqn_train_workspace_status_word(int32_t batch) {
+    if (batch <= 0 || batch > MAX_BATCH || batch % BE) return -1;
+    return ws_epoch(batch / BE) + 12;
+}
+
 extern "C" int64_t mn_iqn_train_workspace_floats(int32_t batch) {
     if (batch <= 0 || batch % BE) return -1;
     return ws_total(batch / BE);
@@ -2000,16 +1948,121 @@ extern "C" int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void
     return MN_OK;
 }
 
-struct mn_xchg;
-struct AdamArgs {      // non-null: the reduction launch also performs clip + Adam (iqn_grad_reduce_adam): two launches per gradient step
+struct mn_xchg {
+    int rank = 0, world = 1, device = -1;
+    gu64 *own = nullptr;                       // [2][P_PAD] granules, this rank's reduced gradient of the last two steps
+    const gu64 *peer[XCHG_MAX_RANKS] = {};     // own + IPC-mapped peers, by rank
+    bool opened[XCHG_MAX_RANKS] = {};
+    unsigned *status = nullptr;                // device word: number of granule groups that timed out
+    int kind = 0;                              // how `own` was allocated: 2 = uncached, 1 = fine-grained, 0 = plain hipMalloc (see mn_xchg_create)
+    uint64_t bound = 200000000ull;             // ticks of the 100 MHz counter a gather waits for a peer's granules (mn_xchg_set_timeout_ms)
+    XchgArgs *dev_args = nullptr;              // the record above in device memory, as the fused kernels read it (xchg_sync)
+};
+
+struct AdamArgs {      // non-null: the step also performs clip + Adam (mn_iqn_train_step*)
     float *params, *exp_avg, *exp_avg_sq;
     int32_t *step_dev;
     double lr, beta1, beta2, eps, max_norm;
-    const XchgPeers *peers;      // shared learner: the one-shot exchange inside the same launch
-    int world;
+    const mn_xchg *x;      // shared learner: the one-shot exchange inside the same launch
     float grad_scale;
-    unsigned *status;
 };
+
+// ---- what this device can hold at once ------------------------------------------------------------------------------------------------------
+// The fused forms wait, inside a launch, for other workgroups of the SAME launch: the local workgroups of the one-launch step for the rows of their XCD group, the
+// reduction + Adam blocks for each other's norm partials.  That is only safe while those workgroups are resident together, which depends on the device (a
+// partitioned MI300-class part in CPX mode shows 32 CUs, not 256) -- so the launch plan is made from the device's CU count and the kernels' occupancy, not
+// from the constant 256 (round 5), and falls back to the forms without in-launch waits between workgroups of one role: three launches (four with
+// the shared learner's exchange).  mn_iqn_train_set_cu_limit: plan as if the device had fewer CUs (tests; two ranks sharing one GPU plan for half of it each).
+struct DevInfo { bool known; int n_cu, ra_per_cu, rax_per_cu; };
+static int g_cu_limit = 0;
+static int dev_info(DevInfo *out) {
+    static std::mutex mu;
+    static DevInfo info[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
+    std::lock_guard<std::mutex> lock(mu);
+    DevInfo &d = info[dev];
+    if (!d.known) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
+        // the forward / backward kernel's dynamic LDS (97 KB) is above the default limit: raised once per device
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return MN_ERR_HIP;
+        int a = 0, b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void *>(iqn_grad_reduce_adam), RA_BT, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void *>(iqn_grad_reduce_adam_xchg), RA_BT, 0) != hipSuccess)
+            return MN_ERR_HIP;
+        d.n_cu = prop.multiProcessorCount;
+        d.ra_per_cu = std::max(1, a);
+        d.rax_per_cu = std::max(1, b);
+        d.known = true;
+    }
+    *out = d;
+    if (g_cu_limit > 0) out->n_cu = std::min(out->n_cu, g_cu_limit);
+    return MN_OK;
+}
+
+struct LaunchPlan {
+    int mode;        // MODE_TWO_ROLES / MODE_LOCAL_ONLY
+    int n_fwd;       // forward / backward workgroups
+    int launches;    // 1: reduction + Adam ride in the forward / backward launch; 2: + iqn_grad_reduce_adam[_xchg]; 3: + iqn_grad_reduce + iqn_adam; 4: + iqn_grad_reduce,
+                     // iqn_grad_gather, iqn_adam (shared learner on a device too small for the fused launch)
+    int hier, n_tail;
+};
+static LaunchPlan plan_launch(const DevInfo &d, int batch, int flags, bool adam, bool xchg) {
+    LaunchPlan p = {};
+    const int n_part = batch / BE;
+    // two-role launches need every local workgroup's target workgroup dispatched no later than itself (target workgroups have the lower block indices) and
+    // a CU for every workgroup; beyond that a local workgroup computes its own targets
+    p.mode = (g_train_mode == MODE_TWO_ROLES && 2 * n_part <= d.n_cu) ? MODE_TWO_ROLES : MODE_LOCAL_ONLY;
+    p.n_fwd = p.mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
+    if (!adam) { p.launches = 2; return p; }      // (mn_iqn_train_grad*: forward / backward + iqn_grad_reduce; Adam is the caller's next call)
+    if ((flags & MN_TRAIN_ONE_LAUNCH) && p.n_fwd <= d.n_cu) {
+        // every forward / backward workgroup has a CU of its own (the local ones wait for each other's rows) ...
+        p.hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
+        // grouped: only as many reduction + Adam blocks as find a CU while the local workgroups run (those the target workgroups vacate + those never used),
+        // each running up to two of the N_ADAM virtual blocks -- a block dispatched behind the local workgroups starts ~2 us late and everybody's Adam waits
+        // for its norm partials; ungrouped: all N_ADAM
+        p.n_tail = p.hier ? std::max((N_ADAM + 1) / 2, std::min(N_ADAM, d.n_cu - n_part)) : N_ADAM;
+        // ... and so has every reduction + Adam block once those are done (they wait for each other's norm partials)
+        if (p.n_tail <= d.n_cu) { p.launches = 1; return p; }
+    }
+    p.hier = p.n_tail = 0;
+    if (N_ADAM <= d.n_cu * (xchg ? d.rax_per_cu : d.ra_per_cu)) { p.launches = 2; return p; }      // all 140 blocks of the fused reduction + Adam launch resident
+    p.launches = xchg ? 4 : 3;
+    return p;
+}
+
+static int xchg_sync(mn_xchg *x) {      // (create / import / set_timeout: never on the step path)
+    XchgArgs xa = {};
+    for (int r = 0; r < x->world; ++r) xa.peers.mb[r] = x->peer[r];
+    xa.own = x->own;
+    xa.world = x->world;
+    xa.status = x->status;
+    xa.bound = x->bound;
+    return hipMemcpy(x->dev_args, &xa, sizeof(xa), hipMemcpyHostToDevice) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+static int launch_adam(float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace, int n_part, double lr, double beta1,
+                       double beta2, double eps, double max_norm, float grad_scale, hipStream_t s) {
+    unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(n_part) + 2);
+    hipLaunchKernelGGL(iqn_adam, dim3(N_ADAM), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, (const float *)(workspace + ws_sq(n_part)), step_dev, ticket, lr, beta1,
+                       beta2, eps, max_norm, grad_scale);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+static int launch_gather(const mn_xchg *x, float *grad, float *workspace, int n_part, float grad_scale, hipStream_t s) {
+    XchgPeers peers;
+    for (int r = 0; r < XCHG_MAX_RANKS; ++r) peers.mb[r] = nullptr;
+    for (int r = 0; r < x->world; ++r) {
+        peers.mb[r] = x->peer[r];
+        if (!peers.mb[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
+    }
+    hipLaunchKernelGGL(iqn_grad_gather, dim3(N_RED), dim3(RED_COLS), 0, s, peers, x->world, (const float *)workspace, n_part, grad, workspace + ws_sq(n_part), grad_scale,
+                       x->status, x->bound);
+    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
 
 static int launch_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                        const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev, const float *taus_target_dev,
@@ -2022,62 +2075,72 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     if (rng_state_dev ? (ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
         return MN_ERR_INVALID;
     if (batch <= 0 || batch > MAX_BATCH || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
-    {   // raise the dynamic-LDS limit once per device; guarded so that concurrent first calls from two threads are safe
-        static std::mutex mu;
-        static bool attr_set[64] = {false};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MN_ERR_HIP;
-        std::lock_guard<std::mutex> lock(mu);
-        if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    LDS_BYTES) != hipSuccess)
-                return MN_ERR_HIP;
-            attr_set[dev] = true;
-        }
-    }
+    DevInfo dev;
+    if (int rc = dev_info(&dev)) return rc;
     const int n_part = batch / BE;
-    // two-role launches need every local workgroup's target workgroup dispatched no later than itself: target workgroups have the
-    // lower block indices.  Beyond one workgroup per CU (batch > 256) a local workgroup computes its own targets instead.
-    const int mode = (g_train_mode == MODE_TWO_ROLES && 2 * n_part <= 256) ? MODE_TWO_ROLES : MODE_LOCAL_ONLY;
+    const mn_xchg *x = adam ? adam->x : nullptr;
+    if (x)
+        for (int r = 0; r < x->world; ++r)
+            if (!x->peer[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
+    const LaunchPlan plan = plan_launch(dev, batch, flags, adam != nullptr, x != nullptr);
     const BatchArgs ba = {ring_states, ring_next_states, ring_rewards, ring_dones, ring_actions, idx_dev, taus_target_dev,
                           taus_local_dev, (const uint64_t *)rng_state_dev, ring_size, idx_out, taus_out};
     hipStream_t s = (hipStream_t)stream;
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
-    const int n_fwd = mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
-    // one launch: only while every forward / backward workgroup has a CU of its own (they wait for each other), i.e. batch <= 512 (256 with two workgroup roles); otherwise two launches
-    if (adam && !adam->peers && (flags & MN_TRAIN_ONE_LAUNCH) && n_fwd <= 256) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
-        const int hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
-        // grouped: all reduction + Adam blocks that find a CU while the local workgroups run (those the target workgroups vacate + those never used); ungrouped: all
-        // grouped: only as many reduction + Adam blocks as find a CU while the local workgroups run (those the target workgroups vacate + those never used),
-        // each running up to two of the N_ADAM virtual blocks -- a block dispatched behind the local workgroups starts ~2 us late and everybody's Adam waits
-        // for its norm partials; ungrouped: all N_ADAM
-        const int n_tail = hier ? std::max((N_ADAM + 1) / 2, std::min(N_ADAM, 256 - n_part)) : N_ADAM;
-        const StepTail tail = {n_tail, N_ADAM, hier, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, rng_state_dev,
-                               adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm};
-        hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd + n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
-                           mode, use_staged, tail);
+    if (plan.launches == 1) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
+        StepTail tail = {plan.n_tail, N_ADAM, plan.hier, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
+                         rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
+        if (x)
+            hipLaunchKernelGGL(iqn_train_fwdbwd<true>, dim3(plan.n_fwd + plan.n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+                               plan.mode, use_staged, tail);
+        else
+            hipLaunchKernelGGL(iqn_train_fwdbwd<false>, dim3(plan.n_fwd + plan.n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+                               plan.mode, use_staged, tail);
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
     const StepTail no_tail = {};
-    hipLaunchKernelGGL(iqn_train_fwdbwd, dim3(n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
-                       params_local, params_target, workspace, batch, gamma, mode, use_staged, no_tail);
-    if (adam && adam->peers)
+    hipLaunchKernelGGL(iqn_train_fwdbwd<false>, dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
+                       params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail);
+    if (plan.launches == 2 && x)
         hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
                            adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm,
-                           *adam->peers, adam->world, adam->grad_scale, adam->status);
-    else if (adam)
+                           (const XchgArgs *)x->dev_args, adam->grad_scale);
+    else if (plan.launches == 2 && adam)
         hipLaunchKernelGGL(iqn_grad_reduce_adam, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
                            adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm);
-    else
+    else      // the stand-alone reduction (mn_iqn_train_grad*; or the first of the launches a small device takes instead of the fused one -- a shared learner's publishes into its mailbox)
         hipLaunchKernelGGL(iqn_grad_reduce, dim3(N_RED), dim3(RED_COLS * RED_SEG), 0, s, workspace, n_part, grad_out, loss_out,
-                           rng_state_dev, ba, prefetch_next);
-    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+                           rng_state_dev, ba, prefetch_next, (uint64_t)(uintptr_t)(adam && x ? x->own : nullptr));
+    if (hipGetLastError() != hipSuccess) return MN_ERR_HIP;
+    if (plan.launches == 4)
+        if (int rc = launch_gather(x, grad_out, workspace, n_part, adam->grad_scale, s)) return rc;
+    if (plan.launches >= 3)      // (the norm partials are the reduction's, or the gather's for grad_scale x the sum)
+        return launch_adam(adam->params, grad_out, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, workspace, n_part, adam->lr, adam->beta1, adam->beta2, adam->eps,
+                           adam->max_norm, x ? adam->grad_scale : 1.0f, s);
+    return MN_OK;
 }
 
-// One gradient step of a single learner as TWO launches: forward / backward, then reduction + clip + Adam (iqn_grad_reduce_adam).  Either the
-// batch is drawn in the launch (rng_state_dev != NULL: the arguments of mn_iqn_train_grad_sampled) or given (idx_dev / taus_*_dev: those of
-// mn_iqn_train_grad).  params_local is updated in place; bit-identical to mn_iqn_train_grad* followed by mn_iqn_train_adam(grad_scale = 1).
+// Test / multi-tenant hook: plan launches as if the device had at most `n_cu` CUs (0 = what the device reports).  Two ranks that share ONE GPU (tests) set half of it each.
+extern "C" int mn_iqn_train_set_cu_limit(int32_t n_cu) {
+    if (n_cu < 0) return MN_ERR_INVALID;
+    g_cu_limit = n_cu;
+    return MN_OK;
+}
+
+// Launches one gradient step takes on the current device: 1 (reduction + Adam ride in the forward / backward launch), 2, 3 (a device on which the 140 blocks of
+// the fused reduction + Adam launch are not resident together), 4 (the same for a shared learner's exchange); < 0: error.  `exchange` != 0: a shared learner's step.
+extern "C" int mn_iqn_train_plan(int32_t batch, int32_t flags, int32_t exchange) {
+    if (batch <= 0 || batch > MAX_BATCH || batch % BE) return -MN_ERR_INVALID;
+    DevInfo dev;
+    if (int rc = dev_info(&dev)) return -rc;
+    return plan_launch(dev, batch, flags, true, exchange != 0).launches;
+}
+
+// One gradient step of a single learner: forward / backward, reduction, clip + Adam -- as one launch (MN_TRAIN_ONE_LAUNCH), two (iqn_grad_reduce_adam) or, on a device that
+// cannot hold the fused launches' workgroups together, three.  Either the batch is drawn in the launch (rng_state_dev != NULL: the arguments of
+// mn_iqn_train_grad_sampled) or given (idx_dev / taus_*_dev: those of mn_iqn_train_grad).  params_local is updated in place; every form is bit-identical to
+// mn_iqn_train_grad* followed by mn_iqn_train_adam(grad_scale = 1).
 extern "C" int mn_iqn_train_step(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
                                  const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev,
                                  const float *taus_target_dev, const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local,
@@ -2085,7 +2148,7 @@ extern "C" int mn_iqn_train_step(const float *ring_states, const float *ring_nex
                                  int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                                  double eps, double max_norm, void *stream) {
     if (!params_local || !exp_avg || !exp_avg_sq || !step_dev) return MN_ERR_INVALID;
-    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, nullptr, 1, 1.0f, nullptr};
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, nullptr, 1.0f};
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
                        rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
                        grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags, stream, &adam);
@@ -2118,45 +2181,49 @@ extern "C" int mn_iqn_train_adam(float *params, float *grad, float *exp_avg, flo
     if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !workspace || batch <= 0 || batch % BE) return MN_ERR_INVALID;
     if (!(grad_scale > 0.f)) return MN_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    const float *blocksq = workspace + ws_sq(batch / BE);
-    unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(batch / BE) + 2);
-    float *blocksq_w = workspace + ws_sq(batch / BE);
     if ((grad_rewritten || grad_scale != 1.0f) && grad_rewritten != 2)      // the reduction kernel's partial sums of squares no longer describe grad (2: mn_iqn_train_exchange already wrote them for grad_scale * grad)
-        hipLaunchKernelGGL(iqn_grad_sumsq, dim3(N_RED), dim3(RED_COLS), 0, s, grad, blocksq_w, grad_scale);
-    hipLaunchKernelGGL(iqn_adam, dim3(N_ADAM), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, blocksq, step_dev, ticket, lr, beta1,
-                       beta2, eps, max_norm, grad_scale);
-    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+        hipLaunchKernelGGL(iqn_grad_sumsq, dim3(N_RED), dim3(RED_COLS), 0, s, grad, workspace + ws_sq(batch / BE), grad_scale);
+    return launch_adam(params, grad, exp_avg, exp_avg_sq, step_dev, workspace, batch / BE, lr, beta1, beta2, eps, max_norm, grad_scale, s);
 }
 
 // ---- one-shot gradient exchange of a shared learner over IPC-mapped mailboxes (see iqn_grad_gather) ---------------------------------
-struct mn_xchg {
-    int rank = 0, world = 1, device = -1;
-    gu64 *own = nullptr;                       // [2][P_PAD] granules, this rank's reduced gradient of the last two steps
-    const gu64 *peer[XCHG_MAX_RANKS] = {};     // own + IPC-mapped peers, by rank
-    bool opened[XCHG_MAX_RANKS] = {};
-    unsigned *status = nullptr;                // device word: number of granule groups that timed out
-    gu64 *xsq = nullptr;                       // [N_RED] self-tagged norm partials of the fused exchange + Adam launch (private to this rank)
-};
-
+// The mailbox is polled by OTHER devices while this device's kernel is still writing it.  Granules are written and read with system-scope accesses (sc0 sc1: past
+// every cache of the issuing device), but what the memory's own caching attributes allow matters too: ordinary hipMalloc memory is coarse-grained -- coherent
+// with other agents at kernel boundaries only, as far as the HIP memory model promises -- so the mailbox is allocated UNCACHED (hipDeviceMallocUncached; what
+// RCCL uses for the buffers its kernels poll across GPUs on gfx942 / gfx950), else fine-grained, and only if the runtime refuses both as plain device memory
+// (mn_xchg_memory_kind tells; round 4 used that: correct between two processes on ONE GPU, unproven across xGMI).  Both kinds are exportable over IPC.
 extern "C" int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out) {
     if (!out || world < 1 || world > XCHG_MAX_RANKS || rank < 0 || rank >= world) return MN_ERR_INVALID;
     mn_xchg *x = new mn_xchg();
     x->rank = rank; x->world = world;
+    x->bound = world > 1 ? 3000000000ull : 200000000ull;      // 30 s with peers (one of them may be evaluating or writing a checkpoint), 2 s alone
     const size_t bytes = 2 * (size_t)P_PAD * sizeof(uint64_t);
-    void *p = nullptr, *sqp = nullptr;
-    // plain device memory: granules are written and polled with system-scope (cache-bypassing) accesses, and hipIpcGetMemHandle exports it
-    if (hipGetDevice(&x->device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess ||
+    void *p = nullptr;
+    if (hipGetDevice(&x->device) != hipSuccess) { delete x; return MN_ERR_HIP; }
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess) x->kind = 2;
+    else if ((void)hipGetLastError(), hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess) x->kind = 1;
+    else if ((void)hipGetLastError(), hipMalloc(&p, bytes) == hipSuccess) x->kind = 0;
+    else p = nullptr;
+    if (!p || hipMemset(p, 0, bytes) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&x->status), sizeof(unsigned)) != hipSuccess || hipMemset(x->status, 0, sizeof(unsigned)) != hipSuccess ||
-        hipMalloc(&sqp, N_RED * sizeof(uint64_t)) != hipSuccess || hipMemset(sqp, 0, N_RED * sizeof(uint64_t)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(p); (void)hipFree(x->status); (void)hipFree(sqp); delete x;
+        hipMalloc(reinterpret_cast<void **>(&x->dev_args), sizeof(XchgArgs)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p); (void)hipFree(x->status); (void)hipFree(x->dev_args); delete x;
         return MN_ERR_ALLOC;
     }
-    x->xsq = (gu64 *)sqp;
     x->own = (gu64 *)p;
     x->peer[rank] = x->own;
+    if (int rc = xchg_sync(x)) { (void)hipFree(p); (void)hipFree(x->status); (void)hipFree(x->dev_args); delete x; return rc; }
     *out = x;
     return MN_OK;
+}
+
+extern "C" int mn_xchg_memory_kind(mn_xchg *x) { return x ? x->kind : -1; }
+
+// How long a gather waits for a peer's granules before it gives up (status word raised, the block's update skipped).  Default: 30 s when there are peers, 2 s alone.
+extern "C" int mn_xchg_set_timeout_ms(mn_xchg *x, int64_t ms) {
+    if (!x || ms <= 0 || ms > 3600000) return MN_ERR_INVALID;
+    x->bound = (uint64_t)ms * 100000ull;      // s_memrealtime: 100 MHz
+    return xchg_sync(x);
 }
 
 extern "C" int mn_xchg_export(mn_xchg *x, void *handle_out) {
@@ -2176,7 +2243,7 @@ extern "C" int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle)
     if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MN_ERR_HIP;
     x->peer[peer_rank] = (const gu64 *)p;
     x->opened[peer_rank] = true;
-    return MN_OK;
+    return xchg_sync(x);
 }
 
 extern "C" int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void *stream) {
@@ -2190,31 +2257,7 @@ extern "C" int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void 
 
 extern "C" int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t batch, float grad_scale, void *stream) {
     if (!x || !grad || !workspace || batch <= 0 || batch % BE || !(grad_scale > 0.f)) return MN_ERR_INVALID;
-    XchgPeers peers;
-    for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
-        peers.mb[r] = r < x->world ? x->peer[r] : nullptr;
-        if (r < x->world && !peers.mb[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
-    }
-    const int n_part = batch / BE;
-    hipLaunchKernelGGL(iqn_grad_gather, dim3(N_RED), dim3(RED_COLS), 0, (hipStream_t)stream, peers, x->world, (const float *)workspace, n_part,
-                       grad, workspace + ws_sq(n_part), grad_scale, x->status);
-    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
-}
-
-extern "C" int mn_iqn_train_exchange_adam(mn_xchg *x, float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev,
-                                          float *workspace, int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm,
-                                          float grad_scale, void *stream) {
-    if (!x || !params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !workspace || batch <= 0 || batch % BE || !(grad_scale > 0.f)) return MN_ERR_INVALID;
-    XchgPeers peers;
-    for (int r = 0; r < XCHG_MAX_RANKS; ++r) {
-        peers.mb[r] = r < x->world ? x->peer[r] : nullptr;
-        if (r < x->world && !peers.mb[r]) return MN_ERR_INVALID;
-    }
-    const int n_part = batch / BE;
-    unsigned *ticket = reinterpret_cast<unsigned *>(workspace + ws_epoch(n_part) + 2);
-    hipLaunchKernelGGL(iqn_adam_xchg, dim3(N_ADAM), dim3(256), 0, (hipStream_t)stream, peers, x->world, x->xsq, (const float *)workspace, n_part, params, grad,
-                       exp_avg, exp_avg_sq, step_dev, ticket, lr, beta1, beta2, eps, max_norm, grad_scale, x->status);
-    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
+    return launch_gather(x, grad, workspace, batch / BE, grad_scale, (hipStream_t)stream);
 }
 
 extern "C" int mn_xchg_status(mn_xchg *x, int32_t *timeouts) {
@@ -2231,16 +2274,16 @@ extern "C" int mn_xchg_destroy(mn_xchg *x) {
         if (x->opened[r]) (void)hipIpcCloseMemHandle((void *)x->peer[r]);
     (void)hipFree((void *)x->own);
     (void)hipFree(x->status);
-    (void)hipFree((void *)x->xsq);
+    (void)hipFree(x->dev_args);
     delete x;
     return MN_OK;
 }
 
-// mn_iqn_train_step for a SHARED learner: the one-shot gradient exchange happens inside the reduction + Adam launch -- every Adam block
+// mn_iqn_train_step for a SHARED learner: the one-shot gradient exchange happens inside the reduction + Adam role -- every Adam block
 // publishes its 64 reduced columns into this rank's mailbox, gathers the same columns of every rank (rank order), and goes on as in
-// mn_iqn_train_step with grad_scale * sum.  Two launches per step, no collective; bit-identical to mn_iqn_train_grad* + mn_iqn_train_exchange +
-// mn_iqn_train_adam(grad_rewritten = 2).  (The workspace need not be attached with mn_xchg_attach for this path: the forward / backward
-// launch's stand-alone reduction kernel is not used.)
+// mn_iqn_train_step with grad_scale * sum.  One launch per step with MN_TRAIN_ONE_LAUNCH (round 5: the exchange rides in the third role of the forward /
+// backward launch), two without, no collective; on a device too small for the fused launches: reduction (publishes), gather, Adam.  All bit-identical to
+// mn_iqn_train_grad* + mn_iqn_train_exchange + mn_iqn_train_adam(grad_rewritten = 2).  (The workspace need not be attached with mn_xchg_attach.)
 extern "C" int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                                       const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev,
                                       const float *taus_target_dev, const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local,
@@ -2248,15 +2291,8 @@ extern "C" int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, cons
                                       int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                                       double eps, double max_norm, float grad_scale, void *stream) {
     if (!x || !params_local || !exp_avg || !exp_avg_sq || !step_dev || !(grad_scale > 0.f)) return MN_ERR_INVALID;
-    XchgPeers peers;
-    for (int r = 0; r <= XCHG_MAX_RANKS; ++r) peers.mb[r] = nullptr;
-    for (int r = 0; r < x->world; ++r) {
-        peers.mb[r] = x->peer[r];
-        if (!peers.mb[r]) return MN_ERR_INVALID;      // a peer's mailbox was never imported
-    }
-    peers.mb[x->world] = x->own;
-    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, &peers, x->world, grad_scale, x->status};
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, x, grad_scale};
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
                        rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
-                       grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags & ~MN_TRAIN_ONE_LAUNCH, stream, &adam);
+                       grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags, stream, &adam);
 }

@@ -26,6 +26,8 @@ struct mn_handle {
     // profiling
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
+    std::vector<hipEvent_t> ev_reset;      // ... and around mn_reset_done (mn_profile_reset_end)
+    int prof_reset_n = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -149,6 +151,7 @@ extern "C" int mn_destroy(mn_handle *h) {
     const bool moved = hipGetDevice(&cur) == hipSuccess && h->device >= 0 && cur != h->device;
     if (moved) (void)hipSetDevice(h->device);   // free on the owning device, then restore the caller's
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_reset) (void)hipEventDestroy(e);
     for (void *p : h->allocs) (void)hipFree(p);
     if (moved) (void)hipSetDevice(cur);
     delete h;
@@ -387,7 +390,10 @@ extern "C" int mn_set_debug_skip(mn_handle *h, int32_t mask) {
 extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return MN_ERR_INVALID;
     MN_ON_DEVICE(h);
+    const bool prof = h->prof_reset_n < h->prof_max;
+    if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], (hipStream_t)stream);
     mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream);
+    if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], (hipStream_t)stream); h->prof_reset_n++; }
     MN_HIP(h, hipGetLastError());
     return MN_OK;
 }
@@ -625,8 +631,30 @@ extern "C" int mn_profile_begin(mn_handle *h, int32_t max_launches) {
         MN_HIP(h, hipEventCreate(&e));
         h->ev.push_back(e);
     }
+    while ((int)h->ev_reset.size() < 2 * max_launches) {
+        hipEvent_t e;
+        MN_HIP(h, hipEventCreate(&e));
+        h->ev_reset.push_back(e);
+    }
     h->prof_max = max_launches;
     h->prof_n = 0;
+    h->prof_reset_n = 0;
+    return MN_OK;
+}
+
+// The mn_reset_done launches of the same window (call BEFORE mn_profile_end, which closes the window).
+extern "C" int mn_profile_reset_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches) {
+    if (!h) return MN_ERR_INVALID;
+    MN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    double sum = 0.0;
+    for (int i = 0; i < h->prof_reset_n; ++i) {
+        float ms = 0.f;
+        MN_HIP(h, hipEventElapsedTime(&ms, h->ev_reset[2 * i], h->ev_reset[2 * i + 1]));
+        sum += ms;
+    }
+    if (mean_ms) *mean_ms = h->prof_reset_n ? sum / h->prof_reset_n : 0.0;
+    if (launches) *launches = h->prof_reset_n;
+    h->prof_reset_n = 0;
     return MN_OK;
 }
 
@@ -643,5 +671,6 @@ extern "C" int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32
     if (launches) *launches = h->prof_n;
     h->prof_max = 0;
     h->prof_n = 0;
+    h->prof_reset_n = 0;
     return MN_OK;
 }

@@ -412,13 +412,21 @@ class IQNAgent(ReferenceLoopMixin):
                 stats["timeouts"] += int((info == 2).sum())
                 ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
             if evaluate_now:
+                self.check_learner()      # (a device synchronisation; the evaluation below is one anyway)
                 self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
                 self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
                 if eval_log_path is not None:
                     self.qnetwork_local.save(eval_log_path)
             if on_step is not None:
                 on_step(it, stats)
+        self.check_learner()
         return stats
+
+    def check_learner(self):
+        """Raise if a bounded wait of the fused gradient step ran out since the last look (`FusedTrainer.check_timeouts`): the step(s) concerned updated
+        nothing, and with the mailbox exchange a peer's gradient did not arrive -- the ranks of a shared learner would drift apart silently otherwise."""
+        if self._fused is not None and self._fused.owns(self):
+            self._fused.check_timeouts()
 
     # vec_step: mn_reset_done on a second HIP stream while the gradient steps of the same vector step run.  Measured (scripts/ab_reset_overlap.sh,
     # alternating on one GPU): 0.950-0.957 ms per vector step at 16 gradient steps per step against 0.941-0.950 with the reset in front of them on

@@ -185,6 +185,39 @@ class FusedTrainer:
             return self.loss[0]
         return self._finish_step(batch)
 
+    def launches_per_step(self, batch=None):
+        """Launches one gradient step takes on this device (C-ABI mn_iqn_train_plan): 1 / 2 for the fused forms, 3 (4 with the exchange) where they do not fit;
+        an RCCL shared learner: 3 + the collective."""
+        ag = self.agent
+        batch = ag.BATCH_SIZE if batch is None else batch
+        if not self._two_launches():
+            return 4 if ag.distributed and getattr(ag, "exchange", "collective") == "mailbox" else 3
+        n = _capi.lib().mn_iqn_train_plan(batch, self._one_launch_flags(batch), 1 if ag.distributed else 0)
+        if n < 0:
+            raise _capi.MarineNavHipError(f"mn_iqn_train_plan failed ({n})")
+        return n
+
+    def timeouts(self):
+        """Bounded waits that ran out since the workspaces were made: reduction + Adam blocks (status word of every workspace) + the mailbox exchange's gathers.
+        Synchronises the device.  0 in a healthy run; anything else means steps were skipped (and a shared learner's ranks no longer agree)."""
+        n = 0
+        for batch, ws in self._ws_by_batch.items():
+            i = _capi.lib().mn_iqn_train_workspace_status_word(batch)
+            n += int(ws[i:i + 1].view(torch.int32).item())
+        if self._mailbox is not None:
+            n += self._mailbox.timeouts()
+        return n
+
+    def check_timeouts(self):
+        """Raise if any bounded wait of the gradient step ran out (a peer that died or fell > the bound behind; workgroups of a fused launch that were not
+        resident together).  Called where the loop synchronises anyway: evaluation points, the end of learn_vec, bench.py's legs."""
+        n = self.timeouts()
+        if n:
+            raise _capi.MarineNavHipError(
+                f"fused IQN gradient step: {n} bounded wait(s) ran out -- the affected steps updated nothing" +
+                (" and this shared learner's ranks may have diverged (a peer's gradient did not arrive within the bound; MN_XCHG_TIMEOUT_MS)"
+                 if self._mailbox is not None and self._mailbox.world > 1 else ""))
+
     def xcd_misplaced(self, batch=None):
         """Diagnostic of the one-launch step: local workgroups that did not run on XCD (block index % 8) since the workspace was made (0 expected)."""
         batch = self.agent.BATCH_SIZE if batch is None else batch
@@ -192,7 +225,7 @@ class FusedTrainer:
         return int(self._workspace(batch)[i:i + 1].view(torch.int32).item())
 
     def _one_launch_flags(self, batch):
-        """MN_TRAIN_ONE_LAUNCH [| MN_TRAIN_UNGROUPED (one_launch_ungrouped: every partial row through memory instead of summed inside its XCD) |
+        """(A shared learner's mailbox exchange rides in the same forms, round 5.)  MN_TRAIN_ONE_LAUNCH [| MN_TRAIN_UNGROUPED (one_launch_ungrouped: every partial row through memory instead of summed inside its XCD) |
         MN_TRAIN_TEST_MISPLACE(k) (test hook `_test_misplace`)].  `IQNAgent.one_launch_step`: True / False, or unset = where it is the faster form --
         batches that are multiples of 256 (33.5 vs 35.8 us per step at 256, 53.7 vs 55.9 at 512; at 32 / 64 / 128 / 192 / 384 two launches are 1 - 8 us
         faster: few local workgroups each summing a large share of their group's rows).  MN_ONE_LAUNCH=0 / 1 overrides the unset case (A / B runs)."""
@@ -206,15 +239,14 @@ class FusedTrainer:
         return 4 | (8 if getattr(ag, "one_launch_ungrouped", False) else 0) | (int(getattr(ag, "_test_misplace", 0)) << 4)
 
     def _two_launches(self):
-        """A single learner's step is two launches (mn_iqn_train_step); so is a shared learner's with the mailbox exchange (the exchange happens
-        inside the reduction + Adam launch, mn_iqn_train_step_xchg); with an RCCL all-reduce between the gradient and Adam it stays three.
-        `agent.two_launch_step = False` selects the three-launch paths (A / B measurements, tests)."""
+        """True: the whole step is ONE call into the library (mn_iqn_train_step / mn_iqn_train_step_xchg: one or two launches, more only on a device too small
+        for the fused forms -- `launches_per_step`) -- a single learner, and a shared learner with the mailbox exchange (the exchange happens inside the
+        reduction + Adam role); with an RCCL all-reduce between the gradient and Adam the step stays three launches + the collective.
+        `agent.two_launch_step = False` selects the separate launches (A / B measurements, tests)."""
         ag = self.agent
         if not getattr(ag, "two_launch_step", True):
             return False
-        if not ag.distributed:
-            return True
-        return getattr(ag, "exchange", "collective") == "mailbox" and getattr(ag, "exchange_fused_adam", True)
+        return not ag.distributed or getattr(ag, "exchange", "collective") == "mailbox"
 
     def _step_call(self, ring5, ring_size, rng, idx, tt, tl, idx_out, taus_out, batch, flags, stream):
         """mn_iqn_train_step / mn_iqn_train_step_xchg with this trainer's buffers."""
@@ -314,10 +346,6 @@ class FusedTrainer:
             if mb is None:
                 from .mailbox import MailboxExchange
                 mb = self._mailbox = MailboxExchange(self.device)
-            if getattr(ag, "exchange_fused_adam", True):      # one launch: gather + norm + clip + Adam (bit-identical to the two below)
-                mb.exchange_adam(self, B, 1.0 / mb.world, ag.LR)
-                weights_changed(ag.qnetwork_local)
-                return self.loss[0]
             scale, rewritten = 1.0 / mb.world, 2
             mb.exchange(self.grad, self._workspace(B), B, scale)
         elif ag.distributed:

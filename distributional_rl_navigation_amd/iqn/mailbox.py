@@ -1,11 +1,14 @@
 """One-shot gradient exchange of a shared learner over IPC-mapped mailboxes (C-ABI `mn_xchg_*`, csrc/iqn_train.hip: iqn_grad_gather).
 
 `IQNAgent(distributed=True)` all-reduces its flat 143 KB gradient over RCCL by default (`iqn/fused_train.py`).  With
-`agent.exchange = "mailbox"` the reduction kernel of every rank publishes the reduced gradient into a mailbox in its own HBM and ONE
-gather kernel per rank sums all mailboxes in rank order, reading the peers' over IPC-mapped pointers (xGMI between GPUs; the shared L2
-when two ranks share one GPU, which is how the tests run it).  The process group is used once, to exchange the 64-byte IPC handles.
+`agent.exchange = "mailbox"` the reduction + Adam blocks of every rank's gradient step publish their reduced columns into a mailbox in the rank's own
+HBM (uncached device memory) and gather the same columns of every rank, in rank order, reading the peers' over IPC-mapped pointers (xGMI between
+GPUs; two ranks sharing one GPU is how the tests run it) -- inside the step's own launch, no collective.  The process group is used once, to exchange the
+64-byte IPC handles.  A gather that does not get a peer's granules within the bound skips the update and counts itself: `FusedTrainer.check_timeouts`
+turns that into an exception at the loop's evaluation points.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -40,6 +43,18 @@ class MailboxExchange:
                         if rc:
                             raise _capi.MarineNavHipError(f"mn_xchg_import of rank {r}'s mailbox failed ({rc})")
         self._attached = set()
+        ms = os.environ.get("MN_XCHG_TIMEOUT_MS")      # how long a gather waits for a peer (default: 30 s with peers, 2 s alone)
+        if ms:
+            self.set_timeout_ms(int(ms))
+
+    def set_timeout_ms(self, ms):
+        rc = _capi.lib().mn_xchg_set_timeout_ms(self.h, int(ms))
+        if rc:
+            raise _capi.MarineNavHipError(f"mn_xchg_set_timeout_ms failed ({rc})")
+
+    def memory_kind(self):
+        """How the mailbox was allocated: "uncached" / "fine-grained" device memory (visible to peers inside a running kernel), or "coarse" (plain hipMalloc)."""
+        return {2: "uncached", 1: "fine-grained", 0: "coarse"}.get(_capi.lib().mn_xchg_memory_kind(self.h), "?")
 
     def attach(self, workspace, batch):
         """The learner stepping on `workspace` publishes its reduced gradient into this rank's mailbox from now on."""
@@ -68,16 +83,6 @@ class MailboxExchange:
                                                C.c_float(grad_scale), stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_train_exchange failed ({rc})")
-
-    def exchange_adam(self, trainer, batch, grad_scale, lr):
-        """`exchange` and the clip + Adam update as ONE launch (C-ABI mn_iqn_train_exchange_adam), on `trainer`'s flat buffers."""
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        rc = _capi.lib().mn_iqn_train_exchange_adam(self.h, p(trainer.local), p(trainer.grad), p(trainer.exp_avg), p(trainer.exp_avg_sq), p(trainer.step_dev),
-                                                    p(trainer._workspace(batch)), int(batch), C.c_double(lr), C.c_double(0.9), C.c_double(0.999),
-                                                    C.c_double(1e-8), C.c_double(0.5), C.c_float(grad_scale), stream)
-        if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_train_exchange_adam failed ({rc})")
 
     def timeouts(self):
         n = C.c_int32()

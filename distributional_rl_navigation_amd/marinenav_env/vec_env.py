@@ -409,6 +409,12 @@ class VecMarineNavEnv:
         self._check(self.L.mn_profile_end(self.h, self._stream(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_reset_end(self):
+        """Mean duration / count of the mn_reset_done launches recorded since profile_begin (call before profile_end)."""
+        ms = C.c_double(); n = C.c_int32()
+        self._check(self.L.mn_profile_reset_end(self.h, self._stream(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     @staticmethod
     def info_string(code):
         return INFO_STRINGS[int(code)]

@@ -242,9 +242,11 @@ int mn_peek_next_double(mn_handle *h, int32_t first_env, int32_t count, double *
 /* Number of envs the last mn_step flagged done (synchronises the stream). */
 int mn_last_done_count(mn_handle *h, void *stream, int32_t *out);
 
-/* Timing hook for benchmarks: records hipEvents on `stream` around the dominant kernel of the
- * next mn_step calls.  mn_step_kernel_ms returns the mean over the recorded launches. */
+/* Timing hook for benchmarks: records hipEvents on `stream` around the step kernel of the next max_launches mn_step / mn_step_append /
+ * mn_rollout calls and around the reset kernel of the next max_launches mn_reset_done calls.  mn_profile_end returns the mean duration of
+ * the recorded step launches and closes the window; mn_profile_reset_end (call it first) that of the recorded mn_reset_done launches. */
 int mn_profile_begin(mn_handle *h, int32_t max_launches);
+int mn_profile_reset_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
 int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches);
 
 /* ---- IQN inference ---------------------------------------------------------------------------
@@ -400,7 +402,18 @@ int64_t mn_iqn_train_workspace_floats(int32_t batch);
  * workgroup of their group (block index % 8) since mn_iqn_train_workspace_init (their partial-gradient rows go through memory instead of staying in the
  * XCD's L2: correct, slower; the dispatcher deals workgroups out to the XCDs round-robin, so 0 is expected). */
 int64_t mn_iqn_train_workspace_misplaced_word(int32_t batch);
+/* Float index inside the workspace of the u32 STATUS word: reduction + Adam blocks of which a bounded wait ran out since mn_iqn_train_workspace_init -- a hand-off
+ * inside a fused launch, or (shared learner) a peer's granules.  Such a block leaves moments and parameters untouched and writes NaN into its piece of the
+ * gradient.  0 in a healthy run; the caller reads the word where it synchronises anyway (evaluation points, the end of a run) and treats non-zero as an error. */
+int64_t mn_iqn_train_workspace_status_word(int32_t batch);
 int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
+/* The fused forms wait, inside a launch, for other workgroups of the same launch, which is only safe while those are resident together: the launch plan is made
+ * from the device's CU count and the kernels' occupancy (round 5), and a device that cannot hold them takes three launches (four for a shared learner:
+ * reduction, gather, Adam) -- bit-identical.  mn_iqn_train_plan: launches one gradient step takes on the current device for this batch and these flags
+ * (exchange != 0: mn_iqn_train_step_xchg); < 0: -error.  mn_iqn_train_set_cu_limit: plan as if the device had at most n_cu CUs (0: what it reports) -- tests, and
+ * ranks that share one GPU (each plans for its share). */
+int mn_iqn_train_plan(int32_t batch, int32_t flags, int32_t exchange);
+int mn_iqn_train_set_cu_limit(int32_t n_cu);
 
 /* ---- One-shot gradient exchange of a shared learner (BASELINE configs[4]; SURVEY 8e: one flat 143 KB bucket per gradient step, latency-
  * bound).  Alternative to an RCCL all-reduce between mn_iqn_train_grad* and mn_iqn_train_adam: every rank owns a MAILBOX in device memory;
@@ -409,15 +422,19 @@ int mn_iqn_train_workspace_init(float *workspace, int32_t batch, void *stream);
  * through IPC-mapped pointers, i.e. directly over xGMI -- polling each granule until it carries the current step's tag, and leaves
  *     grad = sum over ranks, in rank order (bit-identical on every rank; equal to an all-reduce(SUM) for two ranks)
  * plus the norm partials of grad_scale * grad, so that the step continues with mn_iqn_train_adam(..., grad_scale, grad_rewritten = 2).
- * Four launches per step instead of five (no collective launch, no separate norm pass) -- three with mn_iqn_train_exchange_adam --, no host
- * synchronisation, graph-capturable.
+ * Four launches per step instead of five (no collective launch, no separate norm pass), no host synchronisation, graph-capturable -- the form a device too
+ * small for the fused launches falls back to; mn_iqn_train_step_xchg (below) is the exchange INSIDE the gradient step's own launch(es).
  *   mn_xchg_create(rank, world <= 8)    this rank's context + mailbox on the current device
  *   mn_xchg_export(x, handle[64])       hipIpcMemHandle_t of the mailbox, to be sent to every peer (e.g. torch.distributed.all_gather_object)
  *   mn_xchg_import(x, peer, handle[64]) maps a peer's mailbox (once per peer)
  *   mn_xchg_attach(x, workspace, batch) the learner that steps on `workspace` publishes into x's mailbox from now on (x = NULL detaches)
  *   mn_iqn_train_exchange(x, grad, workspace, batch, grad_scale, stream)   after mn_iqn_train_grad* on the same stream
- *   mn_xchg_status(x, &timeouts)        granule groups that did not arrive within ~2 s (0 in a healthy run; the poll is bounded so that a
- *                                       missing peer can never hang the device)
+ *   mn_xchg_status(x, &timeouts)        gathers that did not get a peer's granules within the bound (0 in a healthy run; the poll is bounded so that a
+ *                                       missing peer can never hang the device; the step that timed out updates nothing and raises the workspace's
+ *                                       status word too).  mn_xchg_set_timeout_ms(x, ms): the bound; default 30 s with peers (one of them may be
+ *                                       evaluating or writing a checkpoint meanwhile), 2 s alone
+ *   mn_xchg_memory_kind(x)              how the mailbox was allocated: 2 = uncached device memory (hipDeviceMallocUncached), 1 = fine-grained, 0 = plain
+ *                                       hipMalloc (coarse-grained: cross-device visibility inside a running kernel is then not promised by the memory model)
  * All ranks must call the step functions the same number of times (the tag is the workspace's step count).  RCCL stays the default
  * transport of iqn/fused_train.py; this path is opt-in (IQNAgent.exchange = "mailbox"). */
 /* ---- DQN baseline, acting: the greedy policy of the reference's sb3 `ObsEncoderPolicy` for n observation rows in ONE
@@ -438,14 +455,12 @@ int mn_xchg_export(mn_xchg *x, void *handle_out);
 int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle);
 int mn_xchg_attach(mn_xchg *x, float *workspace, int32_t batch, void *stream);
 int mn_iqn_train_exchange(mn_xchg *x, float *grad, float *workspace, int32_t batch, float grad_scale, void *stream);
-/* mn_iqn_train_exchange + mn_iqn_train_adam(..., grad_rewritten = 2) as ONE launch: every Adam block gathers its own parameters' gradients
- * from the mailboxes and the norm partials travel between the blocks as self-tagged granules.  Bit-identical to the two calls; a shared
- * learner's gradient step is then three launches, like an independent learner's. */
-int mn_iqn_train_exchange_adam(mn_xchg *x, float *params, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, float *workspace,
-                               int32_t batch, double lr, double beta1, double beta2, double eps, double max_norm, float grad_scale, void *stream);
-/* mn_iqn_train_step for a SHARED learner: the exchange happens INSIDE the reduction + clip + Adam launch (every Adam block publishes its 64
- * reduced columns into this rank's mailbox, gathers the same columns of every rank in rank order and continues with grad_scale x the sum).  Two
- * launches per gradient step, like a single learner's; bit-identical to the four-launch sequence above.  Arguments as mn_iqn_train_step. */
+int mn_xchg_memory_kind(mn_xchg *x);
+int mn_xchg_set_timeout_ms(mn_xchg *x, int64_t ms);
+/* mn_iqn_train_step for a SHARED learner: the exchange happens INSIDE the reduction + clip + Adam role (every Adam block publishes its 64
+ * reduced columns into this rank's mailbox, gathers the same columns of every rank in rank order and continues with grad_scale x the sum).  As many
+ * launches per gradient step as a single learner's -- ONE with MN_TRAIN_ONE_LAUNCH (round 5), two without; bit-identical to the four-launch sequence
+ * above, which is also what a device too small for the fused launches takes.  Arguments as mn_iqn_train_step. */
 int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                            const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, const int64_t *idx_dev,
                            const float *taus_target_dev, const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local,

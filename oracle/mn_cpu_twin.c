@@ -352,6 +352,13 @@ int mn_peek_next_double(mn_handle *h, int32_t first, int32_t count, double *out)
 }
 
 int mn_profile_begin(mn_handle *h, int32_t max_launches) { (void)max_launches; return h ? MN_OK : MN_ERR_INVALID; }
+int mn_profile_reset_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches) {
+    (void)stream;
+    if (!h) return MN_ERR_INVALID;
+    if (mean_ms) *mean_ms = 0.0;
+    if (launches) *launches = 0;
+    return MN_OK;
+}
 int mn_profile_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches) {
     (void)stream;
     if (!h) return MN_ERR_INVALID;

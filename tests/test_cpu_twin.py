@@ -16,7 +16,7 @@ TWIN = os.path.join(ROOT, "oracle", "libmarinenav_cpu.so")
 ENV_SYMBOLS = ("mn_default_params", "mn_create", "mn_destroy", "mn_last_error", "mn_num_envs", "mn_set_params", "mn_get_params",
                "mn_seed", "mn_set_schedule", "mn_set_start_goal", "mn_reset", "mn_step", "mn_step_append", "mn_build_info",
                "mn_reset_done", "mn_load_worlds", "mn_get_worlds", "mn_get_state", "mn_set_state", "mn_enable_obs64", "mn_get_obs64",
-               "mn_get_reward64", "mn_peek_next_double", "mn_last_done_count", "mn_profile_begin", "mn_profile_end")
+               "mn_get_reward64", "mn_peek_next_double", "mn_last_done_count", "mn_profile_begin", "mn_profile_end", "mn_profile_reset_end")
 
 
 def bind(path):

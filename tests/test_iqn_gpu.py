@@ -625,6 +625,37 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
         assert r[5] == ref[5] == 12 + 5 + 3 + 16 and torch.equal(r[6], ref[6]) and r[7] == ref[7]
 
 
+def test_launch_plan_follows_the_device_size_and_small_devices_fall_back_bitwise(torch):
+    """The fused forms wait inside a launch for other workgroups of the same launch, so the library plans them from the device's CU count, not from the constant
+    256: `mn_iqn_train_set_cu_limit` pretends a smaller device.  Batch 256: the whole MI355X -> one launch; 200 CUs -> still one (every local workgroup
+    computes its own TD targets: 128 forward / backward workgroups); 100 -> two (the 128 local workgroups would not be resident together; the 140 blocks of the
+    reduction + Adam launch are); 8 -> three launches, nothing waits for a sibling.  All bit-identical, no bounded wait ran out."""
+    from distributional_rl_navigation_amd import _capi
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev, L = "cuda:0", _capi.lib()
+    runs = []
+    try:
+        for limit, want in ((0, 1), (200, 1), (100, 2), (8, 3)):
+            assert L.mn_iqn_train_set_cu_limit(limit) == 0
+            ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            ag.memory.add_batch(*_random_batch(torch, 2048, g))
+            losses = [float(ag.train_from_memory()) for _ in range(10)]
+            ft = ag._fused
+            assert ft.launches_per_step(256) == want and L.mn_iqn_train_plan(256, 4, 1) == (want if want < 3 else 4)
+            assert ft.timeouts() == 0
+            runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone()))
+    finally:
+        L.mn_iqn_train_set_cu_limit(0)
+    assert L.mn_iqn_train_set_cu_limit(-1) != 0 and L.mn_iqn_train_plan(255, 4, 0) < 0
+    a = runs[0]
+    assert all(np.isfinite(a[0]))
+    for b in runs[1:]:
+        assert a[0] == b[0] and a[4] == b[4] == 10
+        for x, y in ((a[1], b[1]), (a[2], b[2]), (a[3], b[3]), (a[5], b[5])):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("batch", [16, 48, 100, 128, 384, 512, 1024])
 def test_one_launch_step_at_other_batch_sizes(torch, batch):
     """The one-launch step away from batch 256: 16 (one row per XCD group), 48 (three), 128 (eight; every reduction + Adam block finds a CU at once), 100 (its half

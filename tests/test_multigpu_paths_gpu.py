@@ -83,16 +83,20 @@ from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 rank, port, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
 exchange = sys.argv[5] if len(sys.argv) > 5 else "collective"
 n_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-# "mailbox": the exchange inside the reduction + Adam launch (mn_iqn_train_step_xchg: two launches per step); "mailbox3": reduction (publishes), then gather +
-# Adam in one launch (mn_iqn_train_exchange_adam); "mailbox4": reduction, mn_iqn_train_exchange, mn_iqn_train_adam
-fused_adam, two_launch = exchange != "mailbox4", exchange == "mailbox"
+# "mailbox1": the exchange inside the ONE launch of the step (mn_iqn_train_step_xchg + MN_TRAIN_ONE_LAUNCH: the reduction + Adam role of the forward / backward
+# launch publishes and gathers); "mailbox": inside the reduction + Adam launch (two launches per step); "mailbox4": reduction (publishes), mn_iqn_train_exchange,
+# mn_iqn_train_adam -- what a device too small for the fused launches takes; "mailbox4p": the same THROUGH mn_iqn_train_step_xchg, by planning for an 8-CU device
+mode = exchange
 exchange = "mailbox" if exchange.startswith("mailbox") else exchange
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
 dev = "cuda:0"
+from distributional_rl_navigation_amd import _capi
+# two ranks share this GPU: each plans its launches for half of it (a fused launch waits for its own workgroups, which must all find a CU next to the peer's)
+_capi.lib().mn_iqn_train_set_cu_limit(8 if mode == "mailbox4p" else 120)
 agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, device=dev, seed=3, distributed=True, rank=rank)
 agent.exchange = exchange      # "collective": the bucket travels over gloo; "mailbox": IPC-mapped mailboxes, gloo only carries the handles
-agent.exchange_fused_adam = fused_adam
-agent.two_launch_step = two_launch or exchange != "mailbox"
+agent.two_launch_step = mode != "mailbox4"
+agent.one_launch_step = mode == "mailbox1"
 assert agent.use_fused_train
 for step in range(n_steps):
     tt, tl = _taus(torch, 10 * step + rank, 32, dev)
@@ -100,9 +104,11 @@ for step in range(n_steps):
 flat = agent._fused.local.cpu()
 gathered = [torch.empty_like(flat) for _ in range(2)]
 dist.all_gather(gathered, flat)
-timeouts = agent._fused._mailbox.timeouts() if exchange == "mailbox" else 0
+timeouts = agent._fused.timeouts()
+launches = agent._fused.launches_per_step(32) if exchange == "mailbox" else 0
+kind = agent._fused._mailbox.memory_kind() if exchange == "mailbox" else ""
 if rank == 0:
-    torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1])), timeouts=timeouts), out)
+    torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1])), timeouts=timeouts, launches=launches, kind=kind), out)
 dist.destroy_process_group()
 """
 
@@ -151,11 +157,69 @@ def test_mailbox_exchange_two_ranks_equals_the_all_reduce_path_bitwise(torch, tm
     ranks bit-identical to each other, no granule timed out."""
     a = _two_rank_run(torch, tmp_path, "collective", "collective", 12)
     b = _two_rank_run(torch, tmp_path, "mailbox", "mailbox", 12)        # two launches per step: the exchange inside the reduction + Adam launch
-    c = _two_rank_run(torch, tmp_path, "mailbox3", "mailbox3", 12)      # three: reduction (publishes), then gather + clip + Adam
+    c = _two_rank_run(torch, tmp_path, "mailbox1", "mailbox1", 12)      # ONE: the exchange inside the reduction + Adam role of the forward / backward launch
     d = _two_rank_run(torch, tmp_path, "mailbox4", "mailbox4", 12)      # four: reduction, mn_iqn_train_exchange, mn_iqn_train_adam
-    for r in (a, b, c, d):
+    e = _two_rank_run(torch, tmp_path, "mailbox4p", "mailbox4p", 12)    # the same four, chosen by the library's launch plan for a device of 8 CUs
+    for r in (a, b, c, d, e):
         assert r["same"] and r["timeouts"] == 0
-    assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], c["params"]) and torch.equal(a["params"], d["params"])
+    assert (b["launches"], c["launches"], d["launches"], e["launches"]) == (2, 1, 4, 4)
+    assert b["kind"] in ("uncached", "fine-grained"), b["kind"]      # the mailbox must be visible to a peer DEVICE inside a running kernel
+    for r in (b, c, d, e):
+        assert torch.equal(a["params"], r["params"])
+
+
+_LATE_PEER_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[4]); sys.path.insert(0, os.path.join(sys.argv[4], "tests"))
+from test_multigpu_paths_gpu import _batch, _taus
+from distributional_rl_navigation_amd import _capi
+from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+rank, port, out, one = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[5] == "1"
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+_capi.lib().mn_iqn_train_set_cu_limit(120)
+agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, device="cuda:0", seed=3, distributed=True, rank=rank)
+agent.exchange, agent.one_launch_step = "mailbox", one
+def step(k):
+    tt, tl = _taus(torch, 10 * k + rank, 32, "cuda:0")
+    return agent.train(_batch(torch, 10 * k + rank, 32, "cuda:0"), taus_target=tt, taus_local=tl)
+step(0); step(1)
+agent._fused._mailbox.set_timeout_ms(300)
+torch.cuda.synchronize(); dist.barrier()
+res = None
+if rank == 0:      # rank 1 stops here: the third step of rank 0 never gets its peer's gradient
+    before = (agent._fused.local.clone(), agent._fused.exp_avg.clone(), agent._fused.exp_avg_sq.clone())
+    step(2)
+    torch.cuda.synchronize()
+    raised = False
+    try:
+        agent.check_learner()
+    except _capi.MarineNavHipError:
+        raised = True
+    res = dict(timeouts=agent._fused.timeouts(), mailbox_timeouts=agent._fused._mailbox.timeouts(), raised=raised,
+               untouched=all(bool(torch.equal(a, b)) for a, b in zip(before, (agent._fused.local, agent._fused.exp_avg, agent._fused.exp_avg_sq))),
+               grad_nan=bool(torch.isnan(agent._fused.grad).all()))
+    torch.save(res, out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_mailbox_exchange_peer_that_falls_behind_is_a_loud_error_not_a_silent_divergence(torch, tmp_path, one_launch):
+    """a gather that runs into its bound (here 0.3 s; the peer simply does not take the step) must not apply an update from stale granules.  The rank
+    that waited: every reduction + Adam block counted in the workspace's status word and in mn_xchg_status, parameters and both moments exactly as before the
+    step, the step's gradient NaN, and `IQNAgent.check_learner` -- what `learn_vec` calls at its evaluation points -- raises.  Both fused forms."""
+    out = str(tmp_path / "late.pt"); port = str(_free_port())
+    script = str(tmp_path / "late_worker.py")
+    with open(script, "w") as f:
+        f.write(_LATE_PEER_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, script, str(r), port, out, ROOT, "1" if one_launch else "0"], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r = torch.load(out)
+    assert r["timeouts"] >= 70 and r["mailbox_timeouts"] >= 1 and r["raised"] and r["untouched"] and r["grad_nan"], r
 
 
 def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graphed(torch):
@@ -165,17 +229,18 @@ def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graph
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         runs = []
-        for distributed, graphed, fused, two in ((False, False, True, True), (True, False, True, True), (True, True, True, True), (True, False, True, False),
-                                                 (True, False, False, False), (True, True, False, False)):
+        for distributed, graphed, one, two in ((False, False, False, True), (True, False, False, True), (True, True, False, True), (True, False, True, True),
+                                               (True, True, True, True), (True, False, False, False), (True, True, False, False)):
             ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
             ag.exchange = "mailbox"
-            ag.exchange_fused_adam, ag.two_launch_step = fused, two
+            ag.one_launch_step, ag.two_launch_step = one, two      # the exchange inside ONE launch / inside the reduction + Adam launch / as its own launch
             ag.use_fused_graph = graphed
             ag.memory.add_batch(*_batch(torch, 7, 300, dev))
             losses = [float(ag.train_steps_from_memory(8)) for _ in range(3)]
             runs.append((losses, ag._fused.local.clone(), ag._fused.exp_avg_sq.clone(), int(ag._fused.step_dev)))
             if distributed:
-                assert ag._fused._mailbox.timeouts() == 0
+                assert ag._fused.timeouts() == 0
+                assert ag._fused.launches_per_step(64) == (1 if one else (2 if two else 4))
         for r in runs[1:]:
             assert r[0] == runs[0][0] and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and r[3] == runs[0][3] == 24
     finally:
