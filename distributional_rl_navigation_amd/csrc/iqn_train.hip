@@ -119,42 +119,80 @@ __device__ unsigned long long g_phase3[3][8];         // reduction + Adam blocks
 #define PH3(k) do { } while (0)
 #endif
 
+// The thread index, opaque to the optimiser at every use.  The fused kernel runs its steps in a loop; with plain threadIdx.x every per-thread address and index of a
+// step is loop-invariant, gets hoisted in front of the loop and lives across the whole body (measured: 1 KB of scratch per lane).  Derived again where it is used, it
+// costs a handful of vector instructions per call site.
+__device__ __forceinline__ int tid_now() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// ---- parameter loads ------------------------------------------------------------------------------------------------------
+// A flat parameter vector as the forward / backward kernel reads it (element index -> value).  COH = false: ordinary loads.  COH = true (the fused, possibly
+// multi-step launch): the local network's parameters are REWRITTEN by other workgroups of the same launch between two of its steps (Adam of step k -> forward
+// of step k + 1); the writer stores them through (sc1), this side reads with agent-scope (sc1) loads, which are not served by this CU's vector cache (whose
+// lines nobody refreshes) -- MI355X_MICROARCH: 16-B sc1 stores AND sc1 loads, behind a drained flag.
+template <bool COH>
+struct ParamView {
+    const float *p;
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ explicit ParamView(const float *P) : p(P), r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, P_TOTAL * 4, 0x00020000)) {}
+    __device__ __forceinline__ float f1(int i) const {
+        if constexpr (COH) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, i * 4, 0, 16));
+        else return p[i];
+    }
+    __device__ __forceinline__ float2 f2(int i) const {      // i even
+        if constexpr (COH) {
+            typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+            const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(r, i * 4, 0, 16);
+            return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+        } else return *reinterpret_cast<const float2 *>(p + i);
+    }
+    __device__ __forceinline__ float4 f4(int i) const {      // i a multiple of 4
+        if constexpr (COH) {
+            typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+            const u32x4p v = __builtin_amdgcn_raw_buffer_load_b128(r, i * 4, 0, 16);
+            return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        } else return *reinterpret_cast<const float4 *>(p + i);
+    }
+};
+
 // ---- MFMA tile primitives --------------------------------------------------------------------------------------------
-// B operand of a 16x16 tile over K = 16 * NB, element (k, n), requested into registers (the loads are issued here; nothing waits).
+// B operand of a 16x16 tile over K = 16 * NB, element (k, n), requested into registers (the loads are issued here; nothing waits).  W = parameter offset `off`.
 //   k-contiguous (nn.Linear weight used as W^T in the forward: element (k, n) at W[n * ldb + k]): one 16-byte load per block.
-template <int NB>
-__device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const float *__restrict__ W, int ldb, int row = -1) {
-    const int lane = threadIdx.x & 63, i = row < 0 ? lane & 15 : row, g = lane >> 4;
+template <int NB, bool COH>
+__device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb, int row = -1) {
+    const int lane = tid_now() & 63, i = row < 0 ? lane & 15 : row, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
-        const float4 v = *reinterpret_cast<const float4 *>(W + i * ldb + kk * 16 + 4 * g);
+        const float4 v = P.f4(off + i * ldb + kk * 16 + 4 * g);
         b[kk][0] = v.x; b[kk][1] = v.y; b[kk][2] = v.z; b[kk][3] = v.w;
     }
 }
-//   the same, or -- when `real` is false -- NB requests of the one 16-byte word at `dummy` (a wave that has no such tile)
-template <int NB>
-__device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const float *__restrict__ W, int ldb, bool real,
-                                                  const float *__restrict__ dummy) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+//   the same, or -- when `real` is false -- NB requests of the one 16-byte word at the head of the vector (a wave that has no such tile)
+template <int NB, bool COH>
+__device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb, bool real) {
+    const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
-        const float4 v = *reinterpret_cast<const float4 *>(real ? W + i * ldb + kk * 16 + 4 * g : dummy);
+        const float4 v = P.f4(real ? off + i * ldb + kk * 16 + 4 * g : 0);
         b[kk][0] = v.x; b[kk][1] = v.y; b[kk][2] = v.z; b[kk][3] = v.w;
     }
 }
 //   k-strided (the same weight used untransposed in the backward: element (k, n) at W[k * ldb + n]): four scalar loads per block.
-template <int NB>
-__device__ __forceinline__ void load_b_kstrided(float (&b)[NB][4], const float *__restrict__ W, int ldb) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+template <int NB, bool COH>
+__device__ __forceinline__ void load_b_kstrided(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb) {
+    const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[kk][s] = W[(kk * 16 + 4 * g + s) * ldb + i];
+        for (int s = 0; s < 4; ++s) b[kk][s] = P.f1(off + (kk * 16 + 4 * g + s) * ldb + i);
 }
 // acc += A . B with A (rows x k, k contiguous, 16-byte aligned rows) in LDS and B in registers.
 template <int NB>
 __device__ __forceinline__ f32x4 mma_a_lds(const float *A, int lda, const float (&b)[NB][4], f32x4 acc) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
     float a[NB][4];
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
@@ -174,7 +212,7 @@ __device__ __forceinline__ f32x4 mma_a_lds(const float *A, int lda, const float 
 template <int NT, typename Store>
 __device__ __forceinline__ void rows_gemm_fixed_a(const float *A, int lda, const float *B, int ldb, int nk0, int step, int nk_end,
                                                   Store st) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
     float a[4], b[NT][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) a[s] = A[(4 * g + s) * lda + i];
@@ -204,7 +242,7 @@ __device__ __forceinline__ void rows_gemm_fixed_a(const float *A, int lda, const
 template <int NT, typename Store>
 __device__ __forceinline__ void rows_gemm_fixed_b(const float *A, int lda, const float *B, int ldb, int mk0, int step, int mk_end,
                                                   Store st) {
-    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
     float b[4], a[NT][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) b[s] = B[(4 * g + s) * ldb + i];
@@ -266,6 +304,18 @@ __device__ __forceinline__ void pstore4(float *base, __amdgpu_buffer_rsrc_t rsrc
 __device__ __forceinline__ void pstore1(float *p, float v, bool wt = false) {
     if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
+}
+
+// ---- arithmetic shared by the launch forms ----------------------------------------------------------------------------------
+// This file is compiled with -ffp-contract=off (csrc/Makefile) and every fused multiply-add it wants is WRITTEN OUT: left to the compiler, `a * b + c * d` was
+// contracted one way in iqn_adam and another way in reduce_adam_body<1> once an unrelated branch was added there (round 5) -- the bit-identity of the launch forms
+// must not hang on that.  Same lesson as the env kernels (mn_device.h).
+__device__ __forceinline__ float sumsq4(float a, float b, float c, float d) { return fmaf(d, d, fmaf(c, c, fmaf(b, b, a * a))); }
+// torch.optim.Adam's single-tensor update on one element: m.lerp_(g, 1 - b1); v.mul_(b2).addcmul_(g, g, value = 1 - b2); p.addcdiv_(m, sqrt(v) / bc2_sqrt + eps, value = -step_size)
+__device__ __forceinline__ void adam_update(float g, float &m, float &v, float &p, float w1, float b2f, float w2, float step_size, float bc2_sqrt, float eps) {
+    m = fmaf(g - m, w1, m);
+    v = fmaf(w2, g * g, v * b2f);
+    p = fmaf(-step_size, m / (sqrtf(v) / bc2_sqrt + eps), p);
 }
 
 // ---- the batch draw ----------------------------------------------------------------------------------------------------
@@ -330,45 +380,46 @@ struct FwdWeights {
 
 // All loads are unconditional and in one straight line (clamped indices instead of branches): a divergent branch around a load
 // makes hipcc wait for every outstanding load at the join, which would turn the prefetch into a chain of round trips.
-__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const float *__restrict__ P);
-__device__ __forceinline__ void prefetch_forward(FwdWeights &w, const float *__restrict__ P) {
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
+template <bool COH>
+__device__ __forceinline__ void prefetch_forward(FwdWeights &w, const ParamView<COH> &P) {
+    const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
     {   // encoders: thread t < 416 computes feature o = t % 208 of batch element t / 208 (model.py:170-173); a velocity / goal
         // feature uses the first two of the 22 values it loads (they stay inside the flat parameter vector)
         const int o = tid % F;
         const int e = o < 16 ? 0 : 1, oo = o - 16 * e;
         const int woff = o < 32 ? (e ? O_GW : O_VW) + oo * 2 : O_SW + (o - 32) * 22;   // even: 8-byte aligned rows
         const int boff = o < 32 ? (e ? O_GB : O_VB) + oo : O_SB + o - 32;
-        const float2 *row = reinterpret_cast<const float2 *>(P + (tid < BE * F ? woff : 0));      // threads >= 416: one shared line
+        const int row = tid < BE * F ? woff : 0;      // threads >= 416: one shared line
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
-            const float2 v = row[k];
+            const float2 v = P.f2(row + 2 * k);
             w.enc[2 * k] = v.x; w.enc[2 * k + 1] = v.y;
         }
-        w.enc_b = P[boff];
+        w.enc_b = P.f1(boff);
     }
     // A wave without such a tile requests ONE 16-byte word instead (every lane the same address: a single cache-line request), so that
     // the request stream stays branch-free without fetching the tile twice
     const int t1b = min(wave + 8, NT1 - 1);
     const bool has1b = wave + 8 < NT1;
-    load_b_kcontig<4>(w.w1a, P + O_W1 + wave * 16 * NC, NC);
-    w.b1a = P[O_B1 + wave * 16 + i];
-    load_b_kcontig_if<4>(w.w1b, P + O_W1 + t1b * 16 * NC, NC, has1b, P);
-    w.b1b = P[has1b ? O_B1 + t1b * 16 + i : 0];
+    load_b_kcontig<4>(w.w1a, P, O_W1 + wave * 16 * NC, NC);
+    w.b1a = P.f1(O_B1 + wave * 16 + i);
+    load_b_kcontig_if<4>(w.w1b, P, O_W1 + t1b * 16 * NC, NC, has1b);
+    w.b1b = P.f1(has1b ? O_B1 + t1b * 16 + i : 0);
 }
 // ... and the operands of layers 2-4 (60 % of the bytes), requested right AFTER the first barrier: a wave cannot write its
 // transitions to LDS before it has ISSUED every request in front of that write, and issuing 170 KB per CU takes 2.7 us of the load
 // path's time (37.0 -> 36.55 us per step).
-__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const float *__restrict__ P) {
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
+template <bool COH>
+__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const ParamView<COH> &P) {
+    const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
     const int t23 = wave & 3;
     const bool l3 = wave < 4;
-    load_b_kcontig_if<13>(w.w2, P + O_W2 + t23 * 16 * F, F, l3, P);
-    w.b2 = P[l3 ? O_B2 + t23 * 16 + i : 0];
+    load_b_kcontig_if<13>(w.w2, P, O_W2 + t23 * 16 * F, F, l3);
+    w.b2 = P.f1(l3 ? O_B2 + t23 * 16 + i : 0);
     // waves 0-3: their hidden_layer_2 tile; waves 4-7: the output layer (9 of 16 columns: columns 9..15 read row 8 again and are
     // never stored) -- one load sequence, the address selects
-    load_b_kcontig<4>(w.w34, P + (l3 ? O_W3 + t23 * 16 * H : O_W4), H, l3 ? i : min(i, NA - 1));
-    w.b34 = P[l3 ? O_B3 + t23 * 16 + i : O_B4 + min(i, NA - 1)];
+    load_b_kcontig<4>(w.w34, P, l3 ? O_W3 + t23 * 16 * H : O_W4, H, l3 ? i : min(i, NA - 1));
+    w.b34 = P.f1(l3 ? O_B3 + t23 * 16 + i : O_B4 + min(i, NA - 1));
 }
 
 // Transposed weight operands of the backward (dh2 = dh3 . W3, dx = dh2 . W2: element (k, n) at W[k * ld + n]), per wave: requested
@@ -377,19 +428,20 @@ struct BwdWeights {
     float w3t[4][4];              // hidden_layer_2 columns of dh2 tile wave & 3 (waves 0-3 use it)
     float w2ta[4][4], w2tb[4][4]; // hidden_layer columns of dx tiles wave, wave + 8
 };
-__device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const float *__restrict__ PL) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    load_b_kstrided<4>(bw.w3t, PL + O_W3 + (wave & 3) * 16, H);
-    load_b_kstrided<4>(bw.w2ta, PL + O_W2 + wave * 16, F);
-    load_b_kstrided<4>(bw.w2tb, PL + O_W2 + min(wave + 8, NT1 - 1) * 16, F);
+template <bool COH>
+__device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const ParamView<COH> &PL) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid_now() >> 6);
+    load_b_kstrided<4>(bw.w3t, PL, O_W3 + (wave & 3) * 16, H);
+    load_b_kstrided<4>(bw.w2ta, PL, O_W2 + wave * 16, F);
+    load_b_kstrided<4>(bw.w2tb, PL, O_W2 + min(wave + 8, NT1 - 1) * 16, F);
 }
 
 // model.py:160-186 for the 16 rows of this workgroup on all eight waves: `obs` [2][28], `tau` [16] in LDS (visible: the caller
 // placed a barrier after writing them).  Leaves cos, (h1,) x, h2, h3, features and q in LDS; ends with a barrier.
-template <bool BWD_PREFETCH>
+template <bool BWD_PREFETCH, bool COH>
 __device__ __forceinline__ void forward_pass(const PassBufs &Bf, const FwdWeights &w, const float *obs, const float *tau,
-                                             BwdWeights *bw = nullptr, const float *__restrict__ PL = nullptr, int ph_local = -1) {
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+                                             BwdWeights *bw, const ParamView<COH> &PL, int ph_local = -1) {
+    const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     {   // encoders: three linear maps, no activation (model.py:170-173).  Branch-free (a branch here would make hipcc wait for
         // every outstanding weight request): threads >= 416 compute a copy of batch element 1's feature into a dead LDS slot
         const int be = min(tid / F, BE - 1), o = tid % F;
@@ -443,7 +495,7 @@ __device__ __forceinline__ void forward_pass(const PassBufs &Bf, const FwdWeight
 #pragma unroll
         for (int r = 0; r < 4; ++r) Bf.h2[(4 * g + r) * LDC + o] = fmaxf(acc[r] + w.b2, 0.f);
     }
-    if constexpr (BWD_PREFETCH) prefetch_backward(*bw, PL);
+    if constexpr (BWD_PREFETCH) prefetch_backward<COH>(*bw, PL);
     __syncthreads();
     PH(4);   /* layer 2 */
     if (wave < 4) {   // h3 = relu(h2 W3^T + b3)
@@ -472,7 +524,7 @@ __device__ __forceinline__ float td_target(const float *q, int row, float rew, f
     float m = q[row * 12];
 #pragma unroll
     for (int a = 1; a < NA; ++a) m = fmaxf(m, q[row * 12 + a]);
-    return rew + gamma * m * (1.f - done);
+    return fmaf(gamma * m, 1.f - done, rew);
 }
 
 struct BatchArgs {
@@ -504,7 +556,7 @@ __host__ __device__ constexpr int64_t pad4(int64_t x) { return (x + 3) / 4 * 4; 
 __host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_part * P_PAD; }
 __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
 __host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
-__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
+__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 4 * (int64_t)n_part * ROWS; }      // (two sets of TD-target granules, by step parity)
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
 // [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] count of local workgroups of
 // XCD-grouped one-launch steps that did not run on the XCD of their group's first workgroup (u32, diagnostic: their rows took the slow way through memory),
@@ -529,7 +581,9 @@ __host__ __device__ constexpr int64_t ws_lflag(int n_part) { return ws_gdone(n_p
 __host__ __device__ constexpr int64_t ws_lossq(int n_part) { return ws_lflag(n_part) + 8 * 64; }
 __host__ __device__ constexpr int64_t ws_xcc(int n_part) { return ws_lossq(n_part) + pad4(2 * n_part); }
 __host__ __device__ constexpr int64_t ws_grp(int n_part) { return ws_xcc(n_part) + pad4(2 * n_part); }
-__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_grp(n_part) + 2 * (int64_t)RED_SEG * P_PAD; }
+//   ws_pflag  256 u64 {step tag}: "the parameters this reduction + Adam block updates in step k are written" (multi-step launch: what the local workgroups of step k + 1 wait for)
+__host__ __device__ constexpr int64_t ws_pflag(int n_part) { return ws_grp(n_part) + 2 * (int64_t)RED_SEG * P_PAD; }
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_pflag(n_part) + 2 * 256; }
 constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
@@ -545,9 +599,9 @@ __host__ __device__ __forceinline__ uint32_t xchg_tag(uint64_t epoch_after_step)
 __device__ __forceinline__ void write_batch_copies(const BatchArgs &ba, uint64_t base, int batch) {
     if (!ba.rng_state) return;
     if (ba.idx_out)
-        for (int k = threadIdx.x; k < batch; k += THREADS) ba.idx_out[k] = perm_row(base, (uint32_t)ba.ring_n, (uint32_t)k);
+        for (int k = tid_now(); k < batch; k += THREADS) ba.idx_out[k] = perm_row(base, (uint32_t)ba.ring_n, (uint32_t)k);
     if (ba.taus_out)
-        for (int e = threadIdx.x; e < 2 * batch * NQ; e += THREADS) ba.taus_out[e] = sample_tau(base, e);
+        for (int e = tid_now(); e < 2 * batch * NQ; e += THREADS) ba.taus_out[e] = sample_tau(base, e);
 }
 
 constexpr int N_ADAM = (P_TOTAL + 255) / 256;   // 140 blocks of 256 parameters
@@ -614,24 +668,45 @@ static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "
 // (defined with group_reduce below) wavefront 0 waits for the "row complete" news of the rows w = x (mod 8); returns the mask of rows that were written
 // through to memory instead of into this XCD's L2, *late = a bounded wait ran out
 __device__ __forceinline__ unsigned long long group_rows_wait(float *__restrict__ ws, int n_part, int x, uint32_t tag, int tid, bool *late);
+// cache policy of the loads that read a group's partial rows back through the XCD's L2.  1 = sc0, 16 = sc1.  Round 4 used sc0 (every row address was read once per
+// launch, so the CU's vector cache could not hold an older copy); in a multi-step launch it can -- the same addresses carry a new row every step and an sc0 load
+// may be served by the vector cache (MI355X_MICROARCH: "sc0 loads hit L1 like plain") -- so: sc1, which bypasses it and is still served by the L2.
+#ifndef MN_ROW_AUX
+#define MN_ROW_AUX 16
+#endif
+constexpr int ROW_AUX = MN_ROW_AUX;
 __device__ __forceinline__ void group_put(const __amdgpu_buffer_rsrc_t &grp, uint32_t tag, int c, float4 acc);
 
+// The counters of the step a reduction + Adam block works on.  The stand-alone launch reads them from memory; the fused launch, which may run several steps,
+// reads them once when it starts and counts itself (nothing in memory moves until its last step).
+struct StepCtx {
+    uint64_t epoch;      // hand-off epoch the step starts with (tags derive from it)
+    int32_t adam_step;   // optimizer steps done before this one
+    uint64_t rs0, ctr;   // generator: seed, call counter of THIS step's batch (unused without rng_state)
+    bool last;           // the launch's last step: tickets are taken, the counters in memory advance to behind this step, the next batch is staged
+    bool fused;          // role of the forward / backward launch: the eight XCD group rows arrive as self-tagged granules (group_reduce)
+    bool multi;          // ... of a launch with more steps to come: parameters are written through (other workgroups of this launch read them), no tail nap
+};
+
 // Physical block `pb` of `n_phys` runs the virtual blocks vb = pb, pb + n_phys, ... < nvb (at most VPB of them; VPB = 1 and n_phys = nvb everywhere but in the
-// XCD-grouped one-launch step, whose 128 resident blocks cover the 140 virtual ones -- a block dispatched later than the others holds everybody's Adam up).
+// fused launch, whose resident blocks cover the 140 virtual ones two each).
 template <int VPB = 1>
 __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys, const int nvb, float *__restrict__ ws, int n_part, float *__restrict__ grad,
                                                  float *__restrict__ loss_out, uint64_t *__restrict__ rng_state, const BatchArgs &ba, int prefetch_next,
                                                  float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, int32_t *__restrict__ step,
-                                                 double lr, double b1, double b2, double eps_d, double max_norm_d, const uint32_t *done, uint32_t done_tag,
-                                                 const XchgArgs *xa = nullptr, float grad_scale = 1.0f, bool grouped = false) {
+                                                 double lr, double b1, double b2, double eps_d, double max_norm_d, const StepCtx sc,
+                                                 const XchgArgs *xa = nullptr, float grad_scale = 1.0f) {
     const XchgPeers *peers = xa ? &xa->peers : nullptr;
     const int world = xa ? xa->world : 1;
+    const bool grouped = sc.fused;
+    const uint32_t done_tag = (uint32_t)(sc.epoch % 0xFFFFFFFFull) + 1u;      // = the forward / backward workgroups' hand-off tag of this step
+    const uint32_t *done = sc.fused ? reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part)) : nullptr;
     __shared__ float4 red[VPB][RED_SEG][RA_COLS];
     __shared__ float sq[VPB][RA_COLS];
     __shared__ float gsh[VPB][4 * RA_COLS];
     __shared__ float nred[4];
     __shared__ float s_bc[2];
-    const int tid = threadIdx.x, cx = tid % RA_COLS, seg = tid / RA_COLS;
+    const int tid = tid_now(), cx = tid % RA_COLS, seg = tid / RA_COLS;
     const int vb = pb;      // (block 0 = virtual block 0: the loss; PH3 stamps)
     int vbs[VPB], col[VPB], p[VPB];
     bool on[VPB];
@@ -647,7 +722,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         return;
     }
     PH3(0);
-    const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) + 1);      // the epoch this step ends with
+    const uint32_t tag = xchg_tag(sc.epoch + 1);      // the epoch this step ends with
     // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
     float mp[VPB], vp[VPB], pp[VPB];
 #pragma unroll
@@ -655,8 +730,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         mp[j] = vp[j] = pp[j] = 0.f;
         if (on[j] && tid < 256 && p[j] < P_TOTAL) { mp[j] = m[p[j]]; vp[j] = v[p[j]]; pp[j] = params[p[j]]; }
     }
-    int t_step = 0;
-    if (tid == RA_BT - 1) t_step = *step + 1;
+    const int t_step = sc.adam_step + 1;
     // staging of the NEXT step's batch (see iqn_grad_reduce): a pure copy, any thread mapping does
     constexpr int SPB = RA_BT / STG;
     const int batch = n_part * BE;
@@ -672,32 +746,18 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         if (e >= 56) return sample_tau(base_n, (e < 64 ? 0 : batch * NQ) + slot * NQ + (e & 7));
         return 0.f;
     };
-    const bool stager = prefetch_next && rng_state && vb >= 1 && tid / STG < SPB;
+    const bool stager = prefetch_next && sc.last && rng_state && vb >= 1 && tid / STG < SPB;
     if (stager) {      // this block's first SPB slots, requested now (blocks 1 .. n_phys - 1 share the batch; more passes, if any, further down)
         st_e = tid % STG;
         const int slot = (vb - 1) * SPB + tid / STG;
         if (slot < batch) st_slot = slot;
     }
-    const uint64_t base_n = stager ? mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)) : 0;      // (read once, here: the counter may move once every block has its ticket)
+    const uint64_t base_n = stager ? mix64(sc.rs0 + 0x9E3779B97F4A7C15ull * (sc.ctr + 2)) : 0;      // = sample_base of the call after this step's
     if (st_slot >= 0) st_v = staged_value(base_n, st_slot, st_e);
     // Segment `seg` of a column = the rows w = seg (mod RED_SEG), ascending (round 4; was: RED_SEG contiguous blocks of rows) -- the rows whose
     // workgroups share an XCD (block index % 8), which is what lets the one-launch step sum a segment inside that XCD's L2 (`grouped`: the eight
     // segment sums are already formed, in ws_grp; one row per segment is left to read).  Same order in every path: all of them stay bit-identical.
     bool late = false;
-    if (done && !grouped) {      // wait for the rows: ONE wavefront per block polls all n_part words (lane i watches rows i, i + 64, ...), every ~0.5 us.  (Eight
-                                 // polling wavefronts per block without a pause saturated the memory channel of the words and delayed the stores behind them.)
-        if (tid < 64) {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                bool ok = true;
-                for (int w = tid; w < n_part; w += 64) ok = ok && __hip_atomic_load(done + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == done_tag;
-                if (__all(ok)) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { late = true; break; }
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        late = __syncthreads_or(late);      // every row (and loss partial) is complete, for every wave
-    }
     PH3(1);
     float lpart = 0.f;      // block 0 sums the loss with iqn_grad_reduce's 256-thread shape
     float4 acc[VPB];
@@ -728,15 +788,16 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             if (s_buddy) {
                 bool glate = false;
                 const unsigned long long gmis = group_rows_wait(ws, n_part, bx, done_tag, tid, &glate);
-                if (gmis == 0 && !glate) {
+                if (gmis == 0 && !glate) {      // (glate: the block polls the granules below like any other; whoever waited for the row in vain raises the status word)
                     constexpr int PER = (N_COLS + 15) / 16, HALF = PER / 2;      // 560 columns per local workgroup, 280 of them here
                     const int c = (pb >> 3) * PER + HALF + tid, c1 = min(N_COLS, (pb >> 3) * PER + PER);
                     if (tid < PER - HALF && c < c1) {
                         const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
                         const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)bx * P_PAD, 0, P_PAD * 8, 0x00020000);
                         float4 t[16];
+                        // (sc1: past this CU's vector cache -- in a multi-step launch it may hold the previous step's row -- and served by the XCD's L2, which has the line)
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((bx + 8 * u) * N_COLS + c) * 16, 0, 1));
+                        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((bx + 8 * u) * N_COLS + c) * 16, 0, ROW_AUX));
                         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                         for (int u = 0; u < 16; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
@@ -767,7 +828,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             // Nothing can arrive for a while: these blocks start when the target workgroups end, i.e. when the TD targets are out, and the backward pass behind
             // those takes >= 9 us.  65 000 threads polling 2.3 MB of granules through that time is memory traffic next to the backward pass (on this chip it
             // costs the step nothing measurable -- 33.4-33.6 us with naps of 0 / 5 / 7 / 9 us -- but it is traffic other streams' kernels would see).
-            if (done)
+            if (!sc.multi)
                 while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)MN_TAIL_NAP) __builtin_amdgcn_s_sleep(32);
             bool want[VPB];
             uint64_t x[VPB][4];
@@ -804,29 +865,18 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
                     acc[j] = make_float4(__uint_as_float((uint32_t)x[j][0]), __uint_as_float((uint32_t)x[j][1]), __uint_as_float((uint32_t)x[j][2]), __uint_as_float((uint32_t)x[j][3]));
         }
     } else {
-    // Third role, ungrouped: the rows were written (through, at agent scope) by workgroups of this launch on other XCDs, and this XCD's L2 may still
-    // hold last step's copies of them.  They are read with agent-scope (sc1) loads, which do not hit such lines -- not behind an acquire fence:
-    // buffer_inv sc1 by 17 blocks per XCD, one after the other, cost 9 us of the first one-launch form.
+    // stand-alone launch: the rows are an earlier launch's
     if (vb == 0 && tid < 256)
-        for (int wq = tid; wq < n_part; wq += 256)
-            lpart += done ? __hip_atomic_load(ws + ws_loss(n_part) + wq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ws[ws_loss(n_part) + wq];
+        for (int wq = tid; wq < n_part; wq += 256) lpart += ws[ws_loss(n_part) + wq];
 #pragma unroll
     for (int j = 0; j < VPB; ++j)
     if (on[j] && col[j] < N_COLS) {
         const float4 *src = reinterpret_cast<const float4 *>(ws) + col[j];
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
         for (int wb = seg; wb < n_part; wb += RED_SEG * RED_MAX_PER) {
             float4 t[RED_MAX_PER];
-            if (done) {
 #pragma unroll
-                for (int u = 0; u < RED_MAX_PER; ++u)
-                    t[u] = wb + RED_SEG * u < n_part ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((wb + RED_SEG * u) * N_COLS + col[j]) * 16, 0, 16))
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-#pragma unroll
-                for (int u = 0; u < RED_MAX_PER; ++u)
-                    t[u] = wb + RED_SEG * u < n_part ? src[(size_t)(wb + RED_SEG * u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int u = 0; u < RED_MAX_PER; ++u)
+                t[u] = wb + RED_SEG * u < n_part ? src[(size_t)(wb + RED_SEG * u) * N_COLS] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < RED_MAX_PER; ++u) { acc[j].x += t[u].x; acc[j].y += t[u].y; acc[j].z += t[u].z; acc[j].w += t[u].w; }
         }
@@ -839,7 +889,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     // This block's ticket, taken HERE -- behind a barrier that every read of the epoch, the Adam step and the generator's counter above sits in front of -- and
     // looked at only at the very end: the round trip of the atomic (~1 us) runs under the norm exchange instead of between Adam and the end of the launch.
     unsigned ticket_old = 0;
-    if (tid == 0) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && sc.last) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seg == 0)
 #pragma unroll
     for (int j = 0; j < VPB; ++j) {
@@ -850,7 +900,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         if (on[j] && col[j] < N_COLS) {
             e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
-            ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
+            ss = sumsq4(s.x, s.y, s.z, s.w);   // padding columns are zeros
         }
         if (peers) {      // shared learner, one-shot exchange IN this launch (mn_iqn_train_step_xchg): publish this rank's columns, gather every rank's
             if (on[j] && col[j] < N_COLS) {
@@ -869,7 +919,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             float sc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) sc[k] = e[k] * grad_scale;
-            ss = ((sc[0] * sc[0] + sc[1] * sc[1]) + sc[2] * sc[2]) + sc[3] * sc[3];      // iqn_grad_sumsq's expression
+            ss = sumsq4(sc[0], sc[1], sc[2], sc[3]);      // iqn_grad_sumsq's expression
         }
         sq[j][cx] = ss;
 #pragma unroll
@@ -947,24 +997,25 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         gq *= coef;
         if (late) { grad[p[j]] = __builtin_nanf(""); continue; }
         grad[p[j]] = gq;      // the (clipped) gradient, as iqn_adam leaves it
-        const float mm = mp[j] + (gq - mp[j]) * wm;
-        const float vv = vp[j] * b2f + wv * (gq * gq);
+        float mm = mp[j], vv = vp[j], pn = pp[j];
+        adam_update(gq, mm, vv, pn, wm, b2f, wv, step_size, bc2_sqrt, eps);
         m[p[j]] = mm;
         v[p[j]] = vv;
-        params[p[j]] = pp[j] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        if (sc.multi) __hip_atomic_store(params + p[j], pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written through: the next step's forward pass reads it (ParamView<true>)
+        else params[p[j]] = pn;
     }
     // the block that took the LAST ticket advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
     // (every block read all of them before taking its ticket; nothing in this launch reads them after that)
     PH3(4);
-    if (tid == 0) {
+    if (tid == 0 && sc.last) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
         if (ticket_old == (unsigned)n_phys - 1u) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) += 1;
-            *step = *step + 1;
+            *reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part)) = sc.epoch + 1;
+            *step = sc.adam_step + 1;
             uint64_t *stg_tag = reinterpret_cast<uint64_t *>(ws + ws_epoch(n_part) + 4);
             if (rng_state) {
-                const uint64_t c = rng_state[1] + 1;
+                const uint64_t c = sc.ctr + 1;
                 rng_state[1] = c;
                 stg_tag[0] = c;
                 stg_tag[1] = prefetch_next ? (uint64_t)ba.ring_n : 0;
@@ -979,7 +1030,8 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict_
                                                               uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
                                                               float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                               int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
-    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u);
+    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false, false};
+    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, sc);
 }
 
 // ... and with the shared learner's one-shot gradient exchange inside (mn_iqn_train_step_xchg): two launches per step for a shared learner too
@@ -988,7 +1040,8 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
                                                                    float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                                    int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d,
                                                                    const XchgArgs *__restrict__ xa, float grad_scale) {
-    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, nullptr, 0u,
+    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false, false};
+    reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, sc,
                         xa, grad_scale);
 }
 
@@ -1054,7 +1107,7 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
     const unsigned long long s_mis = group_rows_wait(ws, n_part, x, tag, tid, &late_w);
     const int s_late = late_w ? 1 : 0;
 #ifdef MN_TRAIN_PHASES
-    if (threadIdx.x == 0) g_wgt[blockIdx.x][3] = wall_clock64();
+    if (tid_now() == 0) g_wgt[blockIdx.x][3] = wall_clock64();
 #endif
     const unsigned long long all = gsz == 64 ? ~0ull : ((1ull << gsz) - 1ull), mis = s_mis & all, well = ~mis & all;
     const unsigned long long takers = well ? well : all;      // nobody where it should be: every row is in memory, everybody can read them
@@ -1079,7 +1132,7 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         const int ca = c0 + (tid < HALF ? tid : 0);      // (threads beyond the half all read column c0 and drop it: no branch between the loads)
         float4 t[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, 1));
+        for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, ROW_AUX));
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < 16; ++u) { a.x += t[u].x; a.y += t[u].y; a.z += t[u].z; a.w += t[u].w; }
@@ -1093,9 +1146,9 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         const int ca = c0 + tid, cb = c0 + THREADS + tid, cb_eff = cb < c1 ? cb : c0;      // (c0 for all of them: one request per wave)
         float4 t[2][16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[0][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, 1));
+        for (int u = 0; u < 16; ++u) t[0][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + ca) * 16, 0, ROW_AUX));
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t[1][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + cb_eff) * 16, 0, 1));
+        for (int u = 0; u < 16; ++u) t[1][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + cb_eff) * 16, 0, ROW_AUX));
         float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -1106,7 +1159,7 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         for (int c = c0 + 2 * THREADS + tid; c < c1; c += THREADS) {      // (never with 16 takers)
             float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int u = 0; u < 16; ++u) {
-                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + c) * 16, 0, 1));
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * u) * N_COLS + c) * 16, 0, ROW_AUX));
                 a2.x += v.x; a2.y += v.y; a2.z += v.z; a2.w += v.w;
             }
             put(c, a2);
@@ -1119,7 +1172,7 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
             for (int i0 = 0; i0 < gsz; i0 += 8) {
                 float4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * (i0 + u)) * N_COLS + c) * 16, 0, 1));
+                for (int u = 0; u < 8; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((x + 8 * (i0 + u)) * N_COLS + c) * 16, 0, ROW_AUX));
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
             }
@@ -1132,24 +1185,30 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
         for (int i = 0; i < gsz; ++i) {
             const int off = ((x + 8 * i) * N_COLS + c) * 16;
             const float4 v = (mis >> i) & 1ull ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, off, 0, 16))
-                                               : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, off, 0, 1));
+                                               : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, off, 0, ROW_AUX));
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         put(c, acc);
     }
 }
 
-// The rest of the step as a THIRD ROLE of the forward / backward launch (n_wg > 0; round 4: one launch per gradient step): workgroups
-// [n_fwd, n_fwd + n_wg) are reduction + Adam blocks (reduce_adam_body).  They are dispatched after every forward / backward workgroup (higher
-// block indices), land on the CUs the target workgroups vacate half way through the launch, and wait there for the "row complete" words the local
-// workgroups write after their last partial-gradient store -- no launch boundary between the backward pass and the optimizer step.
+// ---- The fused step (round 5): reduction + clip + Adam inside the forward / backward launch, for one OR SEVERAL gradient steps ------------------------------
+// Every TARGET workgroup is also a reduction + Adam block (reduce_adam_body): target workgroup w runs the target network on the next_states of step k + 1 --
+// nothing in it depends on the local network -- and then does the reduction + Adam work of step k on the CU it sits on anyway (round 4 launched those blocks
+// behind the forward / backward workgroups, onto the CUs the target workgroups had vacated).  With n_steps > 1 nobody leaves: the launch is PERSISTENT, step
+// k + 1 starts when the reduction + Adam blocks have written step k's parameters (written through; one "parameters ready" word per block, polled by one
+// wavefront of every local workgroup), and reads its batch straight from the ring (its rows follow from {seed, call counter + k} by arithmetic: no staging, one
+// round trip).  What a multi-step launch removes per step: the launch boundary, the L2 write-back of 18 MB of partial rows at it (they are overwritten in the L2
+// by the next step), the generator-state -> batch -> weights chain at the head of a launch, and the target forward pass from the local workgroups' critical path.
+// TD targets of consecutive steps use two sets of granules (step parity): target workgroup w may publish step k + 1's before local workgroup w has read step k's.
+// Always XCD-grouped (the rows of an XCD's workgroups are summed inside its L2); batches whose half is not a multiple of 8 take two launches.
 struct StepTail {
-    int n_wg;           // reduction + Adam blocks launched behind the forward / backward workgroups, running
-    int n_virtual;      // ... the N_ADAM virtual blocks (XCD-grouped: up to two each, when they would not all find a free CU before the local workgroups end)
-    int hier;           // the rows of an XCD's workgroups are summed inside that XCD before anything crosses to the others (n_part % 8 == 0)
+    int n_virtual;      // != 0: the fused step; the N_ADAM virtual reduction + Adam blocks run on ...
+    int n_extra;        // ... the target workgroups + this many workgroups behind the forward / backward ones that do nothing else (small batches: 2 x (n_part + n_extra) >= N_ADAM)
+    int n_steps;        // gradient steps of this launch (>= 1)
     int misplace;       // test hook: pretend these local workgroups did not land on XCD (block index % 8): 1 = every fifth, 2 = all, 3 = all of group 3
-    int prefetch_next;
-    float *grad, *loss_out, *params, *m, *v;
+    int prefetch_next;  // the last step stages the batch of the call after this launch
+    float *grad, *loss_out, *params, *m, *v;      // loss_out [n_steps]
     int32_t *step;
     uint64_t *rng_state;
     double lr, b1, b2, eps, max_norm;
@@ -1157,72 +1216,105 @@ struct StepTail {
     float xa_scale;
 };
 
-// XCHG: the instantiation whose reduction + Adam role carries the shared learner's exchange (mn_iqn_train_step_xchg with MN_TRAIN_ONE_LAUNCH); the single learner's
-// kernel is compiled without that code (its eight mailbox pointers cost 75 more spilled scalar registers in a kernel that has none to spare).
-template <bool XCHG>
+// XCHG: the instantiation whose reduction + Adam role carries the shared learner's exchange; the single learner's kernel is compiled without that code (its
+// mailbox pointers cost 75 more spilled scalar registers in a kernel that has none to spare).  FUSED: the fused step above; false = forward / backward only
+// (two- and three-launch forms; `tail` unused): one step, ordinary parameter loads.
+template <bool XCHG, bool FUSED>
 __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const float *__restrict__ PL, const float *__restrict__ PT,
                                                             float *__restrict__ ws, int batch, float gamma, int mode, int use_staged, StepTail tail) {
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
     __shared__ int s_got;
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int tid = tid_now();
     const int n_part = batch / BE;
-    const bool two_roles = mode == MODE_TWO_ROLES;
-    if (tail.n_virtual) {
-        const int n_fwd = two_roles ? 2 * n_part : n_part;
-        if ((int)blockIdx.x >= n_fwd) {
-            const uint32_t dtag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;      // = the hand-off tag below
-            const uint32_t *gd = reinterpret_cast<const uint32_t *>(ws + ws_gdone(n_part));
-            if (tail.hier)      // XCD-grouped: tail.n_wg (>= half of them) blocks run the tail.n_virtual virtual ones
-                reduce_adam_body<2>((int)blockIdx.x - n_fwd, tail.n_wg, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
-                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f, true);
-            else
-                reduce_adam_body<1>((int)blockIdx.x - n_fwd, tail.n_virtual, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out, tail.rng_state, ba, tail.prefetch_next,
-                                    tail.params, tail.m, tail.v, tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, gd, dtag, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f, false);
-            return;
-        }
-    }
+    const bool two_roles = mode == MODE_TWO_ROLES;      // (FUSED: always)
+    const int n_fwd = two_roles ? 2 * n_part : n_part;
+    const int G = FUSED ? tail.n_steps : 1;
+    const bool is_extra = FUSED && (int)blockIdx.x >= n_fwd;            // reduction + Adam blocks only
+    const bool is_target = two_roles && (int)blockIdx.x < n_part;       // target workgroups come FIRST in dispatch order: nothing they need is produced by a local workgroup
+    const int part = is_extra ? 0 : (two_roles && !is_target ? blockIdx.x - n_part : blockIdx.x);
+    const int b0 = part * BE;
+    const int pb = is_extra ? n_part + ((int)blockIdx.x - n_fwd) : (int)blockIdx.x, n_phys = n_part + tail.n_extra;      // reduction + Adam role: physical block pb of n_phys
 #ifdef MN_TRAIN_PHASES
     const int ph_local = two_roles ? n_part : 0;
-    if (threadIdx.x == 0) g_wgt[blockIdx.x][0] = wall_clock64();
+    if (tid_now() == 0) g_wgt[blockIdx.x][0] = wall_clock64();
+#else
+    const int ph_local = -1;
 #endif
     PH(0);
-    const bool is_target = two_roles && (int)blockIdx.x < n_part;        // target workgroups come FIRST in dispatch order:
-    const int part = two_roles && !is_target ? blockIdx.x - n_part : blockIdx.x;   // nothing they need is produced in this launch
-    const int b0 = part * BE;
-    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + (size_t)part * ROWS;
-    // hand-off tag of this launch: never 0 (the workspace starts zero-filled), different from the previous launches' tags;
-    // the epoch word is advanced by iqn_grad_reduce, i.e. between two launches of this kernel
-    const uint32_t tag = (uint32_t)(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)) % 0xFFFFFFFFull) + 1u;
-    if (tail.n_virtual && tail.hier && !is_target && tid == 0) {      // XCD-grouped one-launch step: where this local workgroup runs (see "local workgroup" below)
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        __hip_atomic_store((gu64 *)(ws + ws_xcc(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)(xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // ---- The first requests of the kernel: (a) this workgroup's two batch slots as the previous step's reduction kernel STAGED them
-    // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
-    // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
-    const float *stage = ws + ws_stage(n_part);
-    const int st_slot = min(tid / STG, BE - 1), st_e = tid % STG;
-    // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
-    uint64_t rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;
+    // ---- the counters this launch starts from; nothing in memory moves before its last step's reduction + Adam blocks have all taken their ticket
+    const uint64_t epoch0 = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part));
+    uint64_t rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;      // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
     if (ba.rng_state) {
         const uint64_t *stg_tag = reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 4);
         rs0 = ba.rng_state[0]; rs1 = ba.rng_state[1];
         tg0 = stg_tag[0]; tg1 = stg_tag[1];
     }
+    int32_t step0 = 0;
+    if (FUSED && (is_target || is_extra)) step0 = *tail.step;
+
+    // Iteration k: target workgroups run the target forward pass of step k, then the reduction + Adam work of step k - 1; local workgroups run step k.
+    const int tid_launch = tid;
+    float *const ws_launch = ws;
+    const float *const PL_launch = PL, *const PT_launch = PT;
+    for (int k = 0; k <= G; ++k) {
+    // (One step's address arithmetic must not be hoisted out of the loop -- hundreds of values would then live across the whole body, 1 KB of scratch per lane: the
+    // thread index and the base pointers are made opaque per iteration, and everything derived from them is derived again.)
+    int tid = tid_launch;
+    float *ws = ws_launch;
+    const float *PL = PL_launch, *PT = PT_launch;
+    if (FUSED) asm volatile("" : "+v"(tid), "+s"(ws), "+s"(PL), "+s"(PT));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const ParamView<FUSED> VL(PL);
+    const float *stage = ws + ws_stage(n_part);
+    const int st_slot = min(tid / STG, BE - 1), st_e = tid % STG;
+    float *out = ws + (size_t)part * P_PAD;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
+    if (k < G && !is_extra) {
+    // hand-off tag of this step: never 0 (the workspace starts zero-filled), different from the neighbouring steps' and launches' tags
+    const uint32_t tag = (uint32_t)((epoch0 + (uint64_t)k) % 0xFFFFFFFFull) + 1u;
+    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + ((size_t)(k & 1) * n_part + part) * ROWS;
+    if (FUSED && !is_target && tid == 0) {      // where this local workgroup runs (see "local workgroup" below)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store((gu64 *)(ws + ws_xcc(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)(xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (FUSED && !is_target && k > 0) {
+        // ---- multi-step launch: the parameters of step k - 1, from every reduction + Adam block (their stores are written through and acknowledged before the
+        // word is): ONE wavefront polls the n_phys words, everything this workgroup reads of the local network from here on is read past its vector cache
+        const uint32_t ptag = (uint32_t)((epoch0 + (uint64_t)k - 1) % 0xFFFFFFFFull) + 1u;
+        bool plate = false;
+        if (wave == 0) {
+            const gu64 *pf = (const gu64 *)(ws + ws_pflag(n_part));
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool ok = true;
+                for (int q = lane; q < n_phys; q += 64) ok = ok && (uint32_t)(__hip_atomic_load(pf + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == ptag;
+                if (__all(ok)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { plate = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (plate && lane == 0) atomicAdd(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 12), 1u);      // (status word: this step runs on stale parameters)
+        }
+        __syncthreads();
+    }
+
+    // ---- The first requests of a step: (a) -- first step of a launch -- this workgroup's two batch slots as the previous launch's reduction blocks STAGED them
+    // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
+    // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
+    const bool try_staged = use_staged && k == 0;
     float st_v = 0.f;
-    if (use_staged) st_v = stage[(b0 + st_slot) * STG + st_e];      // kernel argument: a scalar branch
+    if (try_staged) st_v = stage[(b0 + st_slot) * STG + st_e];      // kernel argument: a scalar branch
     FwdWeights w;
-    prefetch_forward(w, is_target ? PT : PL);
+    const ParamView<FUSED> V(is_target ? PT : PL);
+    prefetch_forward(w, V);
     PH(14);  /* all requests issued */
     // the staged batch is this step's batch iff it was drawn for this call counter from a ring of this many rows
     uint64_t base = 0;
     bool staged = false;
     if (ba.rng_state) {
-        base = mix64(rs0 + 0x9E3779B97F4A7C15ull * (rs1 + 1));      // = sample_base(rng_state)
-        staged = use_staged && tg0 == rs1 && tg1 == (uint64_t)ba.ring_n;
+        base = mix64(rs0 + 0x9E3779B97F4A7C15ull * (rs1 + (uint64_t)k + 1));      // = sample_base of the generator at call counter rs1 + k
+        staged = try_staged && tg0 == rs1 && tg1 == (uint64_t)ba.ring_n;
     }
     PH(15);  /* generator state / staging tag read */
     int64_t row0 = 0, row1 = 0;      // (BE = 2; selects instead of an indexed array, which would live in scratch)
@@ -1278,7 +1370,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
     PH(16);  /* wave 0 has its transitions in LDS */
     __syncthreads();
-    prefetch_forward_late(w, is_target ? PT : PL);
+    prefetch_forward_late(w, V);
     PH(1);   /* draw + gather + weight requests */
 
     // output-layer row of the action taken, for dh3 (element tid + 512 e of the [16][64] tile: row 8 e + (tid >> 6), column tid & 63,
@@ -1286,15 +1378,12 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     float w4row[2] = {0.f, 0.f};
     if (!is_target) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) w4row[e] = PL[O_W4 + s_act[e] * H + (tid & 63)];
+        for (int e = 0; e < 2; ++e) w4row[e] = VL.f1(O_W4 + s_act[e] * H + (tid & 63));
     }
     const PassBufs Bl = {S + S_C, is_target ? nullptr : S + S_H1, S + S_X, S + S_H2, S + S_H3, S + S_FEAT, S + S_Q};
     BwdWeights bw;
-    #ifndef MN_TRAIN_PHASES
-    const int ph_local = -1;
-#endif
-    if (is_target) forward_pass<false>(Bl, w, S + S_OBS, S + S_TAU, nullptr, nullptr, ph_local);
-    else forward_pass<true>(Bl, w, S + S_OBS, S + S_TAU, &bw, PL, ph_local);
+    if (is_target) forward_pass<false>(Bl, w, S + S_OBS, S + S_TAU, nullptr, VL, ph_local);
+    else forward_pass<true>(Bl, w, S + S_OBS, S + S_TAU, &bw, VL, ph_local);
 
     if (is_target) {
         // publish the 16 TD targets: one self-tagged 8-byte granule each ({epoch, value}, agent-scope store: the data is the flag)
@@ -1304,27 +1393,27 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             __hip_atomic_store(granules + tid, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PH(7);   /* granules published */
-        if (blockIdx.x == 0) write_batch_copies(ba, base, batch);
+        if (blockIdx.x == 0 && k == G - 1) write_batch_copies(ba, base, batch);
 #ifdef MN_TRAIN_PHASES
-        if (threadIdx.x == 0) g_wgt[blockIdx.x][1] = wall_clock64();
+        if (tid_now() == 0) g_wgt[blockIdx.x][1] = wall_clock64();
 #endif
-        return;
-    }
+        if (FUSED) __syncthreads();      // (the next forward pass of this workgroup overwrites the rewards / done flags wave 0 has just read)
+    } else {
 
     // ---- local workgroup
-    // XCD-grouped one-launch step: the rows w = x (mod 8) are summed inside one XCD's L2, so their workgroups have to share an XCD.  The dispatcher deals
+    // The rows w = x (mod 8) are summed inside one XCD's L2, so their workgroups have to share an XCD.  The dispatcher deals
     // workgroups out to the XCDs round-robin (scripts/probes/xcc_placement.hip) -- from XCD 0 in a fresh process, from another one after other streams were
     // in use -- so block index % 8 names a set of workgroups on ONE XCD, not which.  Each local workgroup publishes the XCD it runs on; a group's XCD is
     // that of its first workgroup, whose word the others read here (long before they need it, behind the TD targets).
     uint64_t lead_word = 0;
     unsigned my_xcc = 0;
-    if (tail.n_virtual && tail.hier) {
+    if (FUSED) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
         my_xcc &= 15u;
         if (tid == 0 && (part >> 3) != 0) lead_word = __hip_atomic_load((const gu64 *)(ws + ws_xcc(n_part)) + (part & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- TD targets: from the target workgroup of the same two batch elements (ready by now -- it ran the same forward at the same
-    // time on another CU), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
+    // time on another CU; in a multi-step launch one step ahead), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
     // dispatch makes impossible -- kept so that a wait can never hang the device)
     if (two_roles) {
         if (wave == 0) {
@@ -1348,12 +1437,12 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
     if (!two_roles || !s_got) {
         if (two_roles) {   // late fallback: the target side's inputs, from the staged slots or gathered now
-            const int be = min(tid / OBS, BE - 1), k = tid % OBS;
+            const int be = min(tid / OBS, BE - 1), kk = tid % OBS;
             if (staged) {
-                if (tid < BE * OBS) S[T_OBS + be * 28 + k] = stage[(b0 + be) * STG + OBS + k];
+                if (tid < BE * OBS) S[T_OBS + be * 28 + kk] = stage[(b0 + be) * STG + OBS + kk];
                 if (tid < ROWS) S[T_TAU + tid] = stage[(b0 + (tid >> 3)) * STG + 56 + (tid & 7)];
             } else {
-                if (tid < BE * OBS) S[T_OBS + be * 28 + k] = ba.ring_ns[(be ? row1 : row0) * OBS + k];
+                if (tid < BE * OBS) S[T_OBS + be * 28 + kk] = ba.ring_ns[(be ? row1 : row0) * OBS + kk];
                 if (tid < ROWS) {
                     const int e_t = b0 * NQ + tid;
                     S[T_TAU + tid] = ba.rng_state ? sample_tau(base, e_t) : ba.taus_t[e_t];
@@ -1362,10 +1451,11 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             __syncthreads();
         }
         FwdWeights wt;
-        prefetch_forward(wt, PT);
-        prefetch_forward_late(wt, PT);
+        const ParamView<FUSED> VT(PT);
+        prefetch_forward(wt, VT);
+        prefetch_forward_late(wt, VT);
         const PassBufs Bt = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
-        forward_pass<false>(Bt, wt, S + T_OBS, S + T_TAU, nullptr, nullptr, -2);
+        forward_pass<false>(Bt, wt, S + T_OBS, S + T_TAU, nullptr, VT, -2);
         if (tid < ROWS) {
             const int be = tid >> 3;
             S[S_QT + tid] = td_target(S + T_Q, tid, S[S_MISC + be], S[S_MISC + BE + be], gamma);
@@ -1376,13 +1466,10 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     PH(8);   /* TD targets in LDS (hand-off wait, or own target forward) */
     // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407); every thread evaluates the (cheap) gradient of
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
-    float *out = ws + (size_t)part * P_PAD;
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
-    // One-launch step: the row is read by other workgroups of THIS launch.  XCD-grouped (tail.hier): by the workgroups of its group (block index % 8),
-    // which share an XCD, through that XCD's L2: ordinary stores.  A workgroup that is NOT on its group's XCD (never observed), and every workgroup
-    // of the ungrouped form, writes its row through to memory.
+    // Fused step: the row is read by the workgroups of its group (block index % 8), which share an XCD, through that XCD's L2: ordinary stores.  A workgroup
+    // that is NOT on its group's XCD (never observed) writes its row through to memory.
     bool wellplaced = false;
-    if (tail.n_virtual && tail.hier) {
+    if (FUSED) {
         __shared__ int s_well;
         if (tid == 0) {
             const gu64 *lw = (const gu64 *)(ws + ws_xcc(n_part)) + (part & 7);
@@ -1401,14 +1488,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         __syncthreads();
         wellplaced = s_well != 0;
     }
-    if (tail.n_virtual && tail.hier && !wellplaced && tid == 0)      // epoch block word [9]: local workgroups that found themselves on another XCD, ever (diagnostic)
+    if (FUSED && !wellplaced && tid == 0)      // epoch block word [9]: local workgroups that found themselves on another XCD, ever (diagnostic)
         __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 9), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool wt = tail.n_virtual != 0 && !wellplaced;
-    const bool keep = tail.n_virtual != 0 && wellplaced;
-    const bool wt_loss = tail.n_virtual != 0;      // the loss partials are read by one block of the tail, wherever it runs
+    const bool wt = FUSED && !wellplaced;
+    const bool keep = FUSED && wellplaced;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int t = tid + THREADS * e, r = t >> 6, k = t & 63, be = r >> 3;
+        const int t = tid + THREADS * e, r = t >> 6, kq = t & 63, be = r >> 3;
         const float qe = S[S_Q + r * 12 + s_act[be]], tau = S[S_TAU + r];
         float lsum = 0.f, gsum = 0.f;
 #pragma unroll
@@ -1416,26 +1502,26 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             const float td = S[S_QT + be * NQ + j] - qe, ad = fabsf(td);
             const float hub = ad <= 1.f ? 0.5f * td * td : ad - 0.5f;
             const float wq = fabsf(tau - (td < 0.f ? 1.f : 0.f));
-            lsum += wq * hub;
-            gsum += wq * fminf(fmaxf(td, -1.f), 1.f);
+            lsum = fmaf(wq, hub, lsum);
+            gsum = fmaf(wq, fminf(fmaxf(td, -1.f), 1.f), gsum);
         }
         const float scale = 1.f / (float)(batch * NQ);
         const float gr = -gsum * scale;
-        if (k == 0) {
+        if (kq == 0) {
             S[S_G + r] = gr;
             S[S_MISC + 2 * BE + r] = lsum * scale;
         }
         // output layer backward: only the taken action's row carries gradient
-        S[S_DH3 + r * LDC + k] = S[S_H3 + r * LDC + k] > 0.f ? gr * w4row[e] : 0.f;
+        S[S_DH3 + r * LDC + kq] = S[S_H3 + r * LDC + kq] > 0.f ? gr * w4row[e] : 0.f;
     }
     __syncthreads();
     PH(9);   /* loss + dh3 */
     if (tid == 0) {
         float l = 0.f;
         for (int r = 0; r < ROWS; ++r) l += S[S_MISC + 2 * BE + r];
-        if (tail.n_virtual && tail.hier)      // grouped one-launch step: self-tagged, polled by the tail's block 0
+        if (FUSED)      // self-tagged, polled by reduction + Adam block 0
             __hip_atomic_store((gu64 *)(ws + ws_lossq(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else pstore1(ws + ws_loss(n_part) + part, l, wt_loss);
+        else ws[ws_loss(n_part) + part] = l;
     }
 
     // ---- backward (all 8 waves)
@@ -1459,9 +1545,9 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     for (int e = tid; e < NA * H + NA + H; e += THREADS) {   // dW4, db4, db3
         float v = 0.f;
         if (e < NA * H) {
-            const int a = e >> 6, k = e & 63;
+            const int a = e >> 6, kq = e & 63;
             for (int r = 0; r < ROWS; ++r)
-                if (s_act[r >> 3] == a) v += S[S_G + r] * S[S_H3 + r * LDC + k];
+                if (s_act[r >> 3] == a) v = fmaf(S[S_G + r], S[S_H3 + r * LDC + kq], v);
             pstore1(out + O_W4 + e, v, wt);
         } else if (e < NA * H + NA) {
             const int a = e - NA * H;
@@ -1469,9 +1555,9 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
                 if (s_act[r >> 3] == a) v += S[S_G + r];
             pstore1(out + O_B4 + a, v, wt);
         } else {
-            const int k = e - NA * H - NA;
-            for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + k];
-            pstore1(out + O_B3 + k, v, wt);
+            const int kq = e - NA * H - NA;
+            for (int r = 0; r < ROWS; ++r) v += S[S_DH3 + r * LDC + kq];
+            pstore1(out + O_B3 + kq, v, wt);
         }
     }
     __syncthreads();
@@ -1535,10 +1621,10 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
         const float d0 = S[S_DF + o], d1 = S[S_DF + F + o];
         const float *x0 = S + S_OBS, *x1 = S + S_OBS + 28;
         if (o < 16) {
-            for (int k = 0; k < 2; ++k) pstore1(out + O_VW + o * 2 + k, d0 * x0[k] + d1 * x1[k], wt);
+            for (int kq = 0; kq < 2; ++kq) pstore1(out + O_VW + o * 2 + kq, fmaf(d1, x1[kq], d0 * x0[kq]), wt);
             pstore1(out + O_VB + o, d0 + d1, wt);
         } else if (o < 32) {
-            for (int k = 0; k < 2; ++k) pstore1(out + O_GW + (o - 16) * 2 + k, d0 * x0[2 + k] + d1 * x1[2 + k], wt);
+            for (int kq = 0; kq < 2; ++kq) pstore1(out + O_GW + (o - 16) * 2 + kq, fmaf(d1, x1[2 + kq], d0 * x0[2 + kq]), wt);
             pstore1(out + O_GB + o - 16, d0 + d1, wt);
         } else {
             pstore1(out + O_SB + o - 32, d0 + d1, wt);
@@ -1551,8 +1637,8 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             f32x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int e = 4 * q + c, o = 32 + e / 22, k = e % 22;
-                v[c] = S[S_DF + o] * x0[4 + k] + S[S_DF + F + o] * x1[4 + k];
+                const int e = 4 * q + c, o = 32 + e / 22, kq = e % 22;
+                v[c] = fmaf(S[S_DF + F + o], x1[4 + kq], S[S_DF + o] * x0[4 + kq]);
             }
             pstore4(out, out_rsrc, O_SW + 4 * q, v, wt, keep);
         }
@@ -1560,30 +1646,45 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
     if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
-    if (tail.n_virtual) {      // one-launch step: this workgroup's row (and loss partial) is final
+    if (FUSED) {      // this workgroup's row (and loss partial) is final
         // Its stores are acknowledged -- by memory if they were write-through ones, by this XCD's L2 otherwise -- once vmcnt is 0; nothing of a
         // written-through row sits dirty in an L2: no __threadfence() (= an L2 write-back per workgroup, which made the first one-launch form 2.5 x slower)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         PH(17);
 #ifdef MN_TRAIN_PHASES
-        if (threadIdx.x == 0) g_wgt[blockIdx.x][2] = wall_clock64();
+        if (tid_now() == 0) g_wgt[blockIdx.x][2] = wall_clock64();
 #endif
-        if (tail.hier) {
-            if (tid == 0) {
-                if (wellplaced) *reinterpret_cast<volatile uint32_t *>(ws + ws_lflag(n_part) + 64 * (part & 7) + (part >> 3)) = tag;      // for this XCD's L2
-                __hip_atomic_store((gu64 *)(ws + ws_done(n_part)) + part, ((uint64_t)tag << 32) | (wellplaced ? 0u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to wait for behind it)
-            PH(18);
-        } else if (tid == 0) {
-            __hip_atomic_store(reinterpret_cast<uint32_t *>(ws + ws_gdone(n_part)) + part, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what the reduction + Adam blocks wait for
+        if (tid == 0) {
+            if (wellplaced) *reinterpret_cast<volatile uint32_t *>(ws + ws_lflag(n_part) + 64 * (part & 7) + (part >> 3)) = tag;      // for this XCD's L2
+            __hip_atomic_store((gu64 *)(ws + ws_done(n_part)) + part, ((uint64_t)tag << 32) | (wellplaced ? 0u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to wait for behind it)
+        PH(18);
     }
 #ifdef MN_TRAIN_PHASES
     __builtin_amdgcn_s_waitcnt(0);
-    if (threadIdx.x == 0) g_wgt[blockIdx.x][1] = wall_clock64();
+    if (tid_now() == 0) g_wgt[blockIdx.x][1] = wall_clock64();
 #endif
+    }      // local workgroup
+    }      // forward / backward of step k
+    if (!FUSED) break;
+    if ((is_target || is_extra) && k >= 1) {
+        // ---- reduction + clip + Adam of step k - 1
+        const int s = k - 1;
+        const StepCtx sc = {epoch0 + (uint64_t)s, step0 + s, rs0, rs1 + (uint64_t)s, s == G - 1, true, G > 1};
+        reduce_adam_body<2>(pb, n_phys, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out + s, tail.rng_state, ba, tail.prefetch_next, tail.params, tail.m, tail.v,
+                            tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, sc, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f);
+        if (s < G - 1) {      // more steps to come: this block's parameters are out (write-through stores, acknowledged) -- say so
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t stag = (uint32_t)((epoch0 + (uint64_t)s) % 0xFFFFFFFFull) + 1u;
+                __hip_atomic_store((gu64 *)(ws + ws_pflag(n_part)) + pb, (uint64_t)stag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    }      // k
 }
 
 // grad[p] = sum over workgroups of partial[wg][p].  One thread = one float4 column of one of RED_SEG contiguous segments of the
@@ -1595,19 +1696,19 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
                                                                        BatchArgs ba, int prefetch_next, uint64_t mailbox) {
     __shared__ float4 red[RED_SEG][RED_COLS];
     __shared__ float sq[RED_COLS];
-    const int cx = threadIdx.x % RED_COLS, seg = threadIdx.x / RED_COLS;
+    const int cx = tid_now() % RED_COLS, seg = tid_now() / RED_COLS;
     const int col = blockIdx.x * RED_COLS + cx;
     PH2(0, 0);
     constexpr int BT = RED_COLS * RED_SEG;
     // A workspace that mn_iqn_train_workspace_init never saw holds garbage tickets / epoch / tags: the counters would never advance and the
     // learner would silently repeat one batch.  Fail loudly instead: NaN loss, gradient untouched, Adam refuses too.
     if (*reinterpret_cast<const uint32_t *>(ws + ws_epoch(n_part) + 8) != WS_MAGIC) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[0] = __builtin_nanf("");
+        if (blockIdx.x == 0 && tid_now() == 0) loss_out[0] = __builtin_nanf("");
         return;
     }
     float lpart = 0.f;      // block 0 sums the loss: its partials are requested now, summed at the end
     if (blockIdx.x == 0)
-        for (int wq = threadIdx.x; wq < n_part; wq += BT) lpart += ws[ws_loss(n_part) + wq];
+        for (int wq = tid_now(); wq < n_part; wq += BT) lpart += ws[ws_loss(n_part) + wq];
     // ---- staging of the NEXT step's batch (prefetch_next; blocks 1..): slot k of call counter + 1 -- ring row perm(k), its transition,
     // its 16 taus -- goes to a fixed address, so the next forward / backward launch starts with one round trip instead of three.
     // Requested first: the loads ride on the reduction's own memory latency.  The ring must not change before that launch uses it
@@ -1626,10 +1727,10 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         if (e >= 56) return sample_tau(base_n, (e < 64 ? 0 : batch * NQ) + slot * NQ + (e & 7));
         return 0.f;
     };
-    const bool stager = prefetch_next && rng_state && blockIdx.x >= 1 && (int)threadIdx.x / STG < SPB;
+    const bool stager = prefetch_next && rng_state && blockIdx.x >= 1 && (int)tid_now() / STG < SPB;
     if (stager) {      // this block's first SPB slots, requested now (more passes, for batches > 837, at the store below)
-        st_e = threadIdx.x % STG;
-        const int slot = ((int)blockIdx.x - 1) * SPB + threadIdx.x / STG;
+        st_e = tid_now() % STG;
+        const int slot = ((int)blockIdx.x - 1) * SPB + tid_now() / STG;
         if (slot < batch) st_slot = slot;
     }
     const uint64_t base_n = stager ? mix64(rng_state[0] + 0x9E3779B97F4A7C15ull * (rng_state[1] + 2)) : 0;   // = sample_base after this step's increment (read once: see the ticket)
@@ -1653,7 +1754,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     PH2(0, 2);
     // this block's ticket, behind a barrier that its reads of the epoch and the generator's counter sit in front of, looked at only at the end (see reduce_adam_body)
     unsigned ticket_old = 0;
-    if (threadIdx.x == 0) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid_now() == 0) ticket_old = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (seg == 0) {
         float4 s = red[0][cx];
 #pragma unroll
@@ -1667,7 +1768,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
                 for (int k = 0; k < 4; ++k)
                     if (p + k < P_TOTAL) grad[p + k] = e[k];
             }
-            ss = ((s.x * s.x + s.y * s.y) + s.z * s.z) + s.w * s.w;   // padding columns are zeros
+            ss = sumsq4(s.x, s.y, s.z, s.w);   // padding columns are zeros
             // one-shot exchange of a shared learner (mn_xchg_*): the reduced gradient also goes to this rank's mailbox as self-tagged
             // 8-byte granules {step tag, value}, system scope -- the peers' gather kernels poll them, the data is the flag
             const uint64_t mb = mailbox ? mailbox : *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 10);      // (argument, or mn_xchg_attach's word)
@@ -1683,7 +1784,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         sq[cx] = ss;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid_now() == 0) {
         float t = 0.f;
         for (int k = 0; k < RED_COLS; ++k) t += sq[k];
         ws[ws_sq(n_part) + blockIdx.x] = t;
@@ -1693,9 +1794,9 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
         float l = lpart;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-        if ((threadIdx.x & 63) == 0) lw[threadIdx.x >> 6] = l;
+        if ((tid_now() & 63) == 0) lw[tid_now() >> 6] = l;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid_now() == 0) {
             float t = 0.f;
             for (int k = 0; k < BT / 64; ++k) t += lw[k];
             *loss_out = t;
@@ -1705,13 +1806,13 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
     if (st_slot >= 0) ws[ws_stage(n_part) + (size_t)st_slot * STG + st_e] = st_v;
     if (stager && gridDim.x > 1)
         for (int j = (int)blockIdx.x - 1 + ((int)gridDim.x - 1); j * SPB < batch; j += (int)gridDim.x - 1) {
-            const int slot = j * SPB + threadIdx.x / STG;
+            const int slot = j * SPB + tid_now() / STG;
             if (slot < batch)
                 ws[ws_stage(n_part) + (size_t)slot * STG + st_e] = staged_value(base_n, slot, st_e);
         }
     // the block that finishes LAST advances the generator's call counter (the batch of this step was drawn by iqn_train_fwdbwd; the
     // staging blocks above read the old value) and the hand-off epoch, and tags the staged batch
-    if (threadIdx.x == 0) {
+    if (tid_now() == 0) {
         unsigned *ticket = reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 3);
         if (ticket_old == gridDim.x - 1) {
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1742,7 +1843,7 @@ __global__ __launch_bounds__(RED_COLS *RED_SEG) void iqn_grad_reduce(float *__re
 // after an all-reduce(SUM); exactly 1.0f otherwise).
 __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale) {
     __shared__ float sq[RED_COLS];
-    const int q = (blockIdx.x * RED_COLS + threadIdx.x) * 4;
+    const int q = (blockIdx.x * RED_COLS + tid_now()) * 4;
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (q + 3 < P_TOTAL) {
         const float4 x = *reinterpret_cast<const float4 *>(grad + q);
@@ -1752,9 +1853,9 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_sumsq(const float *__restri
             if (q + k < P_TOTAL) e[k] = grad[q + k];
     }
     for (int k = 0; k < 4; ++k) e[k] *= grad_scale;
-    sq[threadIdx.x] = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3];
+    sq[tid_now()] = sumsq4(e[0], e[1], e[2], e[3]);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid_now() == 0) {
         float t = 0.f;
         for (int k = 0; k < RED_COLS; ++k) t += sq[k];
         blocksq[blockIdx.x] = t;
@@ -1773,7 +1874,7 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int
                                                             float *__restrict__ grad, float *__restrict__ blocksq, float grad_scale,
                                                             unsigned *__restrict__ status, uint64_t bound) {
     __shared__ float sq[RED_COLS];
-    const int q = (blockIdx.x * RED_COLS + threadIdx.x) * 4;
+    const int q = (blockIdx.x * RED_COLS + tid_now()) * 4;
     const uint32_t tag = xchg_tag(*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)));      // (the reduction kernel advanced the epoch)
     float e[4] = {0.f, 0.f, 0.f, 0.f};
     if (q < P_PAD) {
@@ -1807,9 +1908,9 @@ __global__ __launch_bounds__(RED_COLS) void iqn_grad_gather(XchgPeers peers, int
                 else e[k] = 0.f;
     }
     for (int k = 0; k < 4; ++k) e[k] *= grad_scale;
-    sq[threadIdx.x] = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3];
+    sq[tid_now()] = sumsq4(e[0], e[1], e[2], e[3]);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid_now() == 0) {
         float t = 0.f;
         for (int k = 0; k < RED_COLS; ++k) t += sq[k];
         blocksq[blockIdx.x] = t;
@@ -1822,17 +1923,17 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
                                                 double max_norm_d, float grad_scale) {
     __shared__ float red[4];
     __shared__ float s_bc[2];
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * 256 + tid_now();
     PH2(1, 0);
     if (ticket[6] != WS_MAGIC) return;      // (ticket = epoch block + 2) workspace not initialised: see iqn_grad_reduce
     // this thread's operands first: their latency overlaps the norm
     float gq = 0.f, mp = 0.f, vp = 0.f, pp = 0.f;
     if (p < P_TOTAL) { gq = grad[p] * grad_scale; mp = m[p]; vp = v[p]; pp = params[p]; }
     float part = 0.f;
-    for (int c = threadIdx.x; c < N_RED; c += 256) part += blocksq[c];
+    for (int c = tid_now(); c < N_RED; c += 256) part += blocksq[c];
     int t_step = 0;
     unsigned ticket_old = 0;
-    if (threadIdx.x == 255) {
+    if (tid_now() == 255) {
         t_step = *step + 1;
         // python-float (double) scalars of torch's Adam, rounded to float32 where the tensor kernels consume them
         s_bc[0] = (float)(lr / (1.0 - pow(b1, (double)t_step)));
@@ -1844,7 +1945,7 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     // wave sums in a fixed order (DPP row / bank shuffles), then the four wave sums
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    if ((tid_now() & 63) == 0) red[tid_now() >> 6] = part;
     __syncthreads();
     PH2(1, 1);   /* norm partials summed, bias corrections computed */
     const float sumsq = (red[0] + red[1]) + (red[2] + red[3]);
@@ -1853,20 +1954,19 @@ __global__ __launch_bounds__(256) void iqn_adam(float *__restrict__ params, floa
     const float step_size = s_bc[0], bc2_sqrt = s_bc[1];
     const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), eps = (float)eps_d;
     const bool bad = !(sumsq == sumsq);      // NaN norm: the exchange in front of this launch timed out (iqn_grad_gather) -- nothing is updated, the status word counts it
-    if (bad && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ticket + 10, 1u);      // (ticket = epoch block + 2; + 10 = the workspace's status word)
+    if (bad && blockIdx.x == 0 && tid_now() == 0) atomicAdd(ticket + 10, 1u);      // (ticket = epoch block + 2; + 10 = the workspace's status word)
     if (p < P_TOTAL && bad) grad[p] = __builtin_nanf("");
     if (p < P_TOTAL && !bad) {
         gq *= coef;
         grad[p] = gq;
-        const float mm = mp + (gq - mp) * w1;                 // lerp, as torch's _single_tensor_adam
-        const float vv = vp * b2f + w2 * (gq * gq);
-        m[p] = mm;
-        v[p] = vv;
-        params[p] = pp - step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        adam_update(gq, mp, vp, pp, w1, b2f, w2, step_size, bc2_sqrt, eps);
+        m[p] = mp;
+        v[p] = vp;
+        params[p] = pp;
     }
     PH2(1, 2);
     // the block with the LAST ticket stores the advanced counter: every block's thread 255 read it before taking its ticket
-    if (threadIdx.x == 255 && ticket_old == gridDim.x - 1) {
+    if (tid_now() == 255 && ticket_old == gridDim.x - 1) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *step = t_step;
     }
@@ -1879,9 +1979,9 @@ __global__ __launch_bounds__(256) void iqn_sample_kernel(int64_t n, int batch, u
                                                          int64_t *__restrict__ idx, float *__restrict__ taus, int n_taus) {
     const uint64_t ctr = state[1], base = sample_base(state);
     __syncthreads();
-    for (int e = threadIdx.x; e < n_taus; e += 256) taus[e] = sample_tau(base, e);
-    for (int k = threadIdx.x; k < batch; k += 256) idx[k] = perm_row(base, (uint32_t)n, (uint32_t)k);
-    if (threadIdx.x == 0) state[1] = ctr + 1;
+    for (int e = tid_now(); e < n_taus; e += 256) taus[e] = sample_tau(base, e);
+    for (int k = tid_now(); k < batch; k += 256) idx[k] = perm_row(base, (uint32_t)n, (uint32_t)k);
+    if (tid_now() == 0) state[1] = ctr + 1;
 }
 
 int g_train_mode = MODE_TWO_ROLES;
@@ -1986,8 +2086,9 @@ static int dev_info(DevInfo *out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
         // the forward / backward kernel's dynamic LDS (97 KB) is above the default limit: raised once per device
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MN_ERR_HIP;
         int a = 0, b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void *>(iqn_grad_reduce_adam), RA_BT, 0) != hipSuccess ||
@@ -2006,9 +2107,10 @@ static int dev_info(DevInfo *out) {
 struct LaunchPlan {
     int mode;        // MODE_TWO_ROLES / MODE_LOCAL_ONLY
     int n_fwd;       // forward / backward workgroups
-    int launches;    // 1: reduction + Adam ride in the forward / backward launch; 2: + iqn_grad_reduce_adam[_xchg]; 3: + iqn_grad_reduce + iqn_adam; 4: + iqn_grad_reduce,
-                     // iqn_grad_gather, iqn_adam (shared learner on a device too small for the fused launch)
-    int hier, n_tail;
+    int launches;    // per gradient step -- 1: the fused step (reduction + Adam ride in the forward / backward launch; a multi-step call is ONE launch altogether);
+                     // 2: + iqn_grad_reduce_adam[_xchg]; 3: + iqn_grad_reduce + iqn_adam; 4: + iqn_grad_reduce, iqn_grad_gather, iqn_adam (shared learner on a device
+                     // too small for the fused launches)
+    int n_extra;     // fused: workgroups behind the forward / backward ones that only run reduction + Adam blocks
 };
 static LaunchPlan plan_launch(const DevInfo &d, int batch, int flags, bool adam, bool xchg) {
     LaunchPlan p = {};
@@ -2018,17 +2120,14 @@ static LaunchPlan plan_launch(const DevInfo &d, int batch, int flags, bool adam,
     p.mode = (g_train_mode == MODE_TWO_ROLES && 2 * n_part <= d.n_cu) ? MODE_TWO_ROLES : MODE_LOCAL_ONLY;
     p.n_fwd = p.mode == MODE_TWO_ROLES ? 2 * n_part : n_part;
     if (!adam) { p.launches = 2; return p; }      // (mn_iqn_train_grad*: forward / backward + iqn_grad_reduce; Adam is the caller's next call)
-    if ((flags & MN_TRAIN_ONE_LAUNCH) && p.n_fwd <= d.n_cu) {
-        // every forward / backward workgroup has a CU of its own (the local ones wait for each other's rows) ...
-        p.hier = !(flags & MN_TRAIN_UNGROUPED) && n_part % 8 == 0 ? 1 : 0;
-        // grouped: only as many reduction + Adam blocks as find a CU while the local workgroups run (those the target workgroups vacate + those never used),
-        // each running up to two of the N_ADAM virtual blocks -- a block dispatched behind the local workgroups starts ~2 us late and everybody's Adam waits
-        // for its norm partials; ungrouped: all N_ADAM
-        p.n_tail = p.hier ? std::max((N_ADAM + 1) / 2, std::min(N_ADAM, d.n_cu - n_part)) : N_ADAM;
-        // ... and so has every reduction + Adam block once those are done (they wait for each other's norm partials)
-        if (p.n_tail <= d.n_cu) { p.launches = 1; return p; }
+    if ((flags & MN_TRAIN_ONE_LAUNCH) && p.mode == MODE_TWO_ROLES && n_part % 8 == 0) {
+        // The fused step: the target workgroups are the reduction + Adam blocks (two virtual blocks each; small batches add blocks that do nothing else).  Its
+        // workgroups wait for each other -- local ones for their XCD group's rows, reduction + Adam blocks for each other's norm partials, in a multi-step
+        // launch everybody for everybody -- so ALL of them must be resident together: one CU each (97 KB of LDS, 226 registers).
+        p.n_extra = std::max(0, (N_ADAM + 1) / 2 - n_part);
+        if (p.n_fwd + p.n_extra <= d.n_cu) { p.launches = 1; return p; }
     }
-    p.hier = p.n_tail = 0;
+    p.n_extra = 0;
     if (N_ADAM <= d.n_cu * (xchg ? d.rax_per_cu : d.ra_per_cu)) { p.launches = 2; return p; }      // all 140 blocks of the fused reduction + Adam launch resident
     p.launches = xchg ? 4 : 3;
     return p;
@@ -2068,10 +2167,11 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
                        const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev, const float *taus_target_dev,
                        const float *taus_local_dev, const float *params_local, const float *params_target, float *workspace,
                        float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma, uint64_t *rng_state_dev,
-                       int64_t ring_size, int64_t *idx_out, float *taus_out, int32_t flags, void *stream, const AdamArgs *adam = nullptr) {
+                       int64_t ring_size, int64_t *idx_out, float *taus_out, int32_t flags, void *stream, const AdamArgs *adam = nullptr, int n_steps = 1) {
     if (!ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones || !params_local || !params_target ||
         !workspace || !grad_out || !loss_out)
         return MN_ERR_INVALID;
+    if (n_steps < 1 || (n_steps > 1 && (!adam || !rng_state_dev))) return MN_ERR_INVALID;      // several steps: whole steps, batches drawn in the launch
     if (rng_state_dev ? (ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
         return MN_ERR_INVALID;
     if (batch <= 0 || batch > MAX_BATCH || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
@@ -2088,19 +2188,28 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     hipStream_t s = (hipStream_t)stream;
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
-    if (plan.launches == 1) {      // the reduction + clip + Adam blocks ride in the same launch as a third role
-        StepTail tail = {plan.n_tail, N_ADAM, plan.hier, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
-                         rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
+    if (plan.launches == 1) {      // the fused step: ONE launch for all n_steps
+        const StepTail tail = {N_ADAM, plan.n_extra, n_steps, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
+                               rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
         if (x)
-            hipLaunchKernelGGL(iqn_train_fwdbwd<true>, dim3(plan.n_fwd + plan.n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+            hipLaunchKernelGGL((iqn_train_fwdbwd<true, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
                                plan.mode, use_staged, tail);
         else
-            hipLaunchKernelGGL(iqn_train_fwdbwd<false>, dim3(plan.n_fwd + plan.n_tail), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
+            hipLaunchKernelGGL((iqn_train_fwdbwd<false, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
                                plan.mode, use_staged, tail);
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
+    if (n_steps > 1) {      // no fused form for this batch / device: the steps one after the other (every later one starts from the batch its predecessor staged)
+        for (int k = 0; k < n_steps; ++k) {
+            const int f = k == 0 ? flags : ((flags | MN_TRAIN_USE_STAGED) & (prefetch_next ? ~0 : ~MN_TRAIN_USE_STAGED));
+            if (int rc = launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev, params_local, params_target,
+                                     workspace, grad_out, loss_out + k, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, f, stream, adam, 1))
+                return rc;
+        }
+        return MN_OK;
+    }
     const StepTail no_tail = {};
-    hipLaunchKernelGGL(iqn_train_fwdbwd<false>, dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
+    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
                        params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail);
     if (plan.launches == 2 && x)
         hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
@@ -2131,9 +2240,9 @@ extern "C" int mn_iqn_train_set_cu_limit(int32_t n_cu) {
 // Launches one gradient step takes on the current device: 1 (reduction + Adam ride in the forward / backward launch), 2, 3 (a device on which the 140 blocks of
 // the fused reduction + Adam launch are not resident together), 4 (the same for a shared learner's exchange); < 0: error.  `exchange` != 0: a shared learner's step.
 extern "C" int mn_iqn_train_plan(int32_t batch, int32_t flags, int32_t exchange) {
-    if (batch <= 0 || batch > MAX_BATCH || batch % BE) return -MN_ERR_INVALID;
+    if (batch <= 0 || batch > MAX_BATCH || batch % BE) return MN_ERR_INVALID;      // (error codes are negative)
     DevInfo dev;
-    if (int rc = dev_info(&dev)) return -rc;
+    if (int rc = dev_info(&dev)) return rc;
     return plan_launch(dev, batch, flags, true, exchange != 0).launches;
 }
 
@@ -2152,6 +2261,32 @@ extern "C" int mn_iqn_train_step(const float *ring_states, const float *ring_nex
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
                        rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
                        grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags, stream, &adam);
+}
+
+// n_steps gradient steps of a single learner, batches drawn in the launch -- ONE launch where the fused step exists (batch a multiple of 16, every workgroup a CU of
+// its own: batch <= 256 on an MI355X), else n_steps x mn_iqn_train_step.  Step k's loss -> losses_out[k].  Bit-identical to n_steps calls of mn_iqn_train_step
+// (with MN_TRAIN_STAGE_NEXT / MN_TRAIN_USE_STAGED as the caller would pass them: `flags` describe the FIRST step; later ones need no staging).
+extern "C" int mn_iqn_train_steps(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
+                                  const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                                  const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
+                                  int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1, double beta2,
+                                  double eps, double max_norm, void *stream) {
+    if (!rng_state_dev || !params_local || !exp_avg || !exp_avg_sq || !step_dev || n_steps < 1) return MN_ERR_INVALID;
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, nullptr, 1.0f};
+    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local, params_target, workspace,
+                       grad_out, losses_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags | MN_TRAIN_ONE_LAUNCH, stream, &adam, n_steps);
+}
+
+// ... and of a SHARED learner (the exchange inside every step's reduction + Adam role; all ranks call with the same n_steps)
+extern "C" int mn_iqn_train_steps_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
+                                       const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                                       const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
+                                       int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1,
+                                       double beta2, double eps, double max_norm, float grad_scale, void *stream) {
+    if (!x || !rng_state_dev || !params_local || !exp_avg || !exp_avg_sq || !step_dev || n_steps < 1 || !(grad_scale > 0.f)) return MN_ERR_INVALID;
+    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, x, grad_scale};
+    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local, params_target, workspace,
+                       grad_out, losses_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags | MN_TRAIN_ONE_LAUNCH, stream, &adam, n_steps);
 }
 
 extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,

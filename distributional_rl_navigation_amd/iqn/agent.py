@@ -51,6 +51,7 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
         self.shared_taus = False                     # opt-in: one set of 32 taus per act LAUNCH instead of per row (fused_act(shared_taus=True))
         self.use_fused_graph = False                 # opt-in: the fused gradient steps of one training event as one captured hipGraph (train_steps_from_memory)
+        self.use_multi_step = True                   # the gradient steps of one training event as ONE persistent launch (mn_iqn_train_steps; bit-identical to the eager steps)
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
@@ -242,6 +243,14 @@ class IQNAgent(ReferenceLoopMixin):
             loss = ft.graphed_steps((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, n_steps)
             self.grad_steps += n_steps
             return loss
+        if (self.use_multi_step and self.use_fused_train and self.device.type == "cuda" and n_steps > 1 and len(self.memory) >= self.BATCH_SIZE):
+            ft = self._fused_trainer()
+            if ft._two_launches():      # (an RCCL shared learner has its collective between the gradient and Adam: single steps)
+                m = self.memory
+                self._enter_train_path("hip")
+                loss = ft.steps_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, n_steps, m.version)
+                self.grad_steps += n_steps
+                return loss
         loss = None
         for _ in range(n_steps):
             loss = self.train_from_memory()

@@ -55,6 +55,9 @@ class VecMarineNavEnv:
             raise _capi.MarineNavHipError("VecMarineNavEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.L = _capi.lib()
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _capi.MarineNavHipError(f"VecMarineNavEnv(device={device!r}): the env kernels are HIP kernels for gfx950 -- there is no CPU path (the reference's "
+                                          "`-D cpu` has no counterpart here; the CPU restatement under oracle/ is test infrastructure)")
         torch.cuda.set_device(self.device)
         self.n_envs = int(n_envs)
         self.params = params if params is not None else _capi.default_params()

@@ -98,11 +98,15 @@ def plan_cadence(total_timesteps, eval_freq, n_envs_total, batch, ref_batch=32, 
 
 
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
-              grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0, precision="f64"):
+              grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0, precision="f64",
+              exchange="collective", shared_taus=False):
     """train_IQN_model.py:74-121 on the vector env.  `params` is one trial of the reference's config grid
     (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps.
     `precision`: the env kernels' arithmetic.  "f64" (default: every float32 output within 1e-5 of the reference, no
-    outliers; measured free while an IQN acts in the loop) or "mixed" (float32 field / sonar decisions)."""
+    outliers; measured free while an IQN acts in the loop) or "mixed" (float32 field / sonar decisions).
+    `exchange` (shared learner): "collective" = RCCL all-reduce of the flat gradient, "mailbox" = the exchange inside the gradient step's launch (iqn/mailbox.py).
+    `shared_taus`: acting draws its 32 quantile fractions once per act launch instead of once per env (opt-in: a different random variable from the
+    reference's per-call draw, model.py:149; A/B on learning in profiles/; the learner's taus are untouched)."""
     import torch
     from .iqn.agent import IQNAgent
     from .marinenav_env.vec_env import VecMarineNavEnv
@@ -143,6 +147,8 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
                      UPDATE_EVERY=1, learning_starts=0, rank=rank if shared else 0)
     agent.grad_steps_per_update = plan["grad_steps_per_vector_step"]
     agent.target_sync_grad_steps = plan["target_sync_grad_steps"]
+    agent.exchange = exchange
+    agent.shared_taus = bool(shared_taus)
     if torch_train:
         agent.use_fused_train = False          # PyTorch autograd + Adam instead of csrc/iqn_train.hip
     agent.learn_vec(total_vector_steps=plan["vector_steps"], train_env=train_env, eval_env=eval_env, eval_config=eval_config,
@@ -194,13 +200,19 @@ def main(argv=None):
     ap.add_argument("--torch-train", action="store_true", help="gradient step through PyTorch instead of the fused HIP kernels")
     ap.add_argument("--precision", default="f64", choices=["f64", "mixed"],
                     help="env kernels: f64 (default; strict 1e-5 parity, free next to the IQN act kernel) or mixed")
+    ap.add_argument("--exchange", default="collective", choices=["collective", "mailbox"],
+                    help="with --shared-learner: how the ranks' gradients meet -- one RCCL all-reduce per gradient step, or the exchange inside the step's own launch")
+    ap.add_argument("--shared-taus", action="store_true", help="acting: one set of 32 taus per act launch instead of per env (opt-in, ~11 %% shorter runs)")
     args = ap.parse_args(argv)
     params = json.load(args.config_file)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = args.device or f"cuda:{local}"
-    torch.cuda.set_device(torch.device(device))
+    # the reference's -D takes "cpu" / "cuda" (train_IQN_model.py:33-40); here: "cuda" = this rank's GPU, "cuda:K" = that GPU, anything else is refused
+    # by the package itself (no CPU path: VecMarineNavEnv raises)
+    device = f"cuda:{local}" if args.device in (None, "cuda") else args.device
+    if torch.device(device).type == "cuda":
+        torch.cuda.set_device(torch.device(device))
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
@@ -209,7 +221,8 @@ def main(argv=None):
     for p in trials:
         p["training_time"] = stamp
     kw = dict(batch=args.batch, replay=args.replay, grad_steps=args.grad_steps, torch_train=args.torch_train,
-              total_grad_steps=args.total_grad_steps, n_evals=args.n_evals, cvar=args.cvar, precision=args.precision)
+              total_grad_steps=args.total_grad_steps, n_evals=args.n_evals, cvar=args.cvar, precision=args.precision,
+              exchange=args.exchange, shared_taus=args.shared_taus)
     if args.num_procs > 1:
         # train_IQN_model.py:173-179: a Pool of workers, one trial each.  `spawn`: every worker gets its own HIP context
         if world > 1:

@@ -383,11 +383,12 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * batch must be even and <= 1024, num_taus must be 8.  Exact float32 (v_mfma_f32_16x16x4_f32). */
 /* The whole gradient step of a single learner -- IQNAgent.train (agent.py:269-304) incl. clip_grad_norm_ and optimizer.step() -- as TWO
  * launches: forward / backward, then a launch in which every block reduces the partial gradients of its own 256 parameters, exchanges the norm
- * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4) -- or, with MN_TRAIN_ONE_LAUNCH in `flags` (batch <= 512: every forward / backward workgroup needs a CU of its own;
- * larger batches take two launches), as ONE launch: those blocks are a third workgroup role of the forward / backward launch, dispatched behind its
- * workgroups.  By default XCD-grouped: the partial-gradient rows of the workgroups that share an XCD (block index mod 8: the dispatcher deals
- * workgroups out round-robin) are summed inside that XCD's L2 and only the eight group rows cross to the other XCDs, as self-tagged granules the
- * reduction blocks poll; MN_TRAIN_UNGROUPED (and every batch whose half is not a multiple of 8) sends every row through memory instead.  All forms
+ * partials with the other blocks as self-tagged granules and applies clip + Adam (round 4) -- or, with MN_TRAIN_ONE_LAUNCH in `flags`, as ONE launch (the FUSED
+ * step; batch a multiple of 16 and every workgroup a CU of its own: batch <= 256 on an MI355X; else two launches): the target workgroups of the forward /
+ * backward launch are also its reduction + Adam blocks.  XCD-grouped: the partial-gradient rows of the workgroups that share an XCD (block index mod 8: the
+ * dispatcher deals workgroups out round-robin) are summed inside that XCD's L2 and only the eight group rows cross to the other XCDs, as self-tagged granules the
+ * reduction blocks poll.  mn_iqn_train_steps: n_steps such steps in ONE persistent launch (round 5) -- step k + 1 starts when the reduction + Adam blocks have
+ * written step k's parameters; losses_out [n_steps].  All forms
  * are bit-identical.  rng_state_dev != NULL: the batch is drawn in the
  * launch (arguments as mn_iqn_train_grad_sampled; idx_dev / taus_*_dev ignored); NULL: the given batch (as mn_iqn_train_grad).  params_local is
  * updated in place, grad_out receives the clipped gradient.  Bit-identical to mn_iqn_train_grad* + mn_iqn_train_adam(grad_scale = 1): those stay
@@ -397,6 +398,11 @@ int mn_iqn_train_step(const float *ring_states, const float *ring_next_states, c
                       const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local, const float *params_target,
                       float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, int32_t batch,
                       int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
+int mn_iqn_train_steps(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
+                       const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                       const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
+                       int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1, double beta2,
+                       double eps, double max_norm, void *stream);
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
 /* Diagnostic: float index inside the workspace of a u32 counter -- local workgroups of one-launch steps that did not run on the XCD of the first
  * workgroup of their group (block index % 8) since mn_iqn_train_workspace_init (their partial-gradient rows go through memory instead of staying in the
@@ -467,6 +473,12 @@ int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ri
                            const float *params_target, float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq,
                            int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                            double eps, double max_norm, float grad_scale, void *stream);
+/* ... n_steps of them in one persistent launch (all ranks call with the same n_steps); arguments as mn_iqn_train_steps */
+int mn_iqn_train_steps_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
+                            const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
+                            const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
+                            int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1,
+                            double beta2, double eps, double max_norm, float grad_scale, void *stream);
 int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
 int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
@@ -494,9 +506,7 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
  * if the ring was not written since the staging call (then the step is bit-identical to the unstaged one). */
 #define MN_TRAIN_USE_STAGED 1
 #define MN_TRAIN_STAGE_NEXT 2
-#define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step only: the reduction + clip + Adam blocks ride in the forward / backward launch (third role) */
-#define MN_TRAIN_UNGROUPED 8       /* with MN_TRAIN_ONE_LAUNCH: every partial-gradient row goes through to memory (the form before the XCD-grouped one; batches whose
-                                    * half is not a multiple of 8 always use it).  Default: the rows of the workgroups of one XCD are summed inside that XCD's L2 */
+#define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step[_xchg]: the fused step -- reduction + clip + Adam inside the forward / backward launch (mn_iqn_train_steps* imply it) */
 #define MN_TRAIN_TEST_MISPLACE(k) ((k) << 4)   /* test hook, k = 1..3, with MN_TRAIN_ONE_LAUNCH: treat some workgroups as if they had landed on another XCD */
 int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                               const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,

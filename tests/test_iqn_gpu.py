@@ -291,11 +291,11 @@ def test_iqn_c_abi_argument_checks(torch):
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
     L = _capi.lib()
-    # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
-    # staging tag / magic word + the staged next batch (256 slots of 72 floats)
-    # + the 280 tagged norm partials of the two-launch step; in brackets the one-launch step's 128 8-byte row-complete words, 128 row-complete words of its ungrouped
-    # form, 8 x 64 XCD-local row-complete words, 128 tagged loss partials, 128 "which XCD" words and the eight XCD group rows as 8-byte granules
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 12 + 2 * 280 + (2 * 128 + 128 + 512 + 2 * 128 + 2 * 128 + 16 * 35788) + 256 * 72
+    # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + two sets (step parity) of 128 x 16 8-byte hand-off granules + epoch / tickets /
+    # staging tag / magic word / status word (16 words) + the 280 tagged norm partials of the fused reduction + Adam launch; in brackets the fused step's 128 8-byte
+    # row-complete words, the 128 buddy words, 8 x 64 XCD-local row-complete words, 128 tagged loss partials, 128 "which XCD" words, the eight XCD group rows as 8-byte
+    # granules and the 256 "parameters ready" words of a multi-step launch; + the staged next batch (256 slots of 72 floats)
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * (2 * 128 * 16) + 16 + 2 * 280 + (2 * 128 + 128 + 512 + 2 * 128 + 2 * 128 + 16 * 35788 + 2 * 256) + 256 * 72
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -587,18 +587,18 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
     backward launch itself (MN_TRAIN_ONE_LAUNCH: one launch per step) -- against `mn_iqn_train_grad*` + `mn_iqn_train_adam` (three launches):
     losses, clipped gradients, parameters, moments, Adam step, generator state bit-identical over sampled steps (staged batches incl.), a ring
     write in between, given-batch steps with injected taus (batch 64: 32 rows, 4 per XCD group), a captured 8-step hipGraph, and in the local-only
-    workgroup mode.  The one-launch step in its XCD-grouped form (default), ungrouped (every row through memory), and grouped with workgroups that
+    workgroup mode (in which the fused step does not exist: the library takes two launches).  The fused step also with workgroups that
     pretend to have landed on another XCD (every fifth / all / all of one group: their rows go through memory, they take no share of the group sum)."""
     from distributional_rl_navigation_amd import _capi
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev = "cuda:0"
     runs = []
-    # (two launches, one launch, ungrouped rows, pretended XCD misplacement 0..3, local-only workgroup mode)
-    cases = ((True, True, False, 0, 0), (True, False, False, 0, 0), (False, False, False, 0, 0), (True, True, False, 0, 1), (True, True, True, 0, 0),
-             (True, True, False, 1, 0), (True, True, False, 2, 0), (True, True, False, 3, 1))
-    for two, one, ungrouped, misplace, mode in cases:
+    # (whole step in the library, fused step asked for, pretended XCD misplacement 0..3, local-only workgroup mode)
+    cases = ((True, True, 0, 0), (True, False, 0, 0), (False, False, 0, 0), (True, True, 0, 1), (True, True, 1, 0), (True, True, 2, 0), (True, True, 3, 0))
+    for two, one, misplace, mode in cases:
         ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
-        ag.two_launch_step, ag.one_launch_step, ag.one_launch_ungrouped, ag._test_misplace = two, one, ungrouped, misplace
+        ag.two_launch_step, ag.one_launch_step, ag._test_misplace = two, one, misplace
+        ag.use_multi_step = False      # (this test: single steps; multi-step launches have their own)
         _capi.lib().mn_iqn_train_set_mode(mode)      # 1: every workgroup computes its own TD targets, no target role in the launch
         g = torch.Generator(device=dev); g.manual_seed(5)
         ag.memory.add_batch(*_random_batch(torch, 2048, g))
@@ -613,7 +613,8 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
         losses.append(float(ag.train_steps_from_memory(8)))
         losses.append(float(ag.train_steps_from_memory(8)))
         ft = ag._fused
-        assert ft._two_launches() == two
+        assert ft._two_launches() == two and ft.timeouts() == 0
+        assert ft.launches_per_step(256) == (3 if not two else (1 if one and mode == 0 else 2))
         runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone(), ag.grad_steps))
     _capi.lib().mn_iqn_train_set_mode(0)
     ref = runs[2]      # three launches
@@ -656,13 +657,53 @@ def test_launch_plan_follows_the_device_size_and_small_devices_fall_back_bitwise
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("batch,misplace", [(256, 0), (256, 1), (256, 3), (32, 0), (64, 2), (128, 0), (100, 0), (512, 0)])
+def test_multi_step_launch_equals_single_steps_bitwise(torch, batch, misplace):
+    """`mn_iqn_train_steps` (round 5): the G gradient steps of a training event as ONE persistent launch -- target workgroups that are also the reduction + Adam
+    blocks, step k + 1 starting when step k's parameters are written (through, behind a drained flag) and reading its batch straight from the ring, TD targets one
+    step ahead in two sets of granules -- against G single fused steps and against the three-launch path: every step's loss, the parameters, both moments, the
+    last clipped gradient, the Adam step and the generator state bit-identical, over events of 16 / 5 / 1 / 16 steps with ring writes in between (so that staged
+    first batches are used and refused), at batch 256 (also with workgroups pretending to sit on another XCD), 32 / 64 / 128 (extra reduction + Adam workgroups)
+    and 100 / 512 (no fused form: the library runs the steps one after the other).  No bounded wait ran out."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    runs = []
+    for form in ("multi", "single", "three"):
+        ag = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=2048, device=dev, seed=11)
+        ag.use_multi_step, ag.two_launch_step, ag.one_launch_step, ag._test_misplace = form == "multi", form != "three", True, misplace
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        ag.memory.add_batch(*_random_batch(torch, 2048, g))
+        losses = []
+        for ev, G in enumerate((16, 16, 5, 1, 16, 3)):
+            if ev in (2, 4):
+                ag.memory.add_batch(*_random_batch(torch, 300, g))      # the ring moves: the batch the previous event staged must not be used
+            last = float(ag.train_steps_from_memory(G))
+            ft = ag._fused
+            if form == "multi" and G > 1:
+                ls = [float(x) for x in ft.losses[:G]]
+                assert ls[-1] == last
+                losses += ls
+            else:
+                losses.append(last)
+        assert ft.timeouts() == 0 and ft.xcd_misplaced(batch) == (0 if misplace == 0 or form == "three" else ft.xcd_misplaced(batch))
+        runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone(), ag.grad_steps))
+    multi, single, three = runs
+    assert all(np.isfinite(multi[0])) and len(multi[0]) == 16 + 16 + 5 + 1 + 16 + 3
+    # the single-step runs report the last loss of every event: the events' ends within the multi-step run's list
+    ends = np.cumsum([16, 16, 5, 1, 16, 3]) - 1
+    assert [multi[0][e] for e in ends] == single[0] == three[0]
+    for r in (single, three):
+        for x, y in zip(multi[1:5], r[1:5]):
+            assert torch.equal(x, y)
+        assert multi[5] == r[5] == 57 and torch.equal(multi[6], r[6]) and multi[7] == r[7] == 57
+
+
 @pytest.mark.parametrize("batch", [16, 48, 100, 128, 384, 512, 1024])
 def test_one_launch_step_at_other_batch_sizes(torch, batch):
-    """The one-launch step away from batch 256: 16 (one row per XCD group), 48 (three), 128 (eight; every reduction + Adam block finds a CU at once), 100 (its half
-    is no multiple of 8: the ungrouped form), 384 / 512 (every workgroup computes its own TD targets; 24 / 32 rows per group, 70 reduction + Adam blocks that
-    run two virtual blocks each and stage the next batch in several passes; at 512 they only find a CU once local workgroups end), 1024 (more forward /
-    backward workgroups than CUs: mn_iqn_train_step falls back to two launches) -- bit-identical to the three-launch path over sampled steps incl. staged
-    batches, and no workgroup away from its group's XCD."""
+    """The fused step away from batch 256: 16 (one row per XCD group; 62 workgroups that only run reduction + Adam blocks behind the 16 forward / backward ones),
+    48 (three rows per group), 128 (eight; the 64 target workgroups run two reduction + Adam blocks each and 6 extra workgroups the rest), and the batches for
+    which the library takes two launches -- 100 (its half is no multiple of 8), 384 / 512 / 1024 (more workgroups than CUs) -- bit-identical to the three-launch
+    path over sampled steps incl. staged batches, and no workgroup away from its group's XCD."""
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev = "cuda:0"
     runs = []
@@ -674,7 +715,8 @@ def test_one_launch_step_at_other_batch_sizes(torch, batch):
         losses = [float(ag.train_from_memory()) for _ in range(10)]
         ft = ag._fused
         if one:
-            assert ft.xcd_misplaced(batch) == 0
+            assert ft.xcd_misplaced(batch) == 0 and ft.timeouts() == 0
+            assert ft.launches_per_step(batch) == (1 if batch in (16, 48, 128) else 2)
         runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone()))
     a, b = runs
     assert all(np.isfinite(a[0])) and a[0] == b[0] and a[4] == b[4] == 10
