@@ -555,8 +555,9 @@ constexpr int RED_SEG = MN_RED_SEG;                            // partial-sum se
 __host__ __device__ constexpr int64_t pad4(int64_t x) { return (x + 3) / 4 * 4; }
 __host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_part * P_PAD; }
 __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
-__host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }
-__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 4 * (int64_t)n_part * ROWS; }      // (two sets of TD-target granules, by step parity)
+__host__ __device__ constexpr int64_t ws_tdq(int n_part) { return (ws_sq(n_part) + pad4(N_RED) + 31) / 32 * 32; }      // 128-byte aligned: a part's 16 granules are one cache line
+constexpr int MN_TD_SLOTS = 2;      // sets of TD-target granules, by step parity
+__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * MN_TD_SLOTS * (int64_t)n_part * ROWS; }      // (two sets of TD-target granules, by step parity)
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
 // [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] count of local workgroups of
 // XCD-grouped one-launch steps that did not run on the XCD of their group's first workgroup (u32, diagnostic: their rows took the slow way through memory),
@@ -706,14 +707,16 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     __shared__ float gsh[VPB][4 * RA_COLS];
     __shared__ float nred[4];
     __shared__ float s_bc[2];
-    const int tid = tid_now(), cx = tid % RA_COLS, seg = tid / RA_COLS;
+    // (seg = the wavefront's index: said so explicitly -- behind tid_now() the compiler no longer knows that it is wave-uniform, built the group row's buffer descriptor per
+    // lane and wrapped every granule load in a waterfall loop)
+    const int tid = tid_now(), cx = tid % RA_COLS, seg = __builtin_amdgcn_readfirstlane(tid / RA_COLS);
     const int vb = pb;      // (block 0 = virtual block 0: the loss; PH3 stamps)
     int vbs[VPB], col[VPB], p[VPB];
     bool on[VPB];
 #pragma unroll
     for (int j = 0; j < VPB; ++j) {
         vbs[j] = pb + j * n_phys;
-        on[j] = vbs[j] < nvb;
+        on[j] = vbs[j] < nvb;      // (block-uniform; see the norm-partial store below for what hipcc does with it)
         col[j] = vbs[j] * RA_COLS + cx;
         p[j] = vbs[j] * 256 + tid;
     }
@@ -931,6 +934,11 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
 #pragma unroll
         for (int j = 0; j < VPB; ++j) {
             if (!on[j]) continue;
+            // ... and by the index itself: `on[j]` alone is NOT safe here.  hipcc keeps it as a lane mask, re-forms its negation inside the divergent granule poll above (under
+            // that loop's EXEC: v_cmp_ne of a v_cndmask of the mask) and uses THAT register for this test -- lanes 0 / 32 that left the poll before its last iteration
+            // read 0 = "on" (ROCm 7.2; found in round 5 with a sentinel region: the store then zeroed the TD-target granules that follow the norm partials in the
+            // workspace, which only a multi-step launch ever reads again).  A scalar compare of the index cannot be merged with that mask.
+            if (2 * vbs[j] + 1 >= N_RED) continue;
             float t = 0.f;
             for (int k = 0; k < RED_COLS; ++k) t += sq[j][tid + k];
             ws[ws_sq(n_part) + 2 * vbs[j] + (tid >> 5)] = t;      // (also where the three-launch path keeps them)
@@ -1219,51 +1227,83 @@ struct StepTail {
 // XCHG: the instantiation whose reduction + Adam role carries the shared learner's exchange; the single learner's kernel is compiled without that code (its
 // mailbox pointers cost 75 more spilled scalar registers in a kernel that has none to spare).  FUSED: the fused step above; false = forward / backward only
 // (two- and three-launch forms; `tail` unused): one step, ordinary parameter loads.
+// The kernel's arguments as ONE struct: the fused kernel re-reads them from the kernarg segment in every step of its loop (through a pointer the optimiser cannot see
+// through) instead of holding ~90 loop-invariant scalar registers across the whole body -- with those held, hipcc spilled 350-420 scalar registers into vector-register
+// lanes and 80-1 100 bytes per lane to scratch, and values restored from those spills were sporadically WRONG (a reduction block's `on[1]` came back true: its norm-partial
+// store then zeroed other workgroups' TD-target granules; round 5, found with a sentinel region).  No scratch, few spills: what the kernel is built to.
+struct TrainArgs {
+    BatchArgs ba;
+    const float *PL, *PT;
+    float *ws;
+    int batch;
+    float gamma;
+    int mode, use_staged;
+    StepTail tail;
+};
+typedef const __attribute__((address_space(4))) TrainArgs *TrainArgsK;
+// (field by field: a struct in the constant address space cannot be copied as a whole)
+__device__ __forceinline__ BatchArgs ld_batch_args(TrainArgsK A) {
+    return BatchArgs{A->ba.ring_s, A->ba.ring_ns, A->ba.ring_r, A->ba.ring_d, A->ba.ring_a, A->ba.idx, A->ba.taus_t, A->ba.taus_l, A->ba.rng_state, A->ba.ring_n,
+                     A->ba.idx_out, A->ba.taus_out};
+}
+__device__ __forceinline__ StepTail ld_step_tail(TrainArgsK A) {
+    return StepTail{A->tail.n_virtual, A->tail.n_extra, A->tail.n_steps, A->tail.misplace, A->tail.prefetch_next, A->tail.grad, A->tail.loss_out, A->tail.params, A->tail.m,
+                    A->tail.v, A->tail.step, A->tail.rng_state, A->tail.lr, A->tail.b1, A->tail.b2, A->tail.eps, A->tail.max_norm, A->tail.xa, A->tail.xa_scale};
+}
+
 template <bool XCHG, bool FUSED>
-__global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const float *__restrict__ PL, const float *__restrict__ PT,
-                                                            float *__restrict__ ws, int batch, float gamma, int mode, int use_staged, StepTail tail) {
+__global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args) {
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
     __shared__ int s_got;
+    const int G = FUSED ? args.tail.n_steps : 1;
+    // ---- the counters this launch starts from; nothing in memory moves before its last step's reduction + Adam blocks have all taken their ticket
+    uint64_t epoch0, rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;      // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
+    int32_t step0 = 0;
+    {
+        const int n_part = args.batch / BE;
+        epoch0 = *reinterpret_cast<const uint64_t *>(args.ws + ws_epoch(n_part));
+        if (args.ba.rng_state) {
+            const uint64_t *stg_tag = reinterpret_cast<const uint64_t *>(args.ws + ws_epoch(n_part) + 4);
+            rs0 = args.ba.rng_state[0]; rs1 = args.ba.rng_state[1];
+            tg0 = stg_tag[0]; tg1 = stg_tag[1];
+        }
+        if (FUSED) step0 = *args.tail.step;
+    }
+#ifdef MN_TRAIN_PHASES
+    if (tid_now() == 0) g_wgt[blockIdx.x][0] = wall_clock64();
+#endif
+
+    // Iteration k: target workgroups run the target forward pass of step k, then the reduction + Adam work of step k - 1; local workgroups run step k.
+    for (int k = 0; k <= G; ++k) {
+    // (One step's scalar and address arithmetic must not be hoisted out of the loop -- hundreds of values would then live across the whole body: the thread index is
+    // opaque at every use (tid_now), the block index and the kernel arguments -- re-read from the kernarg segment -- are made opaque per iteration, and everything
+    // derived from them, the workgroup's role included, is derived again.)
     const int tid = tid_now();
+    TrainArgsK A = (TrainArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    int bid = blockIdx.x;
+    if (FUSED) asm volatile("" : "+s"(A), "+s"(bid));
+    const BatchArgs ba = FUSED ? ld_batch_args(A) : args.ba;
+    const StepTail tail = FUSED ? ld_step_tail(A) : args.tail;
+    float *const ws = FUSED ? A->ws : args.ws;
+    const float *const PL = FUSED ? A->PL : args.PL, *const PT = FUSED ? A->PT : args.PT;
+    const int batch = FUSED ? A->batch : args.batch, mode = FUSED ? A->mode : args.mode;
     const int n_part = batch / BE;
     const bool two_roles = mode == MODE_TWO_ROLES;      // (FUSED: always)
     const int n_fwd = two_roles ? 2 * n_part : n_part;
-    const int G = FUSED ? tail.n_steps : 1;
-    const bool is_extra = FUSED && (int)blockIdx.x >= n_fwd;            // reduction + Adam blocks only
-    const bool is_target = two_roles && (int)blockIdx.x < n_part;       // target workgroups come FIRST in dispatch order: nothing they need is produced by a local workgroup
-    const int part = is_extra ? 0 : (two_roles && !is_target ? blockIdx.x - n_part : blockIdx.x);
+    const bool is_extra = FUSED && bid >= n_fwd;            // reduction + Adam blocks only
+    const bool is_target = two_roles && bid < n_part;       // target workgroups come FIRST in dispatch order: nothing they need is produced by a local workgroup
+    const int part = is_extra ? 0 : (two_roles && !is_target ? bid - n_part : bid);
     const int b0 = part * BE;
-    const int pb = is_extra ? n_part + ((int)blockIdx.x - n_fwd) : (int)blockIdx.x, n_phys = n_part + tail.n_extra;      // reduction + Adam role: physical block pb of n_phys
+    const int pb = is_extra ? n_part + (bid - n_fwd) : bid, n_phys = n_part + tail.n_extra;      // reduction + Adam role: physical block pb of n_phys
 #ifdef MN_TRAIN_PHASES
     const int ph_local = two_roles ? n_part : 0;
-    if (tid_now() == 0) g_wgt[blockIdx.x][0] = wall_clock64();
 #else
     const int ph_local = -1;
 #endif
     PH(0);
-    // ---- the counters this launch starts from; nothing in memory moves before its last step's reduction + Adam blocks have all taken their ticket
-    const uint64_t epoch0 = *reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part));
-    uint64_t rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;      // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
-    if (ba.rng_state) {
-        const uint64_t *stg_tag = reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part) + 4);
-        rs0 = ba.rng_state[0]; rs1 = ba.rng_state[1];
-        tg0 = stg_tag[0]; tg1 = stg_tag[1];
-    }
-    int32_t step0 = 0;
-    if (FUSED && (is_target || is_extra)) step0 = *tail.step;
-
-    // Iteration k: target workgroups run the target forward pass of step k, then the reduction + Adam work of step k - 1; local workgroups run step k.
-    const int tid_launch = tid;
-    float *const ws_launch = ws;
-    const float *const PL_launch = PL, *const PT_launch = PT;
-    for (int k = 0; k <= G; ++k) {
-    // (One step's address arithmetic must not be hoisted out of the loop -- hundreds of values would then live across the whole body, 1 KB of scratch per lane: the
-    // thread index and the base pointers are made opaque per iteration, and everything derived from them is derived again.)
-    int tid = tid_launch;
-    float *ws = ws_launch;
-    const float *PL = PL_launch, *PT = PT_launch;
-    if (FUSED) asm volatile("" : "+v"(tid), "+s"(ws), "+s"(PL), "+s"(PT));
+    const float gamma = FUSED ? A->gamma : args.gamma;
+    const int use_staged = FUSED ? A->use_staged : args.use_staged;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     const ParamView<FUSED> VL(PL);
     const float *stage = ws + ws_stage(n_part);
@@ -1273,7 +1313,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     if (k < G && !is_extra) {
     // hand-off tag of this step: never 0 (the workspace starts zero-filled), different from the neighbouring steps' and launches' tags
     const uint32_t tag = (uint32_t)((epoch0 + (uint64_t)k) % 0xFFFFFFFFull) + 1u;
-    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + ((size_t)(k & 1) * n_part + part) * ROWS;
+    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + ((size_t)(k % MN_TD_SLOTS) * n_part + part) * ROWS;
     if (FUSED && !is_target && tid == 0) {      // where this local workgroup runs (see "local workgroup" below)
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1393,7 +1433,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             __hip_atomic_store(granules + tid, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PH(7);   /* granules published */
-        if (blockIdx.x == 0 && k == G - 1) write_batch_copies(ba, base, batch);
+        if (bid == 0 && k == G - 1) write_batch_copies(ba, base, batch);
 #ifdef MN_TRAIN_PHASES
         if (tid_now() == 0) g_wgt[blockIdx.x][1] = wall_clock64();
 #endif
@@ -1432,6 +1472,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
             const bool all_ok = __all(ok);
             if (all_ok && lane < ROWS) S[S_QT + lane] = v;
             if (lane == 0) s_got = all_ok ? 1 : 0;
+            if (!all_ok && lane == 0) atomicAdd(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 13), 1u);      // (diagnostic: TD targets computed here after a wait in vain)
         }
         __syncthreads();
     }
@@ -1645,7 +1686,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(BatchArgs ba, const 
     }
     if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
-    if (!two_roles && blockIdx.x == 0) write_batch_copies(ba, base, batch);
+    if (!two_roles && bid == 0) write_batch_copies(ba, base, batch);
     if (FUSED) {      // this workgroup's row (and loss partial) is final
         // Its stores are acknowledged -- by memory if they were write-through ones, by this XCD's L2 otherwise -- once vmcnt is 0; nothing of a
         // written-through row sits dirty in an L2: no __threadfence() (= an L2 write-back per workgroup, which made the first one-launch form 2.5 x slower)
@@ -2192,11 +2233,11 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
         const StepTail tail = {N_ADAM, plan.n_extra, n_steps, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
                                rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
         if (x)
-            hipLaunchKernelGGL((iqn_train_fwdbwd<true, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
-                               plan.mode, use_staged, tail);
+            hipLaunchKernelGGL((iqn_train_fwdbwd<true, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s,
+                               TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail});
         else
-            hipLaunchKernelGGL((iqn_train_fwdbwd<false, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s, ba, params_local, params_target, workspace, batch, gamma,
-                               plan.mode, use_staged, tail);
+            hipLaunchKernelGGL((iqn_train_fwdbwd<false, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s,
+                               TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail});
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
     if (n_steps > 1) {      // no fused form for this batch / device: the steps one after the other (every later one starts from the batch its predecessor staged)
@@ -2209,8 +2250,8 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
         return MN_OK;
     }
     const StepTail no_tail = {};
-    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s, ba,
-                       params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail);
+    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s,
+                       TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail});
     if (plan.launches == 2 && x)
         hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
                            adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm,
