@@ -1,0 +1,198 @@
+"""The act path's per-network context (C-ABI mn_iqn_ctx): cached weight image + invalidation, independent contexts on
+concurrent streams, and the quantile capture of IQNAgent.act_eval against the reference's own forward (golden G7)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+def test_act_eval_quantiles_match_reference_forward(torch):
+    """`act_eval_batch` = batched IQNAgent.act_eval (agent.py:217-236): quantiles [n,32,9] and taus [n,32,1] equal the
+    reference network's forward with the same injected taus (G7 `fwd_quantiles_*`, `fwd_taus_*`, seeded init and the
+    shipped checkpoint), actions = argmax of the quantile means."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    Z = np.load(os.path.join(G, "g7_iqn.npz"))
+    dev = "cuda:0"
+    obs = torch.from_numpy(Z["obs"]).to(dev); taus = torch.from_numpy(Z["taus32"]).to(dev)
+    agent = IQNAgent(26, 9, seed=7, BUFFER_SIZE=64, device=dev)
+    for cvar in (1.0, 0.5):
+        a, quant, t = agent.act_eval_batch(obs, 0.0, cvar, taus=taus)
+        assert quant.shape == (16, 32, 9) and t.shape == (16, 32, 1) and a.dtype == torch.int32
+        np.testing.assert_allclose(quant.cpu().numpy(), Z[f"fwd_quantiles_cvar{cvar}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(t.cpu().numpy(), Z[f"fwd_taus_cvar{cvar}"], rtol=0, atol=1e-7)
+        q = quant.mean(dim=1)
+        np.testing.assert_allclose(q.cpu().numpy(), Z[f"qvals_cvar{cvar}"], rtol=1e-5, atol=1e-5)
+        assert torch.equal(a.long(), q.argmax(dim=1))
+        # per-row cvar tensor = the adaptive policy's call shape
+        a2, quant2, t2 = agent.act_eval_batch(obs, 0.0, torch.full((16,), cvar, device=dev), taus=taus)
+        assert torch.equal(quant2, quant) and torch.equal(t2, t)
+    agent.load_model(os.path.join(G, "pretrained_IQN_seed3"), dev)
+    _, quant, _ = agent.act_eval_batch(obs, 0.0, 1.0, taus=taus)
+    np.testing.assert_allclose(quant.cpu().numpy(), Z["pretrained_quantiles"], rtol=2e-5, atol=3e-4)      # |Z| up to ~110, float32
+    # library-drawn taus: returned taus are the ones the kernel used (re-injecting them reproduces the quantiles)
+    a, quant, t = agent.act_eval_batch(obs, 0.0, 0.5)
+    assert float(t.max()) < 0.5 and float(t.min()) >= 0.0
+    a2, quant2, _ = agent.act_eval_batch(obs, 0.0, 1.0, taus=t.view(16, 32))
+    assert torch.equal(quant, quant2) and torch.equal(a, a2)
+    # the mean-first hot path (no quantile output) agrees with the quantile path to float32 rounding
+    q_hot = agent.qvals_batch(obs, 1.0, taus=t.view(16, 32))
+    np.testing.assert_allclose(q_hot.cpu().numpy(), quant.mean(dim=1).cpu().numpy(), rtol=1e-5, atol=2e-5)
+    # large ragged batch through the quantile kernel vs PyTorch
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    big = torch.randn(3001, 26, device=dev, generator=g) * 4
+    tb = torch.rand(3001, 32, device=dev, generator=g)
+    _, quant, _ = agent.act_eval_batch(big, 0.0, 1.0, taus=tb)
+    with torch.no_grad():
+        ref, _ = agent.qnetwork_local.forward(big, 32, 1.0, taus=tb)
+    scale = float(ref.abs().max())
+    assert float((quant - ref).abs().max()) < 2e-5 * max(1.0, scale)
+
+
+def test_weight_image_cache_and_invalidation(torch):
+    """The permuted weight image is rebuilt only when the weights changed: (a) a PyTorch-side write (optimizer step,
+    load_state_dict, in-place op) is picked up from the parameters' version counters; (b) the fused HIP Adam step
+    (which PyTorch cannot see) invalidates explicitly; (c) a write that bypasses both is NOT seen until
+    `weights_changed` -- i.e. the cache is real."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_qvals, weights_changed
+    dev = "cuda:0"
+    agent = IQNAgent(26, 9, seed=2, BATCH_SIZE=32, BUFFER_SIZE=256, device=dev)
+    net = agent.qnetwork_local
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    obs = torch.randn(512, 26, device=dev, generator=g) * 3; taus = torch.rand(512, 32, device=dev, generator=g)
+    ref = lambda: net.get_qvals(obs, 1.0, taus=taus)
+    close = lambda a, b: float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+    q0 = fused_qvals(net, obs, 1.0, taus=taus)
+    with torch.no_grad():
+        assert close(q0, ref())
+        # (c) raw write behind PyTorch's back: same storage, no version bump
+        w = net.output_layer.bias
+        raw = torch.empty(0, device=dev).set_(w.untyped_storage(), w.storage_offset(), w.shape)   # alias without version link
+        v_before = w._version
+        raw.add_(1.0)
+        assert w._version == v_before
+        q_stale = fused_qvals(net, obs, 1.0, taus=taus)
+        assert torch.equal(q_stale, q0)                      # cached image still in use
+        weights_changed(net)
+        q_new = fused_qvals(net, obs, 1.0, taus=taus)
+        assert close(q_new, ref()) and close(q_new, q0 + 1.0)
+        # (a) PyTorch-side in-place write: detected without any call
+        net.output_layer.bias.sub_(1.0)
+        assert close(fused_qvals(net, obs, 1.0, taus=taus), q0)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd["hidden_layer.weight"] = sd["hidden_layer.weight"] * 0.5
+        net.load_state_dict(sd)
+        assert close(fused_qvals(net, obs, 1.0, taus=taus), ref())
+    # (b) fused HIP gradient steps
+    agent.memory.add_batch(torch.randn(256, 26, device=dev, generator=g), torch.randint(0, 9, (256,), device=dev, generator=g),
+                           torch.randn(256, device=dev, generator=g), torch.randn(256, 26, device=dev, generator=g),
+                           (torch.rand(256, device=dev, generator=g) < 0.1).float())
+    agent.memory.size = 256
+    for _ in range(3):
+        agent.train_from_memory()
+        with torch.no_grad():
+            assert close(fused_qvals(net, obs, 1.0, taus=taus), ref())
+
+
+def test_two_agents_act_concurrently_on_two_streams(torch):
+    """Two networks, two contexts, two streams of one device, interleaved launches without host synchronisation:
+    every result equals the network's own serial result (round 1's single per-device weight image raced here)."""
+    from distributional_rl_navigation_amd.iqn.fused_act import fused_act
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    dev = "cuda:0"
+    nets = [ObsEncoder(26, 9, seed=s, device=dev) for s in (1, 2)]
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    obs = torch.randn(20000, 26, device=dev, generator=g) * 4; taus = torch.rand(20000, 32, device=dev, generator=g)
+    serial = [fused_act(n_, obs, 0.0, 1.0, taus=taus, want_qvals=True) for n_ in nets]
+    assert not torch.equal(serial[0][1], serial[1][1])
+    streams = [torch.cuda.Stream(device=dev) for _ in nets]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(6):
+        for k, (n_, s_) in enumerate(zip(nets, streams)):
+            with torch.cuda.stream(s_):
+                if rep % 2 == 1:      # force a re-pack on this stream while the other stream's kernel is in flight
+                    from distributional_rl_navigation_amd.iqn.fused_act import weights_changed
+                    weights_changed(n_)
+                outs[k].append(fused_act(n_, obs, 0.0, 1.0, taus=taus, want_qvals=True))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for a, q in outs[k]:
+            assert torch.equal(q, serial[k][1]) and torch.equal(a, serial[k][0])
+
+
+def test_iqn_ctx_c_abi_errors(torch):
+    from distributional_rl_navigation_amd import _capi
+    L = _capi.lib()
+    INVALID = -1
+    assert L.mn_iqn_create(None) == INVALID and L.mn_iqn_destroy(None) == INVALID and L.mn_iqn_weights_changed(None) == INVALID
+    h = C.c_void_p()
+    assert L.mn_iqn_create(C.byref(h)) == 0 and h.value
+    obs = torch.zeros(4, 26, device="cuda:0"); taus = torch.zeros(4, 32, device="cuda:0"); act = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.mn_iqn_act(None, p(obs), p(taus), None, None, None, C.c_float(0.0), p(act), None, 4, 32, None) == INVALID   # no context
+    assert L.mn_iqn_act(h, p(obs), p(taus), None, None, None, C.c_float(0.0), p(act), None, 4, 32, None) == INVALID      # no weights
+    ptrs = (C.c_void_p * 14)(*[obs.data_ptr()] * 14)
+    assert L.mn_iqn_act(h, p(obs), p(taus), ptrs, None, None, C.c_float(0.0), None, None, 4, 32, None) == INVALID       # nothing to write
+    assert L.mn_iqn_act(h, p(obs), p(taus), ptrs, None, None, C.c_float(0.0), p(act), None, 4, 8, None) == INVALID      # K must be 32
+    assert L.mn_iqn_profile_begin(h, -1) == INVALID
+    assert L.mn_iqn_destroy(h) == 0
+    assert L.mn_build_info() == 0        # the shipped library has no ablation switch
+
+
+@pytest.mark.parametrize("weights", ["seeded", "pretrained"])
+def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
+    """The acting kernel exists in three forms (`mn_iqn_set_variant`: 2 = split-f16 MFMA, the default; 0 = exact-f32 16x16x4;
+    1 = the exact-f32 32x32x2 re-layout; 3 = the split-f16 kernel on 32x32x16 tiles).  Same network, float32-class results in all: each matches eager PyTorch to float32
+    rounding on ragged batch sizes, they match each other, and they pick the same greedy action wherever the top-2 gap is
+    above the rounding noise."""
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
+    from distributional_rl_navigation_amd.iqn.model import ObsEncoder
+    dev = "cuda:0"
+    net = ObsEncoder(26, 9, seed=5, device=dev) if weights == "seeded" else ObsEncoder.load(os.path.join(G, "pretrained_IQN_seed3"), dev)
+    ctx = act_context(net)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    for n in (1, 7, 64, 1000, 8192 + 3):
+        obs = torch.randn(n, 26, device=dev, generator=g) * 5.0
+        obs[:, 4:][torch.rand(n, 22, device=dev, generator=g) < 0.4] = 0.0
+        taus = torch.rand(n, 32, device=dev, generator=g)
+        with torch.no_grad():
+            ref = net.get_qvals(obs, 1.0, taus=taus)
+        out = {}
+        for variant in (0, 1, 2, 3):
+            ctx.set_variant(variant)
+            out[variant] = fused_act(net, obs, 0.0, 1.0, taus=taus, want_qvals=True)
+        ctx.set_variant(ctx.DEFAULT_VARIANT)
+        scale = max(1.0, float(ref.abs().max()))
+        for variant in (0, 1, 2, 3):
+            a, q = out[variant]
+            assert float((q - ref).abs().max()) < 3e-5 * scale, (variant, n)
+            top2 = ref.topk(2, dim=1).values
+            clear = (top2[:, 0] - top2[:, 1]) > 1e-3 * scale
+            assert torch.equal(a.long()[clear], ref.argmax(dim=1)[clear])
+        assert float((out[0][1] - out[1][1]).abs().max()) < 3e-5 * scale
+        assert float((out[0][1] - out[2][1]).abs().max()) < 3e-5 * scale
+        assert float((out[0][1] - out[3][1]).abs().max()) < 3e-5 * scale
+    # exploration epilogue of the 32x32x2 kernel: same rule as the default kernel (greedy iff u > eps)
+    ctx.set_variant(1)
+    n = 20000
+    obs = torch.randn(n, 26, device=dev, generator=g) * 4.0; taus = torch.rand(n, 32, device=dev, generator=g)
+    g2 = torch.Generator(device=dev); g2.manual_seed(1)
+    greedy = fused_act(net, obs, 0.0, 1.0, taus=taus)
+    mixed = fused_act(net, obs, 0.3, 1.0, taus=taus, generator=g2)
+    frac = float((mixed == greedy).float().mean())
+    ctx.set_variant(ctx.DEFAULT_VARIANT)
+    assert 0.70 < frac < 0.77 and bool(((mixed >= 0) & (mixed < 9)).all())

@@ -1,0 +1,278 @@
+"""BASELINE configs[3] (524 288 envs as 8 shards, independent learners) and configs[4] (shared IQN, RCCL gradient
+all-reduce, CVaR 0.5 acting) exercised on ONE GPU: every code path of the multi-GPU configurations that does not need
+a second device runs here -- the fused HIP gradient step under a real `nccl` (RCCL) process group, the same step
+across two ranks (two processes sharing the GPU, gloo transport), shard == slice at configs[3]'s full size, and
+bench.py's --shared-learner line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _batch(torch, seed, B, dev):
+    g = np.random.RandomState(seed)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return (t(g.normal(0, 5, (B, 26)).astype(np.float32)), t(g.randint(9, size=(B, 1)).astype(np.int64)),
+            t(g.normal(0, 3, (B, 1)).astype(np.float32)), t(g.normal(0, 5, (B, 26)).astype(np.float32)),
+            t((g.uniform(size=(B, 1)) < 0.2).astype(np.float32)))
+
+
+def _taus(torch, seed, B, dev):
+    g = np.random.RandomState(1000 + seed)
+    return (torch.from_numpy(g.uniform(size=(B, 8)).astype(np.float32)).to(dev),
+            torch.from_numpy(g.uniform(size=(B, 8)).astype(np.float32)).to(dev))
+
+
+def test_fused_step_under_nccl_world_size_1_is_bitwise_the_plain_step(torch):
+    """`IQNAgent(distributed=True)` on an RCCL process group of one rank: mn_iqn_train_grad -> dist.all_reduce(flat
+    gradient) -> mn_iqn_train_adam (iqn/fused_train.py) must give bit-identical losses / gradients / weights to the
+    non-distributed fused step (sum over one rank, divided by 1)."""
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device(dev))
+    try:
+        agents = [IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=128, device=dev, seed=5, distributed=d) for d in (False, True)]
+        for a in agents:
+            assert a.use_fused_train
+        for step in range(4):
+            exp = _batch(torch, step, 64, dev)
+            tt, tl = _taus(torch, step, 64, dev)
+            losses = [float(a.train(exp, taus_target=tt, taus_local=tl)) for a in agents]
+            assert losses[0] == losses[1]
+            for p0, p1 in zip(agents[0].qnetwork_local.parameters(), agents[1].qnetwork_local.parameters()):
+                assert torch.equal(p0, p1) and torch.equal(p0.grad, p1.grad)
+        assert int(agents[1]._fused.step_dev) == 4
+        # the replay-driven entry the training loop uses (sample on device -> gather from the ring -> step)
+        for a in agents:
+            a.memory.add_batch(*_batch(torch, 99, 128, dev))
+            a._fused.rng_state.copy_(torch.tensor([7, 0], dtype=torch.int64))
+        l0, l1 = (float(a.train_from_memory()) for a in agents)
+        assert l0 == l1
+    finally:
+        dist.destroy_process_group()
+
+
+_TWO_RANK_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[4]); sys.path.insert(0, os.path.join(sys.argv[4], "tests"))
+from test_multigpu_paths_gpu import _batch, _taus
+from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+rank, port, out = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+exchange = sys.argv[5] if len(sys.argv) > 5 else "collective"
+n_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+# "mailbox": the exchange inside the reduction + Adam launch (mn_iqn_train_step_xchg: two launches per step); "mailbox3": reduction (publishes), then gather +
+# Adam in one launch (mn_iqn_train_exchange_adam); "mailbox4": reduction, mn_iqn_train_exchange, mn_iqn_train_adam
+fused_adam, two_launch = exchange != "mailbox4", exchange == "mailbox"
+exchange = "mailbox" if exchange.startswith("mailbox") else exchange
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+dev = "cuda:0"
+agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=64, device=dev, seed=3, distributed=True, rank=rank)
+agent.exchange = exchange      # "collective": the bucket travels over gloo; "mailbox": IPC-mapped mailboxes, gloo only carries the handles
+agent.exchange_fused_adam = fused_adam
+agent.two_launch_step = two_launch or exchange != "mailbox"
+assert agent.use_fused_train
+for step in range(n_steps):
+    tt, tl = _taus(torch, 10 * step + rank, 32, dev)
+    agent.train(_batch(torch, 10 * step + rank, 32, dev), taus_target=tt, taus_local=tl)
+flat = agent._fused.local.cpu()
+gathered = [torch.empty_like(flat) for _ in range(2)]
+dist.all_gather(gathered, flat)
+timeouts = agent._fused._mailbox.timeouts() if exchange == "mailbox" else 0
+if rank == 0:
+    torch.save(dict(params=flat, same=bool(torch.equal(gathered[0], gathered[1])), timeouts=timeouts), out)
+dist.destroy_process_group()
+"""
+
+
+def test_fused_step_two_ranks_equals_big_batch(torch, tmp_path):
+    """configs[4]'s learner with world size 2: two processes (both on this GPU; the 143 KB gradient bucket travels
+    over gloo instead of RCCL, which refuses two ranks on one device) each run the fused HIP step on their own batch
+    with the all-reduce between mn_iqn_train_grad and mn_iqn_train_adam.  The ranks must stay bit-identical, and
+    equal -- to float32 summation order -- ONE fused step on the union of the two batches (clip after averaging)."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    out = str(tmp_path / "r0.pt"); port = str(_free_port())
+    script = str(tmp_path / "worker.py")
+    with open(script, "w") as f:
+        f.write(_TWO_RANK_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, script, str(r), port, out, ROOT], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    res = torch.load(out)
+    assert res["same"], "ranks diverged: all-reduced gradients must keep shared learners identical"
+    dev = "cuda:0"
+    ref = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=64, device=dev, seed=3)
+    for step in range(3):
+        b0, b1 = _batch(torch, 10 * step, 32, dev), _batch(torch, 10 * step + 1, 32, dev)
+        (t0, l0), (t1, l1) = _taus(torch, 10 * step, 32, dev), _taus(torch, 10 * step + 1, 32, dev)
+        ref.train(tuple(torch.cat([a, b]) for a, b in zip(b0, b1)), taus_target=torch.cat([t0, t1]), taus_local=torch.cat([l0, l1]))
+    np.testing.assert_allclose(res["params"].numpy(), ref._fused.local.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def _two_rank_run(torch, tmp_path, tag, exchange, n_steps):
+    out = str(tmp_path / f"{tag}.pt"); port = str(_free_port())
+    script = str(tmp_path / "worker.py")
+    with open(script, "w") as f:
+        f.write(_TWO_RANK_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, script, str(r), port, out, ROOT, exchange, str(n_steps)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return torch.load(out)
+
+
+def test_mailbox_exchange_two_ranks_equals_the_all_reduce_path_bitwise(torch, tmp_path):
+    """The one-shot gradient exchange (`mn_xchg_*`, iqn/mailbox.py): two ranks (two processes on this GPU) publish their reduced
+    gradients into IPC-exported mailboxes from inside the reduction kernel and each sums both mailboxes in rank order with one gather
+    kernel -- no collective.  Same batches through the all-reduce path (bucket over gloo): parameters bit-identical after 12 steps,
+    ranks bit-identical to each other, no granule timed out."""
+    a = _two_rank_run(torch, tmp_path, "collective", "collective", 12)
+    b = _two_rank_run(torch, tmp_path, "mailbox", "mailbox", 12)        # two launches per step: the exchange inside the reduction + Adam launch
+    c = _two_rank_run(torch, tmp_path, "mailbox3", "mailbox3", 12)      # three: reduction (publishes), then gather + clip + Adam
+    d = _two_rank_run(torch, tmp_path, "mailbox4", "mailbox4", 12)      # four: reduction, mn_iqn_train_exchange, mn_iqn_train_adam
+    for r in (a, b, c, d):
+        assert r["same"] and r["timeouts"] == 0
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["params"], c["params"]) and torch.equal(a["params"], d["params"])
+
+
+def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graphed(torch):
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        runs = []
+        for distributed, graphed, fused, two in ((False, False, True, True), (True, False, True, True), (True, True, True, True), (True, False, True, False),
+                                                 (True, False, False, False), (True, True, False, False)):
+            ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
+            ag.exchange = "mailbox"
+            ag.exchange_fused_adam, ag.two_launch_step = fused, two
+            ag.use_fused_graph = graphed
+            ag.memory.add_batch(*_batch(torch, 7, 300, dev))
+            losses = [float(ag.train_steps_from_memory(8)) for _ in range(3)]
+            runs.append((losses, ag._fused.local.clone(), ag._fused.exp_avg_sq.clone(), int(ag._fused.step_dev)))
+            if distributed:
+                assert ag._fused._mailbox.timeouts() == 0
+        for r in runs[1:]:
+            assert r[0] == runs[0][0] and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and r[3] == runs[0][3] == 24
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+def test_shards_equal_slices_at_config3_size(torch, precision):
+    """BASELINE configs[3]: 524 288 envs as 8 shards of 65 536 (rank r: first_index = r * 65 536).  One 524 288-env
+    handle vs the eight shard handles, same actions: worlds, observations, rewards, done flags and counters of shard
+    r are bitwise rows [r n, (r+1) n) of the big run, through resets -- in float64 (what `bench.py --gpus N` runs with a learner
+    in the loop, `bench.default_precision`) and in the kernel-only configs' mixed precision."""
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    n, world, T = 65536, 8, 6
+    dev = "cuda:0"
+    big = VecMarineNavEnv(n * world, seed=0, device=dev, precision=precision)
+    big.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+    ob = big.reset().clone()
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    acts = [torch.randint(0, 9, (n * world,), device=dev, dtype=torch.int32, generator=g) for _ in range(T)]
+    trace = []
+    for t in range(T):
+        o, r, d, i = big.step(acts[t])
+        trace.append((o.clone(), r.clone(), d.clone(), i.clone()))
+        big.reset_done()
+    final_big = big.obs.clone()
+    sb, epb, totb = big.get_state()
+    wb = big.get_worlds(3 * n + 100, 16)
+    big.close()
+    total_done = 0
+    for r_ in range(world):
+        sh = VecMarineNavEnv(n, seed=0, first_index=r_ * n, device=dev, precision=precision)
+        sh.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+        sl = slice(r_ * n, (r_ + 1) * n)
+        assert torch.equal(sh.reset(), ob[sl])
+        for t in range(T):
+            o, rew, d, i = sh.step(acts[t][sl])
+            assert torch.equal(o, trace[t][0][sl]) and torch.equal(rew, trace[t][1][sl])
+            assert torch.equal(d, trace[t][2][sl]) and torch.equal(i, trace[t][3][sl])
+            total_done += int(d.sum())
+            sh.reset_done()
+        assert torch.equal(sh.obs, final_big[sl])
+        s, ep, tot = sh.get_state()
+        assert np.array_equal(s, sb[sl]) and np.array_equal(ep, epb[sl]) and np.array_equal(tot, totb[sl])
+        if r_ == 3:
+            for a, b in zip(sh.get_worlds(100, 16), wb):
+                assert np.array_equal(a["cores"], b["cores"]) and np.array_equal(a["obstacles"], b["obstacles"])
+        sh.close()
+    assert total_done > 200       # resets happened inside the compared window
+
+
+def test_bench_shared_learner_line(torch):
+    """`python bench.py --gpus 1 --shared-learner --cvar 0.5` (configs[4] on one GPU: single-rank RCCL group, the
+    all-reduce executes) prints ONE JSON line with the contract's keys."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shared-learner", "--cvar", "0.5",
+                          "--envs", "4096", "--steps", "24", "--warmup", "8", "--cpu-steps", "0", "--no-learner-only"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["config"]["learner"] == "shared, RCCL grad all-reduce" and j["config"]["cvar"] == 0.5
+    assert j["config"]["process_group"] == "nccl" and j["config"]["ablation"] is False
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["grad_steps_per_sec"] > 0
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+
+
+def test_graphed_fused_steps_equal_eager_steps_bitwise_plain_and_under_nccl(torch):
+    """`IQNAgent.use_fused_graph`: the 8 gradient steps of a training event -- forward / backward, reduction, (shared learner) the RCCL
+    all-reduce of the flat gradient, Adam, every step -- captured once and replayed as ONE hipGraph launch.  Counters (generator, Adam
+    step, hand-off epoch) live on the device, so three replays continue where eager calls would: losses, parameters, moments,
+    generator state bit-identical to 24 eager steps; checked without a process group and with a single-rank RCCL group, and across a
+    write to the replay ring between two replays."""
+    import torch.distributed as dist
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for distributed in (False, True):
+        if distributed:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=torch.device(dev))
+        try:
+            runs = []
+            for graphed in (False, True):
+                ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
+                ag.use_fused_graph = graphed
+                ag.memory.add_batch(*_batch(torch, 7, 300, dev))      # the ring is full (graphs are used from then on: its row count is constant)
+                losses = []
+                for ev in range(3):
+                    if ev == 2:
+                        ag.memory.add_batch(*_batch(torch, 8, 100, dev))      # ring written between two replays of the SAME graph
+                    losses.append(float(ag.train_steps_from_memory(8)))
+                ft = ag._fused
+                runs.append((losses, ft.local.clone(), ft.exp_avg_sq.clone(), ft.rng_state.clone(), int(ft.step_dev), ag.grad_steps))
+            (l0, p0, v0, r0, s0, g0), (l1, p1, v1, r1, s1, g1) = runs
+            assert l0 == l1 and torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(r0, r1)
+            assert s0 == s1 == 24 and g0 == g1 == 24 and int(r0[1]) == 24
+        finally:
+            if distributed:
+                dist.destroy_process_group()

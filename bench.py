@@ -32,7 +32,8 @@ means is written HERE, not in the line.
                         act_exact_f32 = the loop with the exact-f32 MFMA act kernel; shared_learner_ws1 = learner alone, grad-steps/s: one launch per
                         step, the RCCL all-reduce at world size 1 eager / inside captured 16-step graphs, the mailbox exchange inside the one-launch
                         step; act_shared_taus (opt-in: 32 taus per launch instead of per env; tiled = environments in the MFMA columns, wave = wavefront
-                        per env); train_cadence = what train_iqn runs: 16 gradient steps per vector step, eps 0.05
+                        per env); train_cadence = what train_iqn runs: 16 gradient steps per vector step, eps 0.05 (_multi_step: the 16 steps of an event as one
+                        persistent launch, opt-in)
   learner_only          back-to-back gradient steps, grad-steps/s: fused_hip (one launch per step), fused_hip_g16 (persistent 16-step launches: what a training
                         event of train_iqn is), eager PyTorch, hipGraph of PyTorch
 """
@@ -301,6 +302,10 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
     train_step = lambda o: agent.vec_step(env, o, 0.05, args.cvar, train_every=1, per_iter=n)[0]
     dt, act_ms = shared_leg(train_step, steps, 10)
     out["train_cadence_shared_taus"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt, "act_launch_ms": act_ms}
+    agent.use_multi_step = True      # the 16 steps of an event as ONE persistent launch (opt-in)
+    dt, obs = _timed(device, train_step, steps, 10, obs)
+    agent.use_multi_step = False
+    out["train_cadence_multi_step"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt}
     dt, obs = _timed(device, train_step, steps, 10, obs)
     out["train_cadence"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt,
                             "grad_steps_per_vector_step": 16, "launches_per_grad_step": agent._fused.launches_per_step()}
@@ -557,6 +562,7 @@ def main():
             learner_only[mode] = reps / (time.perf_counter() - t1)
             if mode == "fused_hip" and not (agent.distributed and agent.exchange == "collective"):
                 # the same steps as persistent 16-step launches (mn_iqn_train_steps: what a training event of train_iqn is)
+                agent.use_multi_step = True
                 for _ in range(3):
                     agent.train_steps_from_memory(16)
                 torch.cuda.synchronize(device)
@@ -565,6 +571,7 @@ def main():
                     agent.train_steps_from_memory(16)
                 torch.cuda.synchronize(device)
                 learner_only["fused_hip_g16"] = 40 * 16 / (time.perf_counter() - t1)
+                agent.use_multi_step = False
         agent.use_fused_train = was_fused
 
     result_line = None

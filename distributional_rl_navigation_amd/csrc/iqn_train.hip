@@ -113,7 +113,11 @@ __device__ unsigned long long g_phase3[3][8];         // reduction + Adam blocks
 #define PH2(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) g_phase2[kern][blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
 #define PH3(k) do { if (threadIdx.x == 0 && (vb == 0 || vb == nvb / 2 || vb == nvb - 1)) g_phase3[vb == 0 ? 0 : (vb == nvb - 1 ? 2 : 1)][k] = wall_clock64(); } while (0)
 #define PH(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_phase[blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
+// multi-step launch: stamps of target workgroup 0 / the first local workgroup per step (mod 4): [role][step & 3][stamp]
+__device__ unsigned long long g_stepph[2][4][16];
+#define PHK(kk, i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_stepph[blockIdx.x == 0 ? 0 : 1][(kk) & 3][i] = wall_clock64(); } while (0)
 #else
+#define PHK(kk, i) do { } while (0)
 #define PH(k) do { } while (0)
 #define PH2(kern, k) do { } while (0)
 #define PH3(k) do { } while (0)
@@ -555,7 +559,7 @@ constexpr int RED_SEG = MN_RED_SEG;                            // partial-sum se
 __host__ __device__ constexpr int64_t pad4(int64_t x) { return (x + 3) / 4 * 4; }
 __host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_part * P_PAD; }
 __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
-__host__ __device__ constexpr int64_t ws_tdq(int n_part) { return (ws_sq(n_part) + pad4(N_RED) + 31) / 32 * 32; }      // 128-byte aligned: a part's 16 granules are one cache line
+__host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }      // (NOT rounded up to a cache line: shifting everything behind it by 32 bytes cost the stand-alone reduction 6 us -- measured, round 5)
 constexpr int MN_TD_SLOTS = 2;      // sets of TD-target granules, by step parity
 __host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * MN_TD_SLOTS * (int64_t)n_part * ROWS; }      // (two sets of TD-target granules, by step parity)
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
@@ -707,6 +711,8 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     __shared__ float gsh[VPB][4 * RA_COLS];
     __shared__ float nred[4];
     __shared__ float s_bc[2];
+    __shared__ int s_lateflag;      // block-wide OR of `late`: written only by a thread whose bounded wait ran out, read behind barriers that are there anyway
+                                    // (__syncthreads_or is a workgroup reduction through LDS: ~0.5 us each, three per step)
     // (seg = the wavefront's index: said so explicitly -- behind tid_now() the compiler no longer knows that it is wave-uniform, built the group row's buffer descriptor per
     // lane and wrapped every granule load in a waterfall loop)
     const int tid = tid_now(), cx = tid % RA_COLS, seg = __builtin_amdgcn_readfirstlane(tid / RA_COLS);
@@ -725,6 +731,8 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         return;
     }
     PH3(0);
+    if (tid_now() == 0) s_lateflag = 0;
+    __syncthreads();
     const uint32_t tag = xchg_tag(sc.epoch + 1);      // the epoch this step ends with
     // this thread's Adam operands first (threads 0 .. 255 own one parameter each): their latency overlaps the reduction
     float mp[VPB], vp[VPB], pp[VPB];
@@ -887,7 +895,8 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
     }
 #pragma unroll
     for (int j = 0; j < VPB; ++j) red[j][seg][cx] = acc[j];
-    late = __syncthreads_or(late);      // (a bounded wait that ran out anywhere in the block poisons the block's output)
+    if (late) s_lateflag = 1;
+    __syncthreads();      // (a bounded wait that ran out anywhere in the block poisons the block's output: s_lateflag, read further down)
     PH3(2);
     // This block's ticket, taken HERE -- behind a barrier that every read of the epoch, the Adam step and the generator's counter above sits in front of -- and
     // looked at only at the very end: the round trip of the atomic (~1 us) runs under the norm exchange instead of between Adam and the end of the launch.
@@ -928,7 +937,8 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
 #pragma unroll
         for (int k = 0; k < 4; ++k) gsh[j][4 * cx + k] = e[k];
     }
-    late = __syncthreads_or(late);      // (the exchange's gather may have run into its bound in some thread)
+    if (late) s_lateflag = 1;      // (the exchange's gather may have run into its bound in some thread)
+    __syncthreads();
     gu64 *xsq = (gu64 *)(ws + ws_xsq(n_part));
     if (tid == 0 || tid == RED_COLS)
 #pragma unroll
@@ -988,7 +998,9 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
     if (tid < 256 && (tid & 63) == 0) nred[tid >> 6] = part;
-    late = __syncthreads_or(late);
+    if (late) s_lateflag = 1;
+    __syncthreads();
+    late = s_lateflag != 0;
     const float sumsq = (nred[0] + nred[1]) + (nred[2] + nred[3]);
     const float norm = sqrtf(sumsq);
     const float coef = fminf((float)max_norm_d / (norm + 1e-6f), 1.f);
@@ -1251,12 +1263,13 @@ __device__ __forceinline__ StepTail ld_step_tail(TrainArgsK A) {
                     A->tail.v, A->tail.step, A->tail.rng_state, A->tail.lr, A->tail.b1, A->tail.b2, A->tail.eps, A->tail.max_norm, A->tail.xa, A->tail.xa_scale};
 }
 
-template <bool XCHG, bool FUSED>
+template <bool XCHG, bool FUSED, bool MULTI>
 __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args) {
+    static_assert(FUSED || !MULTI, "several steps per launch: the fused step only");
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
     __shared__ int s_got;
-    const int G = FUSED ? args.tail.n_steps : 1;
+    const int G = MULTI ? args.tail.n_steps : 1;      // (MULTI = false: one step, compiled as a single pass -- no loop-carried state, ordinary parameter loads)
     // ---- the counters this launch starts from; nothing in memory moves before its last step's reduction + Adam blocks have all taken their ticket
     uint64_t epoch0, rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;      // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
     int32_t step0 = 0;
@@ -1275,7 +1288,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
 #endif
 
     // Iteration k: target workgroups run the target forward pass of step k, then the reduction + Adam work of step k - 1; local workgroups run step k.
-    for (int k = 0; k <= G; ++k) {
+    for (int k = 0; k <= (MULTI ? G : (FUSED ? 1 : 0)); ++k) {
     // (One step's scalar and address arithmetic must not be hoisted out of the loop -- hundreds of values would then live across the whole body: the thread index is
     // opaque at every use (tid_now), the block index and the kernel arguments -- re-read from the kernarg segment -- are made opaque per iteration, and everything
     // derived from them, the workgroup's role included, is derived again.)
@@ -1305,7 +1318,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     const float gamma = FUSED ? A->gamma : args.gamma;
     const int use_staged = FUSED ? A->use_staged : args.use_staged;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const ParamView<FUSED> VL(PL);
+    const ParamView<MULTI> VL(PL);
     const float *stage = ws + ws_stage(n_part);
     const int st_slot = min(tid / STG, BE - 1), st_e = tid % STG;
     float *out = ws + (size_t)part * P_PAD;
@@ -1319,7 +1332,11 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store((gu64 *)(ws + ws_xcc(n_part)) + part, ((uint64_t)tag << 32) | (uint64_t)(xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (FUSED && !is_target && k > 0) {
+
+    // ---- The first requests of a step: (a) -- first step of a launch -- this workgroup's two batch slots as the previous launch's reduction blocks STAGED them
+    // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
+    // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
+    if (MULTI && !is_target && k > 0) {
         // ---- multi-step launch: the parameters of step k - 1, from every reduction + Adam block (their stores are written through and acknowledged before the
         // word is): ONE wavefront polls the n_phys words, everything this workgroup reads of the local network from here on is read past its vector cache
         const uint32_t ptag = (uint32_t)((epoch0 + (uint64_t)k - 1) % 0xFFFFFFFFull) + 1u;
@@ -1338,15 +1355,14 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         }
         __syncthreads();
     }
-
-    // ---- The first requests of a step: (a) -- first step of a launch -- this workgroup's two batch slots as the previous launch's reduction blocks STAGED them
-    // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
-    // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
+    PHK(k, 0);   /* step k begins (parameters of step k - 1 seen) */
+    // (Measured and dropped: gathering the batch in FRONT of that wait -- 1.6 us earlier requests, but two sites that define the 140 weight registers cost 48 bytes of
+    // scratch per lane and the step got 1 us longer.)
     const bool try_staged = use_staged && k == 0;
     float st_v = 0.f;
     if (try_staged) st_v = stage[(b0 + st_slot) * STG + st_e];      // kernel argument: a scalar branch
     FwdWeights w;
-    const ParamView<FUSED> V(is_target ? PT : PL);
+    const ParamView<MULTI> V(is_target ? PT : PL);
     prefetch_forward(w, V);
     PH(14);  /* all requests issued */
     // the staged batch is this step's batch iff it was drawn for this call counter from a ring of this many rows
@@ -1412,6 +1428,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     __syncthreads();
     prefetch_forward_late(w, V);
     PH(1);   /* draw + gather + weight requests */
+    PHK(k, 1);
 
     // output-layer row of the action taken, for dh3 (element tid + 512 e of the [16][64] tile: row 8 e + (tid >> 6), column tid & 63,
     // i.e. batch element e): two more early requests
@@ -1433,11 +1450,12 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
             __hip_atomic_store(granules + tid, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PH(7);   /* granules published */
+        PHK(k, 2);
         if (bid == 0 && k == G - 1) write_batch_copies(ba, base, batch);
 #ifdef MN_TRAIN_PHASES
         if (tid_now() == 0) g_wgt[blockIdx.x][1] = wall_clock64();
 #endif
-        if (FUSED) __syncthreads();      // (the next forward pass of this workgroup overwrites the rewards / done flags wave 0 has just read)
+        if (MULTI) __syncthreads();      // (the next forward pass of this workgroup overwrites the rewards / done flags wave 0 has just read)
     } else {
 
     // ---- local workgroup
@@ -1492,7 +1510,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
             __syncthreads();
         }
         FwdWeights wt;
-        const ParamView<FUSED> VT(PT);
+        const ParamView<MULTI> VT(PT);
         prefetch_forward(wt, VT);
         prefetch_forward_late(wt, VT);
         const PassBufs Bt = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
@@ -1505,6 +1523,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     }
 
     PH(8);   /* TD targets in LDS (hand-off wait, or own target forward) */
+    PHK(k, 3);
     // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407); every thread evaluates the (cheap) gradient of
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
     // Fused step: the row is read by the workgroups of its group (block index % 8), which share an XCD, through that XCD's L2: ordinary stores.  A workgroup
@@ -1686,6 +1705,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     }
     if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
+    PHK(k, 4);
     if (!two_roles && bid == 0) write_batch_copies(ba, base, batch);
     if (FUSED) {      // this workgroup's row (and loss partial) is final
         // Its stores are acknowledged -- by memory if they were write-through ones, by this XCD's L2 otherwise -- once vmcnt is 0; nothing of a
@@ -1693,6 +1713,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         PH(17);
+        PHK(k, 5);
 #ifdef MN_TRAIN_PHASES
         if (tid_now() == 0) g_wgt[blockIdx.x][2] = wall_clock64();
 #endif
@@ -1702,6 +1723,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         }
         group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to wait for behind it)
         PH(18);
+        PHK(k, 6);
     }
 #ifdef MN_TRAIN_PHASES
     __builtin_amdgcn_s_waitcnt(0);
@@ -1713,7 +1735,8 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     if ((is_target || is_extra) && k >= 1) {
         // ---- reduction + clip + Adam of step k - 1
         const int s = k - 1;
-        const StepCtx sc = {epoch0 + (uint64_t)s, step0 + s, rs0, rs1 + (uint64_t)s, s == G - 1, true, G > 1};
+        const StepCtx sc = {epoch0 + (uint64_t)s, step0 + s, rs0, rs1 + (uint64_t)s, s == G - 1, true, MULTI};
+        PHK(s, 8);   /* reduction + Adam of step s begins */
         reduce_adam_body<2>(pb, n_phys, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out + s, tail.rng_state, ba, tail.prefetch_next, tail.params, tail.m, tail.v,
                             tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, sc, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f);
         if (s < G - 1) {      // more steps to come: this block's parameters are out (write-through stores, acknowledged) -- say so
@@ -1724,6 +1747,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
                 __hip_atomic_store((gu64 *)(ws + ws_pflag(n_part)) + pb, (uint64_t)stag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        PHK(s, 12);   /* parameters out */
     }
     }      // k
 }
@@ -2039,6 +2063,9 @@ extern "C" int mn_iqn_train_debug_wgt(unsigned long long *out_host) {   // [1024
 extern "C" int mn_iqn_train_debug_phases3(unsigned long long *out_host) {   // [first, middle, last reduction + Adam block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase3), sizeof(unsigned long long) * 24) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
+extern "C" int mn_iqn_train_debug_stepph(unsigned long long *out_host) {   // [target workgroup 0, first local workgroup][step & 3][16]
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stepph), sizeof(unsigned long long) * 128) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
 extern "C" int mn_iqn_train_debug_phases2(unsigned long long *out_host) {   // [reduce, adam][block 0, middle block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase2), sizeof(unsigned long long) * 32) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
@@ -2127,10 +2154,11 @@ static int dev_info(DevInfo *out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
         // the forward / backward kernel's dynamic LDS (97 KB) is above the default limit: raised once per device
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return MN_ERR_HIP;
+        const void *kernels[] = {reinterpret_cast<const void *>(iqn_train_fwdbwd<false, false, false>), reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true, false>),
+                                 reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true, false>), reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true, true>),
+                                 reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true, true>)};
+        for (const void *kf : kernels)
+            if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return MN_ERR_HIP;
         int a = 0, b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void *>(iqn_grad_reduce_adam), RA_BT, 0) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void *>(iqn_grad_reduce_adam_xchg), RA_BT, 0) != hipSuccess)
@@ -2232,12 +2260,12 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     if (plan.launches == 1) {      // the fused step: ONE launch for all n_steps
         const StepTail tail = {N_ADAM, plan.n_extra, n_steps, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
                                rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
-        if (x)
-            hipLaunchKernelGGL((iqn_train_fwdbwd<true, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s,
-                               TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail});
-        else
-            hipLaunchKernelGGL((iqn_train_fwdbwd<false, true>), dim3(plan.n_fwd + plan.n_extra), dim3(THREADS), LDS_BYTES, s,
-                               TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail});
+        const TrainArgs ta = {ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail};
+        const dim3 grid(plan.n_fwd + plan.n_extra);
+        if (x && n_steps > 1) hipLaunchKernelGGL((iqn_train_fwdbwd<true, true, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
+        else if (x) hipLaunchKernelGGL((iqn_train_fwdbwd<true, true, false>), grid, dim3(THREADS), LDS_BYTES, s, ta);
+        else if (n_steps > 1) hipLaunchKernelGGL((iqn_train_fwdbwd<false, true, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
+        else hipLaunchKernelGGL((iqn_train_fwdbwd<false, true, false>), grid, dim3(THREADS), LDS_BYTES, s, ta);
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
     if (n_steps > 1) {      // no fused form for this batch / device: the steps one after the other (every later one starts from the batch its predecessor staged)
@@ -2250,7 +2278,7 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
         return MN_OK;
     }
     const StepTail no_tail = {};
-    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s,
+    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s,
                        TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail});
     if (plan.launches == 2 && x)
         hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,

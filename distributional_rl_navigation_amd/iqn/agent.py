@@ -51,7 +51,9 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
         self.shared_taus = False                     # opt-in: one set of 32 taus per act LAUNCH instead of per row (fused_act(shared_taus=True))
         self.use_fused_graph = False                 # opt-in: the fused gradient steps of one training event as one captured hipGraph (train_steps_from_memory)
-        self.use_multi_step = True                   # the gradient steps of one training event as ONE persistent launch (mn_iqn_train_steps; bit-identical to the eager steps)
+        self.use_multi_step = False                  # opt-in: the gradient steps of one training event as ONE persistent launch (mn_iqn_train_steps; bit-identical to the
+                                                     # single steps).  One launch instead of G for the host; on the GPU 33.4 us per step against 32.4 for single fused steps
+                                                     # (round 5: the parameter hand-off between steps costs what the launch boundary did) -- so not the default
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
