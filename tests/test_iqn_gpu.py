@@ -628,15 +628,15 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
 
 def test_launch_plan_follows_the_device_size_and_small_devices_fall_back_bitwise(torch):
     """The fused forms wait inside a launch for other workgroups of the same launch, so the library plans them from the device's CU count, not from the constant
-    256: `mn_iqn_train_set_cu_limit` pretends a smaller device.  Batch 256: the whole MI355X -> one launch; 200 CUs -> still one (every local workgroup
-    computes its own TD targets: 128 forward / backward workgroups); 100 -> two (the 128 local workgroups would not be resident together; the 140 blocks of the
-    reduction + Adam launch are); 8 -> three launches, nothing waits for a sibling.  All bit-identical, no bounded wait ran out."""
+    256: `mn_iqn_train_set_cu_limit` pretends a smaller device.  Batch 256: the whole MI355X -> one launch (256 workgroups, one CU each); 200 or 100 CUs ->
+    two (the fused step's workgroups would not all be resident together; the 140 blocks of the reduction + Adam launch are); 8 -> three launches, nothing waits for a
+    sibling.  All bit-identical, no bounded wait ran out."""
     from distributional_rl_navigation_amd import _capi
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev, L = "cuda:0", _capi.lib()
     runs = []
     try:
-        for limit, want in ((0, 1), (200, 1), (100, 2), (8, 3)):
+        for limit, want in ((0, 1), (200, 2), (100, 2), (8, 3)):
             assert L.mn_iqn_train_set_cu_limit(limit) == 0
             ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
             g = torch.Generator(device=dev); g.manual_seed(5)
@@ -648,7 +648,7 @@ def test_launch_plan_follows_the_device_size_and_small_devices_fall_back_bitwise
             runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone()))
     finally:
         L.mn_iqn_train_set_cu_limit(0)
-    assert L.mn_iqn_train_set_cu_limit(-1) != 0 and L.mn_iqn_train_plan(255, 4, 0) < 0
+    assert L.mn_iqn_train_set_cu_limit(-1) != 0 and L.mn_iqn_train_plan(255, 4, 0) < 0 and L.mn_iqn_train_plan(256, 4, 0) == 1
     a = runs[0]
     assert all(np.isfinite(a[0]))
     for b in runs[1:]:
