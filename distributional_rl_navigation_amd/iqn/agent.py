@@ -7,6 +7,7 @@ This file is the batched code the MI355X path actually runs: `act_batch`, `vec_s
 the fused / pipelined gradient step.  Optional data-parallel training over RCCL:
 one flat 35 785-float gradient bucket, one all_reduce per grad step.
 """
+import json
 import os
 import random
 
@@ -89,6 +90,7 @@ class IQNAgent(ReferenceLoopMixin):
         self.eval_successes = dict(greedy=[], adaptive=[])
         self.eval_times = dict(greedy=[], adaptive=[])
         self.eval_energies = dict(greedy=[], adaptive=[])
+        self.best_eval = None                        # learn_vec: the best greedy evaluation so far (successes, mean return) and when
 
     def _make_adam(self):
         """Adam(lr=1e-4) as agent.py:66; on the GPU the fused single-kernel implementation (same update rule)."""
@@ -388,7 +390,7 @@ class IQNAgent(ReferenceLoopMixin):
     # ---- batched loop on the HIP vector env ----------------------------------------------------------
     def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,
                   eval_log_path=None, total_timesteps=None, world_size=1, cvar=1.0, verbose=True,
-                  train_every=None, on_step=None, report_timestep_scale=1.0):
+                  train_every=None, on_step=None, report_timestep_scale=1.0, eval_adaptive=True):
         """Vectorised agent.py:94-173.  One iteration = one vector step of `train_env` (n_envs env
         steps): act_batch -> mn_step -> replay.add_batch -> mn_reset_done -> (every UPDATE_EVERY vector
         steps) sample + train.  `current_timestep` counts env steps over all ranks, so eps, the
@@ -424,8 +426,18 @@ class IQNAgent(ReferenceLoopMixin):
                 ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
             if evaluate_now:
                 self.check_learner()      # (a device synchronisation; the evaluation below is one anyway)
-                self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
-                self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
+                res = self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
+                if eval_adaptive:
+                    self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
+                # agent.py:140-148 keeps the LATEST network at every evaluation point; the batched run also keeps the BEST greedy evaluation so far beside it
+                # (`best_*`: ~1 run in 12 ends on a checkpoint far below its own best -- profiles/r05_learning_curve.txt)
+                score = (int(sum(res["successes"])), float(np.mean(res["rewards"])))
+                if self.best_eval is None or score > self.best_eval["score"]:
+                    self.best_eval = dict(score=score, timestep=self.eval_timesteps["greedy"][-1], grad_steps=self.grad_steps, vector_step=it)
+                    if eval_log_path is not None:
+                        self.qnetwork_local.save(eval_log_path, prefix="best_")
+                        with open(os.path.join(eval_log_path, "best_evaluation.json"), "w") as f:
+                            json.dump(dict(successes=score[0], n_worlds=len(res["successes"]), mean_return=score[1], **{k: v for k, v in self.best_eval.items() if k != "score"}), f)
                 if eval_log_path is not None:
                     self.qnetwork_local.save(eval_log_path)
             if on_step is not None:

@@ -25,7 +25,8 @@ class ObsEncoder(nn.Module):
 
         self.state_size = state_size
         self.action_size = action_size
-        assert state_size == 26, "observation dimension needs to be 26 (velocity, goal, measurements)"
+        if state_size != 26:
+            raise ValueError(f"ObsEncoder is built for the 26-value marinenav observation (2 velocity + 2 goal + 11 x 2 sonar), got state_size = {state_size}")
         self.velocity_encoder = nn.Linear(2, 16)
         self.goal_encoder = nn.Linear(2, 16)
         self.sensor_encoder = nn.Linear(22, 176)
@@ -56,7 +57,8 @@ class ObsEncoder(nn.Module):
 
     def forward(self, inputs, num_tau=8, cvar=1.0, taus=None):
         """model.py:160-186 -> (quantiles [B, num_tau, A], taus [B, num_tau, 1])."""
-        assert inputs.shape[1] == self.state_size, "input size not equal state size"
+        if inputs.shape[1] != self.state_size:
+            raise ValueError(f"ObsEncoder.forward: rows of {inputs.shape[1]} values, the network takes {self.state_size}")
         batch_size = inputs.shape[0]
         v_features = self.velocity_encoder(inputs[:, :2])
         g_features = self.goal_encoder(inputs[:, 2:4])
@@ -78,22 +80,21 @@ class ObsEncoder(nn.Module):
     def get_constructor_parameters(self):
         return dict(state_size=self.state_size, action_size=self.action_size, seed=self.seed_id)
 
-    def save(self, directory):
-        """model.py:198-207: network_params.pth + constructor_params.json."""
+    def save(self, directory, prefix=""):
+        """The reference's two-file checkpoint (model.py:198-207): `network_params.pth` (state dict) + `constructor_params.json`; `prefix` names a second
+        pair beside it ("best_": the best evaluation so far, `IQNAgent.learn_vec`)."""
         # clone: the parameters may be views of one flat buffer (iqn/fused_train.py); upstream checkpoints hold one
         # independent storage per tensor
-        torch.save({k: v.detach().clone() for k, v in self.state_dict().items()}, os.path.join(directory, "network_params.pth"))
-        with open(os.path.join(directory, "constructor_params.json"), mode="w") as f:
+        torch.save({k: v.detach().clone() for k, v in self.state_dict().items()}, os.path.join(directory, prefix + "network_params.pth"))
+        with open(os.path.join(directory, prefix + "constructor_params.json"), mode="w") as f:
             json.dump(self.get_constructor_parameters(), f)
 
     @classmethod
-    def load(cls, directory, device="cpu"):
-        """model.py:209-225."""
-        model_params = torch.load(os.path.join(directory, "network_params.pth"), map_location=device)
-        with open(os.path.join(directory, "constructor_params.json"), mode="r") as f:
-            constructor_params = json.load(f)
-        constructor_params["device"] = device
-        model = cls(**constructor_params)
-        model.load_state_dict(model_params)
-        model.to(device)
-        return model
+    def load(cls, directory, device="cpu", prefix=""):
+        """Rebuild a network from a checkpoint directory written by `save` or by the reference (model.py:209-225): the constructor arguments from the JSON
+        file, then the weights."""
+        with open(os.path.join(directory, prefix + "constructor_params.json")) as f:
+            kwargs = dict(json.load(f), device=device)
+        net = cls(**kwargs)
+        net.load_state_dict(torch.load(os.path.join(directory, prefix + "network_params.pth"), map_location=device))
+        return net.to(device)

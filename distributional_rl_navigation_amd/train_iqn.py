@@ -99,14 +99,16 @@ def plan_cadence(total_timesteps, eval_freq, n_envs_total, batch, ref_batch=32, 
 
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
               grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0, precision="f64",
-              exchange="collective", shared_taus=False):
+              exchange="collective", shared_taus=False, target_sync_mult=1.0, final_eps=0.05, eval_adaptive=True):
     """train_IQN_model.py:74-121 on the vector env.  `params` is one trial of the reference's config grid
     (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps.
     `precision`: the env kernels' arithmetic.  "f64" (default: every float32 output within 1e-5 of the reference, no
     outliers; measured free while an IQN acts in the loop) or "mixed" (float32 field / sonar decisions).
     `exchange` (shared learner): "collective" = RCCL all-reduce of the flat gradient, "mailbox" = the exchange inside the gradient step's launch (iqn/mailbox.py).
     `shared_taus`: acting draws its 32 quantile fractions once per act launch instead of once per env (opt-in: a different random variable from the
-    reference's per-call draw, model.py:149; A/B on learning in profiles/; the learner's taus are untouched)."""
+    reference's per-call draw, model.py:149; A/B on learning in profiles/; the learner's taus are untouched).
+    `target_sync_mult`, `final_eps`: study knobs (scripts/learning_curve.py) -- the target network is copied every target_sync_mult x the planned number of gradient
+    steps; the exploration floor (agent.py: 0.05).  `eval_adaptive` = False skips the adaptive-CVaR evaluation at the evaluation points (the reference runs both)."""
     import torch
     from .iqn.agent import IQNAgent
     from .marinenav_env.vec_env import VecMarineNavEnv
@@ -144,9 +146,9 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
 
     agent = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
                      seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
-                     UPDATE_EVERY=1, learning_starts=0, rank=rank if shared else 0)
+                     UPDATE_EVERY=1, learning_starts=0, rank=rank if shared else 0, final_eps=final_eps)
     agent.grad_steps_per_update = plan["grad_steps_per_vector_step"]
-    agent.target_sync_grad_steps = plan["target_sync_grad_steps"]
+    agent.target_sync_grad_steps = max(1, int(round(plan["target_sync_grad_steps"] * target_sync_mult)))
     agent.exchange = exchange
     agent.shared_taus = bool(shared_taus)
     if torch_train:
@@ -154,7 +156,7 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     agent.learn_vec(total_vector_steps=plan["vector_steps"], train_env=train_env, eval_env=eval_env, eval_config=eval_config,
                     eval_freq=plan["eval_every_vector_steps"], eval_log_path=exp_dir if writer else None,
                     total_timesteps=plan["vector_steps"] * total, world_size=world, cvar=cvar, verbose=False,
-                    report_timestep_scale=params["total_timesteps"] / (plan["vector_steps"] * total))
+                    report_timestep_scale=params["total_timesteps"] / (plan["vector_steps"] * total), eval_adaptive=eval_adaptive)
     if writer:
         agent.qnetwork_local.save(exp_dir)
     train_env.close()
