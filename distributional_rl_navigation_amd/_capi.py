@@ -113,8 +113,6 @@ SIGNATURES = [
     ("mn_xchg_destroy", C.c_int, [_vp]),
     ("mn_probe_mfma_clock", C.c_int, [C.c_double, _pd, _vp]),
     ("mn_iqn_refresh", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp]),
-    ("mn_iqn_pack_slot", C.c_int, [_vp, C.POINTER(C.c_void_p), _i32, _vp]),
-    ("mn_iqn_select_slot", C.c_int, [_vp, _i32]),
     ("mn_iqn_act", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, C.c_float, _vp, _vp, _i32, _i32, _vp]),
     ("mn_iqn_act_rng", C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _i32, _i32, _vp]),
     ("mn_replay_append", C.c_int, [_vp] * 10 + [_i64, _i64, _i64, _vp]),

@@ -829,9 +829,6 @@ struct mn_iqn_ctx {
     bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
-    uint32_t *slot_sp[2] = {nullptr, nullptr};   // mn_iqn_pack_slot: explicitly managed images of the split-f16 kernel (slot 1 allocated on demand)
-    float *slot_consts = nullptr;           // scale constants scratch of the slot packs
-    int sel_slot = -1;                      // mn_iqn_select_slot: >= 0 = act launches read slot_sp[sel_slot] and never pack
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
@@ -909,9 +906,6 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->h1_sp);
     (void)hipFree(c->timg);
     (void)hipFree(c->taux);
-    (void)hipFree(c->slot_sp[0]);
-    (void)hipFree(c->slot_sp[1]);
-    (void)hipFree(c->slot_consts);
     if (moved) (void)hipSetDevice(cur);
     delete c;
     return MN_OK;
@@ -992,9 +986,8 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     const bool use32 = !quantiles_dev && c->variant == 1;
     if (c->tau_mode != 0) {
         // Launch-shared taus: ONE set of 32 quantile fractions for every environment of the launch (iqn_act_split.h, stage_sh).  Only the
-        // split-f16 kernel has this form; per-row CVaR (adaptive policies) needs per-environment taus; the explicitly managed image slots
-        // of the two-stream loop would pair a lagging image with a layer-1 constant of the live weights.
-        if (c->variant != 2 || cvar_row_dev || c->sel_slot >= 0) return MN_ERR_INVALID;
+        // split-f16 kernel has this form; per-row CVaR (adaptive policies) needs per-environment taus.
+        if (c->variant != 2 || cvar_row_dev) return MN_ERR_INVALID;
         const int pack_blocks = c->dirty_sp ? sp::PACK_BLOCKS : 0;
         if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
         int rng_blocks = 0;
@@ -1028,9 +1021,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     if (use_sp || use_sp32) {
         bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
         uint32_t *image = use_sp32 ? c->packed_sp32 : c->packed_sp;
-        const bool slot = use_sp && c->sel_slot >= 0;      // explicitly managed image (mn_iqn_pack_slot / mn_iqn_select_slot): never packed here
-        if (slot) image = c->slot_sp[c->sel_slot];
-        const int pack_blocks = (dirty_s && !slot) ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
+        const int pack_blocks = dirty_s ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
         if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
@@ -1048,7 +1039,7 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
             if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
             else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
         }
-        if (!slot) dirty_s = false;
+        dirty_s = false;
         if (use_sp32)
             hipLaunchKernelGGL(sp32::iqn_qvals_split32_kernel, dim3(blocks), dim3(512), sp32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
@@ -1092,28 +1083,6 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
                            packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
     if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
-}
-
-extern "C" int mn_iqn_pack_slot(mn_iqn_ctx *c, const float *const *weights, int32_t slot, void *stream) {
-    if (!c || !weights || slot < 0 || slot > 1) return MN_ERR_INVALID;
-    for (int i = 0; i < 14; ++i) if (!weights[i]) return MN_ERR_INVALID;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MN_ERR_INVALID;
-    if (!c->slot_consts && (hipMalloc(reinterpret_cast<void **>(&c->slot_consts), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
-                            hipMemset(c->slot_consts, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return MN_ERR_ALLOC;
-    if (!c->slot_sp[slot] && hipMalloc(reinterpret_cast<void **>(&c->slot_sp[slot]), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
-    const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
-                          weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->slot_consts);
-    hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->slot_consts, c->slot_sp[slot]);
-    return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
-}
-
-extern "C" int mn_iqn_select_slot(mn_iqn_ctx *c, int32_t slot) {
-    if (!c || slot < -1 || slot > 1 || (slot >= 0 && !c->slot_sp[slot])) return MN_ERR_INVALID;
-    c->sel_slot = slot;
-    return MN_OK;
 }
 
 extern "C" int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *stream) {

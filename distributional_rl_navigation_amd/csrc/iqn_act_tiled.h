@@ -125,7 +125,10 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
     extern __shared__ __attribute__((aligned(16))) float lds[];
     u32x4 *lds4 = reinterpret_cast<u32x4 *>(lds);
     const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
+    typedef __attribute__((address_space(3))) u32x4 lds_u4;
+    typedef __attribute__((address_space(1))) u32x4 glb_u4;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, col = lane & 15, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;      // the draws of this call were made by the prep kernel
     const u32x4 *t4 = reinterpret_cast<const u32x4 *>(timg);
     {   // T[0], W3, and the float part gathered from the weight image
@@ -197,14 +200,17 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
     int lbase = lane;      // opaque LDS index base (keeps hipcc from materialising one address register per read)
     asm volatile("" : "+v"(lbase));
     for (int tau = 0; tau < K_TAUS; ++tau) {
-        const int cur = ((tau & 1) ? TL_T1 : TL_T0) + lbase, nxt = ((tau & 1) ? TL_T0 : TL_T1) + tid;
+        const int cur = ((tau & 1) ? TL_T1 : TL_T0) + lbase;
         const bool more = tau + 1 < K_TAUS;
         const u32x4 *tnext = t4 + (size_t)(more ? tau + 1 : tau) * T_U4_PER_TAU + tid;
+        // where this WAVE's 1 KB pieces of the next tile land: LDS-DMA writes wave-uniform base + lane x 16 bytes (round 5: was global -> 8 registers -> ds_write)
+        lds_u4 *nxt_wave = (lds_u4 *)(lds) + ((tau & 1) ? TL_T0 : TL_T1) + 64 * wave_u;
         // layer 2: acc2[mt][c] = T[tau] (Sf f), three f16 products per float32 product.  One software-pipelined stream of 28 steps
         // (K block, output tile): the A operands of step s + 2 are requested from LDS before the six MFMAs of step s are issued, so a
         // wave hides its own LDS latency (the per-tau barrier keeps the waves of a workgroup in step: a partner wave is in the same
-        // phase, not in another one).  The next tau's tile travels global -> registers -> the other LDS buffer in the same stream, one
-        // 16-byte unit per K block (the buffer was last read one iteration ago, before the barrier that ended it).
+        // phase, not in another one).  The next tau's tile travels global -> the other LDS buffer by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+        // ds_write) in the same stream, one 1 KB piece per wave and K block (the buffer was last read one iteration ago, before the barrier that ended it; the
+        // barrier that ends THIS iteration waits for the pieces to land: hipcc puts the vmcnt(0) in front of it).
         f32x4 acc2[4][TC];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
 #define TILED_AHEAD 2
 #endif
         constexpr int NS = 4 * KB2, AHEAD = TILED_AHEAD;
-        u32x4 ah[AHEAD + 1], al[AHEAD + 1], pf[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        u32x4 ah[AHEAD + 1], al[AHEAD + 1];
 #pragma unroll
         for (int s0 = 0; s0 < AHEAD; ++s0) {
             ah[s0] = lds4[cur + (((s0 & 3) * KB2 + (s0 >> 2)) * 2) * 64];
@@ -227,8 +233,9 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
                 ah[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2) * 64];
                 al[slot2] = lds4[cur + (((s2 & 3) * KB2 + (s2 >> 2)) * 2 + 1) * 64];
             }
-            if constexpr (mt == 0 && !(TILED_ABL & 2)) pf[kb & 1] = tnext[kb * 512];                          // next tau, unit kb: requested ...
-            if constexpr (mt == 3 && kb >= 1 && !(TILED_ABL & 2)) { if (more) lds4[nxt + (kb - 1) * 512] = pf[(kb - 1) & 1]; }      // ... and parked seven steps (~42 MFMAs) later
+            if constexpr (mt == 0 && !(TILED_ABL & 2)) {      // next tau, piece kb of this wave
+                if (more) __builtin_amdgcn_global_load_lds((const glb_u4 *)(tnext + kb * 512), nxt_wave + kb * 512, 16, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);      // (left alone hipcc sinks the global load to its use and waits for it there)
             const f16x8 a_h = __builtin_bit_cast(f16x8, ah[slot]), a_l = __builtin_bit_cast(f16x8, al[slot]);
             if constexpr (!(TILED_ABL & 8)) {
@@ -288,8 +295,7 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
             for (int c = 0; c < TC; ++c) hs[c][mt] += (TILED_ABL & 1) ? acc3[mt][c] : relu4s(fma4(acc3[mt][c], sc[c].c3e, bb * sc[c].S3));
         }
         if (!(TILED_ABL & 2)) {
-        if (more) lds4[nxt + (KB2 - 1) * 512] = pf[(KB2 - 1) & 1];      // the last unit of the next tile
-        __syncthreads();      // every wave has read T[tau] and parked its share of T[tau + 1]
+        __syncthreads();      // every wave has read T[tau], and its pieces of T[tau + 1] have landed
         }
     }
 

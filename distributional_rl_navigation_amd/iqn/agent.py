@@ -451,18 +451,6 @@ class IQNAgent(ReferenceLoopMixin):
         if self._fused is not None and self._fused.owns(self):
             self._fused.check_timeouts()
 
-    # vec_step: mn_reset_done on a second HIP stream while the gradient steps of the same vector step run.  Measured (scripts/ab_reset_overlap.sh,
-    # alternating on one GPU): 0.950-0.957 ms per vector step at 16 gradient steps per step against 0.941-0.950 with the reset in front of them on
-    # the one stream, 0.3758 against 0.3735 ms in the main loop -- the two cross-stream dependencies cost more than the ~25 us reset they hide.  Off.
-    overlap_reset = os.environ.get("MN_OVERLAP_RESET", "0") == "1"
-
-    def _reset_stream(self, device):
-        st = getattr(self, "_reset_side_stream", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            self._reset_side_stream = st
-        return st
-
     def vec_step(self, train_env, obs, eps, cvar=1.0, train_every=None, per_iter=None):
         """One iteration of the vectorised loop: act_batch -> mn_step -> replay.add_batch ->
         mn_reset_done -> (cadence permitting) sample + train + target sync.  Everything is enqueued on
@@ -483,21 +471,9 @@ class IQNAgent(ReferenceLoopMixin):
                 self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         loss = None
         due = cadence_tick(self, train_every)      # iqn/cadence.py: agent.py:126-147's rule (+ the target cadence in gradient steps)
-        if due.train and self.overlap_reset and obs.is_cuda:
-            # The resets of the finished envs (a ~20 us dependent chain per env, a few hundred envs) next to the gradient steps instead of in
-            # front of them: the learner reads the replay ring the step just appended to, never the env state or the observation rows the
-            # reset writes, and its launches leave CUs idle (target workgroups end half way, launch boundaries).  Same arithmetic either way.
-            main = torch.cuda.current_stream(obs.device)
-            side = self._reset_stream(obs.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                obs = train_env.reset_done()
-            loss = self.train_steps_from_memory(self.grad_steps_per_update)
-            main.wait_stream(side)
-        else:
-            obs = train_env.reset_done()                                # first observations where done
-            if due.train:
-                loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
+        obs = train_env.reset_done()                                # first observations where done
+        if due.train:
+            loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
         if due.sync:
             self._sync_target()
         if self.current_timestep >= self.learning_starts:

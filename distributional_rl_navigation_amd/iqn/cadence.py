@@ -3,7 +3,7 @@
 The reference's loop (thirdparty/IQN/agent.py:126-147) trains every `UPDATE_EVERY` learning steps once the buffer holds more than a
 batch, hard-copies the target network every `target_update_interval` learning steps, and evaluates + checkpoints every `eval_freq`
 learning steps; all three are tested at the CURRENT `learning_timestep`, which is then advanced.  The single-env adapter
-(`iqn/compat.py: learn`), the batched loop (`iqn/agent.py: vec_step`, `learn_vec`) and the two-stream loop (`iqn/overlap.py`) all ask
+(`iqn/compat.py: learn`), the batched loop (`iqn/agent.py: vec_step`, `learn_vec`) all ask
 `cadence_tick`; the batched loops add a target cadence counted in gradient steps (`target_sync_grad_steps`, `train_iqn.plan_cadence`).
 """
 from collections import namedtuple

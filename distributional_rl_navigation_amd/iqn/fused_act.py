@@ -98,19 +98,6 @@ class ActContext:
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_refresh failed ({rc})")
 
-    def pack_slot(self, net, slot):
-        """Build the split-f16 image of the current weights into slot 0 / 1 on the current stream (mn_iqn_pack_slot)."""
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = _capi.lib().mn_iqn_pack_slot(self.h, self.weights(net), int(slot), stream)
-        if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_pack_slot failed ({rc})")
-
-    def select_slot(self, slot):
-        """Later act launches read image slot 0 / 1 and never pack; -1 = back to the cached image (mn_iqn_select_slot)."""
-        rc = _capi.lib().mn_iqn_select_slot(self.h, int(slot))
-        if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_select_slot failed ({rc})")
-
     def profile_begin(self, max_launches):
         rc = _capi.lib().mn_iqn_profile_begin(self.h, int(max_launches))
         if rc:

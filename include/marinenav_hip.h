@@ -305,13 +305,6 @@ int mn_iqn_set_grid(mn_iqn_ctx *c, int32_t max_workgroups);
  * mn_iqn_weights_changed would do).  For callers that issue act calls of ONE context on several streams: refresh on one stream,
  * make the others wait for it, and no act call has to write the image. */
 int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *stream);
-/* Two explicitly managed weight images of the split-f16 kernel (variant 2), for a learner that updates the weights on one stream
- * while act launches of other streams are in flight: mn_iqn_pack_slot builds the image of the CURRENT weights into slot 0 or 1 on
- * `stream` (stream-ordered after the writer of the weights); mn_iqn_select_slot(slot) makes every later act launch of the context
- * read that slot (and never pack); -1 returns to the cached image.  The caller orders a slot's pack against the act launches that
- * read it (events); launches already issued keep the image they were given. */
-int mn_iqn_pack_slot(mn_iqn_ctx *c, const float *const *weights, int32_t slot, void *stream);
-int mn_iqn_select_slot(mn_iqn_ctx *c, int32_t slot);
 
 /* Fused IQNAgent.act (thirdparty/IQN/agent.py:186-205) for n observations: ObsEncoder.forward with
  * K = 32 quantile samples + mean over them (model.py:141-191), then argmax and the epsilon-greedy choice.
