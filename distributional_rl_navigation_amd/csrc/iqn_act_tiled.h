@@ -199,6 +199,9 @@ __global__ __launch_bounds__(512) void iqn_qvals_tiled_kernel(const float *__res
     static_assert(T_U4_PER_TAU % 512 == 0 && PF == KB2, "prefetch shape: one unit per thread and K block");
     int lbase = lane;      // opaque LDS index base (keeps hipcc from materialising one address register per read)
     asm volatile("" : "+v"(lbase));
+    // (not unrolled: unrolled by two -- hipcc's choice, the buffer toggle becomes a constant -- the kernel needs 15 more registers than there are: 60 bytes of scratch
+    // per lane, 12 MB of spill traffic per launch; round 5: 187 -> 181 us)
+#pragma unroll 1
     for (int tau = 0; tau < K_TAUS; ++tau) {
         const int cur = ((tau & 1) ? TL_T1 : TL_T0) + lbase;
         const bool more = tau + 1 < K_TAUS;
