@@ -418,7 +418,8 @@ def main():
                          distributed=args.shared_learner and use_dist, act_chunk=args.act_chunk,
                          UPDATE_EVERY=args.update_every, rank=rank if args.shared_learner else 0)
         agent.grad_steps_per_update = args.grad_steps
-        agent.use_fused_graph = args.graph_train
+        # (two ranks on one GPU exchange over gloo, i.e. through the host: not capturable -- eager events there)
+        agent.use_fused_graph = args.graph_train and not (args.shared_learner and args.exchange == "collective" and args.ranks_per_gpu > 1)
         agent.shared_taus = args.shared_taus
         agent.exchange = args.exchange
         agent.use_fused_train = not args.torch_train

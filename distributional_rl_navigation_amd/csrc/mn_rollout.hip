@@ -152,7 +152,7 @@ __global__ __launch_bounds__(MN_WAVE, 1) void mn_rollout_policy_kernel(MnArrays 
         action = __shfl(action, (int)(threadIdx.x & (MN_WAVE - 1)) - q);      // from the group's lane 0
         __syncthreads();      // every lane has its action before the step overwrites the row
         float *trow = T.obs ? T.obs + ((size_t)t * n + (ln.active ? e : 0)) * MN_OBS_DIM : nullptr;
-        const MnStepOut o = ln.template step<false>(A, P, action, rows[slot], (PARITY && A.obs64) ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none,
+        const MnStepOut o = ln.template step<false>(A, P, action, rows[slot], (PARITY && A.obs64 && alive) ? A.obs64 + (size_t)e * MN_OBS_DIM : nullptr, none,
                                                     nullptr, nullptr, (alive && trow) ? trow : nullptr);
         if (ln.active && q == 0) {
             const size_t k = (size_t)t * n + e;
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(MN_WAVE, 1) void mn_rollout_policy_kernel(MnArrays 
             }
         }
         // (an env that has finished keeps stepping from its terminal pose -- the lane group's cross-lane work is wave-uniform -- but
-        // nothing of it is stored or traced; its row in LDS no longer feeds a policy call)
+        // nothing of it is stored or traced -- incl. the float64 copies of mn_enable_obs64, which keep the TERMINAL observation and reward --;
+        // its row in LDS no longer feeds a policy call)
         if (!__any(alive)) {      // the whole wave is done: fill the remaining trace entries and leave
             for (int t2 = t + 1; t2 < n_steps; ++t2)
                 if (ln.active && q == 0) {

@@ -57,6 +57,7 @@ class IQNAgent(ReferenceLoopMixin):
                                                      # (round 5: the parameter hand-off between steps costs what the launch boundary did) -- so not the default
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
+        self._graph_bypass_logged = False
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
         # Adam) instead of ~150 PyTorch autograd / Adam kernels; False = the PyTorch path (always used on the CPU)
         self.use_fused_train = torch.device(device).type == "cuda"
@@ -239,8 +240,11 @@ class IQNAgent(ReferenceLoopMixin):
         vector step need to stay ahead of the GPU.  Same arithmetic, same generator stream: bit-identical to the eager calls."""
         # (while the ring is still filling its row count changes with every vector step and each change would be a re-capture +
         # device synchronisation: the eager steps -- bit-identical -- run until the ring is full)
-        if (self.use_fused_graph and self.use_fused_train and self.device.type == "cuda" and n_steps > 1
-                and len(self.memory) >= self.BATCH_SIZE and len(self.memory) == self.memory.capacity):
+        want_graph = self.use_fused_graph and self.use_fused_train and self.device.type == "cuda" and n_steps > 1
+        if want_graph and len(self.memory) < self.memory.capacity and not self._graph_bypass_logged:
+            self._graph_bypass_logged = True
+            print(f"[IQNAgent] use_fused_graph: eager gradient steps until the replay ring is full ({len(self.memory)} of {self.memory.capacity} rows)", flush=True)
+        if want_graph and len(self.memory) >= self.BATCH_SIZE and len(self.memory) == self.memory.capacity:
             m = self.memory
             ft = self._fused_trainer()
             self._enter_train_path("hip")

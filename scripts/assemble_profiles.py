@@ -1,28 +1,88 @@
-"""Copy the summaries scripts/measure_round3.sh left under gpurun_out/m3 into profiles/r03_* (headers kept, bodies replaced)."""
-import os, re, shutil
+"""Copy the summaries scripts/measure_round.sh left under gpurun_out/<measure dir> into profiles/<round tag>_* with headers.
+usage: python scripts/assemble_profiles.py [round tag, default r05] [measure dir, default m5]"""
+import json, os, re, shutil, sys
+RT = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+MD = sys.argv[2] if len(sys.argv) > 2 else 'm5'
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-M, P = R + '/gpurun_out/m3/', R + '/profiles/'
-body = lambda f: open(M + f).read()
-old = open(P + 'r03_full_loop_kernel_stats.txt').read().split('\n')
-hdr = old[:3]
-pm_i = [i for i, l in enumerate(old) if l.startswith('# PMC passes')][0]
-pmc_hdr = old[pm_i:pm_i + 3]
+M, P = R + '/gpurun_out/' + MD + '/', R + '/profiles/' + RT + '_'
+clean = lambda t: '\n'.join(l for l in t.split('\n') if 'amdgpu.ids' not in l and not l.startswith('[W') and 'RCCL version' not in l and 'HIP version' not in l
+                            and 'ROCm version' not in l and 'Hostname ' not in l and 'Librccl path' not in l)
+body = lambda f: clean(open(M + f).read())
 pm = body('pmc_summary.txt')
-def mean(k, c):
-    return float(re.search(r'^%s\s+%s\s+n=\s*\d+ mean=\s*([\d.]+)' % (k, c), pm, re.M).group(1)) / 1e3
-out = '\n'.join(hdr) + '\n' + body('prof_loop_summary.txt').rstrip() + '\n\n' + '\n'.join(pmc_hdr) + '\n' + pm.rstrip() + '\n'
-out += ('# derived (KB = 1000 B): iqn_train_fwdbwd WRITE_SIZE %.1f MB per launch for the 18.3 MB of partial gradients it stores (128 x 35 788 floats, non-temporal\n'
-        '# 16-byte stores), reads 2 x %.2f = %.1f MB; iqn_grad_reduce reads 2 x %.2f = %.1f MB (the partials + the staged batch\'s ring rows); act kernel: %.2f M MFMA-busy\n'
-        '# cycles (372 x 16 x 65 536 = 390.07 M), 2 x %.2f + %.2f = %.1f MB of HBM traffic for 15.5 MB of algorithmic input / output; step kernel (float64,\n'
-        '# with replay append): 2 x %.2f + %.2f = %.1f MB.\n') % (
-    mean('train', 'WRITE_SIZE'), mean('train', 'FETCH_SIZE'), 2 * mean('train', 'FETCH_SIZE'), mean('reduce', 'FETCH_SIZE'), 2 * mean('reduce', 'FETCH_SIZE'),
-    mean('act', 'SQ_VALU_MFMA_BUSY_CYCLES') / 1e3, mean('act', 'FETCH_SIZE'), mean('act', 'WRITE_SIZE'), 2 * mean('act', 'FETCH_SIZE') + mean('act', 'WRITE_SIZE'),
-    mean('step', 'FETCH_SIZE'), mean('step', 'WRITE_SIZE'), 2 * mean('step', 'FETCH_SIZE') + mean('step', 'WRITE_SIZE'))
-open(P + 'r03_full_loop_kernel_stats.txt', 'w').write(out)
-print(out[-520:])
-for src, dst in (('prof_g16_summary.txt', 'r03_train_cadence_kernel_stats.txt'), ('prof_h2_summary.txt', 'r03_two_halves_kernel_stats.txt')):
-    o = open(P + dst).read().split('\n')
-    h = [l for l in o if l.startswith('# r03') or l.startswith('# Kernel durations')]
-    open(P + dst, 'w').write('\n'.join(h) + '\n' + body(src).rstrip() + '\n')
-shutil.copy(M + 'bench_default.json', P + 'r03_bench_default.json')
-shutil.copy(M + 'bench_halves2.json', P + 'r03_bench_halves2.json')
+def mean(txt, k, c):
+    m = re.search(r'^%s\s+%s\s+n=\s*\d+ mean=\s*([\d.]+)' % (k, c), txt, re.M)
+    return float(m.group(1)) / 1e3 if m else float('nan')
+hbm = lambda txt, k: 2 * mean(txt, k, 'FETCH_SIZE') + mean(txt, k, 'WRITE_SIZE')
+
+out = ("# %s: bench.py --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also --no-clock-probe under rocprofv3 --kernel-trace --stats (MI355X, 1 GPU; scripts/measure_round.sh):\n"
+       "# BASELINE configs[2] -- 65 536 envs + IQN training, 1 gradient step every 4 vector steps, float64 env kernels, per-env taus (the default), one batch / one stream.\n"
+       "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is ONE launch: iqn_train_fwdbwd<XCHG = false, FUSED = true, MULTI = false>\n"
+       "# (target / local / reduction + clip + Adam workgroup roles, XCD-grouped).  mn_reset_kernel's average contains the initial all-env resets (max column); in the loop: bench.py's live row.\n") % RT
+out += body('prof_loop_summary.txt').rstrip() + '\n\n'
+out += ("# PMC passes (separate runs, one counter each: rocprofv3 --kernel-trace --pmc <counter>; the same command with --steps 24 --warmup 8 --update-every 1 --grad-steps 4),\n"
+        "# mean per launch; FETCH_SIZE / WRITE_SIZE in KB of 1000 B; HBM bytes = 2 x FETCH_SIZE (gfx950 correction, profiles/r01_pmc_calibration.txt) + WRITE_SIZE\n")
+out += pm.rstrip() + '\n'
+out += ('# derived, per launch: step kernel (float64, with replay append): 2 x %.2f + %.2f = %.1f MB (algorithmic 734 B x 65 536 = 48.1 MB; step only 406 B = 26.6 MB);\n'
+        '# reset kernel: 2 x %.2f + %.2f = %.1f MB (~220 episode ends per vector step at this cadence: 2 048 B algorithmic each = 0.45 MB; the rest is the 2.5 KB MT19937 block read per reset,\n'
+        '# written back when regenerated, and partial lines of the SoA tables);\n'
+        '# act kernel (per-env taus): %.2f M MFMA-busy cycles (372 x 16 x 65 536 = 390.07 M), %.1f M vector-ALU instructions = %.0f per env, %.1f MB;\n'
+        '# gradient step (one launch): %.1f MB (18.3 MB of partial-gradient rows are written once; read back through the XCDs\' L2s).\n') % (
+    mean(pm, 'step', 'FETCH_SIZE'), mean(pm, 'step', 'WRITE_SIZE'), hbm(pm, 'step'),
+    mean(pm, 'reset', 'FETCH_SIZE'), mean(pm, 'reset', 'WRITE_SIZE'), hbm(pm, 'reset'),
+    mean(pm, 'act', 'SQ_VALU_MFMA_BUSY_CYCLES') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') * 1e3 / 65536, hbm(pm, 'act'), hbm(pm, 'train'))
+open(P + 'full_loop_kernel_stats.txt', 'w').write(out)
+
+ps = body('pmc_shared_summary.txt')
+out = ("# %s: the same loop with launch-shared taus (bench.py --shared-taus ...; opt-in): the act kernel is iqn_qvals_tiled_kernel at 65 536 envs (csrc/iqn_act_tiled.h) behind two\n"
+       "# preparation launches (iqn_shared_prep_kernel: the call's draws + the layer-1 constant; iqn_tiled_prep_kernel: T = W2 diag(h1) as hi / lo f16 pairs)\n") % RT
+out += body('prof_shared_summary.txt').rstrip() + '\n\n# PMC passes, act kernel only (mean per launch)\n' + ps.rstrip() + '\n'
+out += ('# derived: %.2f M MFMA-busy cycles (216 x 16 x 65 536 = 226.5 M + the encoders\' exact-f32 MFMAs); %.1f M vector-ALU instructions (matrix instructions included) per launch = %.0f per env\n'
+        '# (per-env-tau kernel: 1 419); WRITE_SIZE %.2f MB (r04: 12.9 MB -- 24 spilled registers per lane; round 5: T streamed by LDS-DMA, tau loop not unrolled, 254 VGPRs, no scratch);\n'
+        '# FETCH 2 x %.1f MB.\n') % (
+    mean(ps, 'act', 'SQ_VALU_MFMA_BUSY_CYCLES') / 1e3, mean(ps, 'act', 'SQ_INSTS_VALU') / 1e3, mean(ps, 'act', 'SQ_INSTS_VALU') * 1e3 / 65536,
+    mean(ps, 'act', 'WRITE_SIZE'), mean(ps, 'act', 'FETCH_SIZE'))
+open(P + 'shared_taus_loop_kernel_stats.txt', 'w').write(out)
+
+out = ("# %s: the cadence that trains -- bench.py --update-every 1 --grad-steps 16 --eps 0.05 (16 gradient steps per vector step) under rocprofv3 --kernel-trace --stats.\n"
+       "# Kernel durations include the launch boundary.  A gradient step = ONE launch of iqn_train_fwdbwd<false, true, false> (reduction + clip + Adam inside, XCD-grouped).\n") % RT
+out += body('prof_g16_summary.txt').rstrip() + '\n'
+open(P + 'train_cadence_kernel_stats.txt', 'w').write(out)
+
+shutil.copy(M + 'bench_default.json', P + 'bench_default.json')
+shutil.copy(M + 'bench_shared_taus.json', P + 'bench_shared_taus.json')
+open(P + 'experiment_sweep.txt', 'w').write(("# %s: scripts/experiment_sweep.py (MI355X): the reference's full comparison, run_experiments.py:213-282 -- IQN x 5 through the fused act kernel,\n"
+    "# DQN through csrc/dqn_act.hip, APF / BA as one mn_rollout_policy launch each\n" % RT) + body('experiment_sweep.txt'))
+
+out = ("# %s: the gradient step by launch form (learner alone, batch 256 drawn in the launch, replay 100 000; MI355X, one box, one session).\n"
+       "# (1) scripts/learner_bench.py 3000: wall clock over 3 000 back-to-back steps.  'mode 1' = every local workgroup computes its own target forward (the fallback of the in-launch TD hand-off).\n"
+       "#     1 launch = iqn_train_fwdbwd<., FUSED> with the reduction + clip + Adam workgroups as its tail role; 2 = iqn_train_fwdbwd + iqn_grad_reduce_adam; 3 = + iqn_grad_reduce, iqn_adam (the RCCL form);\n"
+       "#     persistent = mn_iqn_train_steps: G steps per launch (iqn_train_fwdbwd<., true, MULTI>), bit-identical to G single steps (tests/test_iqn_gpu.py).\n") % RT
+out += body('learner_bench.txt').rstrip() + '\n\n'
+out += "# (2) rocprofv3 --kernel-trace --stats of scripts/learner_prof.py <form> (600 steps each; durations start to start)\n"
+for form, name in ((1, 'one launch per step'), (2, 'two launches per step'), (3, 'three launches per step'), (16, 'persistent 16-step launches')):
+    rows = [l for l in body('prof_learner_%d_summary.txt' % form).split('\n') if 'iqn_' in l]
+    out += '# -- %s\n' % name + '\n'.join(rows) + '\n'
+out += ("\n# (3) scripts/train_multi_phase_timing.py 16 100: 100 MHz stamps of the first local workgroup and target workgroup 0 over the last steps of a 16-step persistent launch (profiling build)\n")
+out += body('train_multi_phase_timing.txt').rstrip() + '\n'
+out += ("#\n# Reading (VERDICT r4 item 3: 'persistent multi-step launch, >= 35 k grad-steps/s' -- closed with numbers, target NOT met).  A step of the persistent launch costs what a\n"
+        "# single fused launch costs plus ~1 us: the launch boundary it removes (~2 us: compare 1 vs 2 launches) is replaced by the hand-off of the freshly written parameters -- 128 tail\n"
+        "# workgroups on 8 XCDs each publish 'my 256 parameters of step k are out' and 128 local workgroups wait for all of them (begins(k+1) - parameters out(k) = 1.5-1.9 us) -- and every\n"
+        "# step's weights have to be read past the L2 (sc1 loads: 'requests out' 5.2-5.3 us against 4.4 in the single launch).  Per step: inputs 5.3, forward 5.8, backward 9.1, row\n"
+        "# acknowledged 1.2, group share 5.0, tail 5.8 (target wg: tail begins -> parameters out: 23 us, of which it waits ~17 for the group rows).  The data dependence Adam(k) -> forward(k+1)\n"
+        "# leaves only the 5 us of inputs to overlap, and doing so changes either the summation order or the step semantics.  So single launches stay the default\n"
+        "# (IQNAgent.use_multi_step = False); the multi-step form is kept for hosts that cannot enqueue 16 launches per vector step, and is what bench.py reports as\n"
+        "# learner_only.fused_hip_g16 / also.train_cadence_multi_step.\n")
+open(P + 'train_step_launches.txt', 'w').write(out)
+
+out = ("# %s: scripts/scale.sh on ONE MI355X (no multi-GPU node was available to the build).  c3 = configs[3] (independent learners), c4 = configs[4] (shared learner, CVaR 0.5, RCCL all-reduce),\n"
+       "# c4t = c4 at the cadence that trains (16 gradient steps per vector step, graphed events), c4m / c4mt = the same two with the in-launch mailbox exchange.\n"
+       "# (1) bash scripts/scale.sh 1 -- N = 1, one rank, RCCL group of one\n") % RT
+out += body('scale_n1.txt').rstrip() + '\n'
+out += ("# (2) RANKS_PER_GPU=2 bash scripts/scale.sh 2 -- bench.py's world > 1 branch under torch.distributed.run with TWO ranks sharing the GPU (gloo for the host-side group: RCCL refuses two\n"
+        "#     ranks per device; the mailbox legs map each other's mailbox over real hipIpc handles).  Each rank steps 65 536 envs, so the GPU does twice the work per vector step: the N = 2\n"
+        "#     rows show that the path runs and what it costs on one device, not scaling.  all_reduce_ms here is the gloo all-reduce through the host.\n")
+out += body('scale_two_ranks_one_gpu.txt').rstrip() + '\n'
+open(P + 'scale.txt', 'w').write(out)
+shutil.copy(M + 'reset_scaling.txt', '/tmp/reset_scaling_session.txt')
+j = json.load(open(M + 'bench_default.json'))
+print(j['value'] / 1e6, j['ms_per_step'], j['roofline']['launch_ms'], j['roofline_env_step']['launch_ms'])

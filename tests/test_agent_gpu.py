@@ -335,27 +335,49 @@ def test_experiment_capture_schema(torch):
     assert isinstance(res["IQN_0.5"]["out_of_area"][0], bool)
 
 
-@pytest.mark.parametrize("precision", ["f64", "mixed"])
-def test_headline_configuration_loop_at_full_size(torch, precision):
+@pytest.mark.parametrize("precision,cvar,shared", [("f64", 1.0, None), ("mixed", 1.0, None), ("f64", 0.5, "collective"), ("f64", 0.5, "mailbox")],
+                         ids=["f64", "mixed", "f64-cvar0.5-shared-collective", "f64-cvar0.5-shared-mailbox"])
+def test_headline_configuration_loop_at_full_size(torch, precision, cvar, shared):
     """(`precision`: "f64" is what bench.py / train_iqn run when an IQN is in the loop -- `bench.default_precision` --, "mixed" the
-    kernel-only configs' arithmetic.)
+    kernel-only configs' arithmetic.  The `shared` cases are ONE RANK's workload of BASELINE configs[4]: CVaR(0.5) action selection and
+    `IQNAgent(distributed=True)` under an RCCL process group -- of one rank here, the box has one GPU -- with the gradient exchange
+    as the RCCL all-reduce between the gradient and Adam launches, or over the mailbox inside the gradient step's one launch.)
     BASELINE configs[2] exactly as bench.py composes it -- 65 536 envs, replay 100 000, batch 256, one gradient step
     every 4 vector steps, fused act / step+append / reset / gradient-step kernels -- run for 24 vector steps with the
     bookkeeping and the data it leaves behind asserted at full size (size-independent properties)."""
-    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
-    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
     n, cap, B, T = 65536, 100_000, 256, 24
     dev = "cuda:0"
+    if shared:
+        import socket
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        _headline_loop(torch, precision, cvar, shared, n, cap, B, T, dev)
+    finally:
+        if shared:
+            dist.destroy_process_group()
+
+
+def _headline_loop(torch, precision, cvar, shared, n, cap, B, T, dev):
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
     env = VecMarineNavEnv(n, seed=0, device=dev, precision=precision)
     env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
-    agent = IQNAgent(26, 9, BATCH_SIZE=B, BUFFER_SIZE=cap, device=dev, seed=100, learning_starts=0, UPDATE_EVERY=4)
+    agent = IQNAgent(26, 9, BATCH_SIZE=B, BUFFER_SIZE=cap, device=dev, seed=100, learning_starts=0, UPDATE_EVERY=4,
+                     distributed=shared is not None)
     assert agent.use_fused_act and agent.use_fused_train
+    if shared:
+        agent.exchange = shared
     before = torch.cat([p.detach().reshape(-1).clone() for p in agent.qnetwork_local.parameters()])
     obs = env.reset()
     losses, dones = [], 0
     for t in range(T):
         prev = obs.clone()
-        obs, reward, done, info, loss = agent.vec_step(env, obs, eps=0.5, per_iter=n)
+        obs, reward, done, info, loss = agent.vec_step(env, obs, eps=0.5, cvar=cvar, per_iter=n)
         assert torch.isfinite(obs).all() and torch.isfinite(reward).all() and ((info != 0) == done.bool()).all()
         dones += int(done.sum())
         if loss is not None:
@@ -375,14 +397,18 @@ def test_headline_configuration_loop_at_full_size(torch, precision):
     after = torch.cat([p.detach().reshape(-1) for p in agent.qnetwork_local.parameters()])
     assert bool(torch.isfinite(after).all()) and float((after - before).abs().max()) > 1e-5        # the learner moved the weights
     assert int(agent._fused.step_dev) == T // 4
+    if shared:
+        agent.check_learner()                                           # no bounded wait of the exchange ran out
+        assert agent._fused.launches_per_step() == (1 if shared == "mailbox" else 3) and agent._fused.timeouts() == 0
     s, ep, tot = env.get_state()
     assert (tot == T).all() and (ep <= T).all()
     # exploration at eps = 0.5 with the library-drawn random numbers of that very call: greedy wherever u > eps, and the
     # greedy action is the argmax of the Q-values under the call's own taus
     from distributional_rl_navigation_amd.iqn.fused_act import fused_act
-    a_mixed = agent.act_batch(obs, 0.5)
+    a_mixed = agent.act_batch(obs, 0.5, cvar)
     d = agent._act_rng.draws(n, 32).clone()
     taus, u = d[:n * 32].view(n, 32), d[n * 32:]
+    assert 0.9 * cvar < float(taus.max()) < cvar                                                # the draws ARE U[0,1) * cvar (model.py:149-153)
     a_greedy = fused_act(agent.qnetwork_local, obs.contiguous(), 0.0, 1.0, taus=taus)
     keep = u > 0.5
     assert torch.equal(a_mixed[keep], a_greedy[keep]) and 0.48 < float(keep.float().mean()) < 0.52
