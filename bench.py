@@ -23,12 +23,16 @@ means is written HERE, not in the line.
   roofline_env_step     `mn_step_kernel<double, ..., APPEND>` (HBM-bound by the north-star): (406 + 328) B per env-step x envs / launch_ms over
                         8 TB/s; frac_step_only counts SURVEY 8(d)'s 406 B alone.  reset: `mn_reset_kernel` of the same vector steps, live events:
                         launch_ms, resets per launch (counted over 16 extra steps after the timed region), bytes per reset = 4 B x MT19937 words an
-                        episode start consumes + the tables / pose / first observation it writes (RESET_BYTES), frac of 8 TB/s
+                        episode start consumes + the tables / pose / first observation it writes (RESET_BYTES), frac of 8 TB/s; on_critical_path false:
+                        the launch ran on the env handle's own stream UNDER the next vector step's act kernel (config.resets; its launch_ms is then the
+                        time beside that kernel's workgroups, not time a vector step waits for); under_act_share: the share of the run's reset launches
+                        the library put there (it keeps them in front while many episodes end per vector step, e.g. right after the initial reset)
   cpu_baseline          the scalar C oracle (oracle/, kind "port") on one host core, bounded sample; cpu_all_cores: one oracle env per host thread;
                         cpu_reference_python: the reference's own MarineNavEnv.step measured where it can be imported
   clock                 mn_probe_mfma_clock (a pure f16 MFMA stream on every CU for ~50 ms) right before / after the timed region, GHz; power: rocm-smi
   also.*                other configurations timed by the same run (N = 1): config1 = BASELINE configs[1] (4 096 envs, random policy, kernels only) per
                         world size (cores_obstacles) and arithmetic: [launch-pair M env steps/s, mn_rollout T=100 M env steps/s, step kernel us];
+                        reset_in_front = the loop with the episode resets in front of the act kernel instead of under it (config.resets);
                         act_exact_f32 = the loop with the exact-f32 MFMA act kernel; shared_learner_ws1 = learner alone, grad-steps/s: one launch per
                         step, the RCCL all-reduce at world size 1 eager / inside captured 16-step graphs, the mailbox exchange inside the one-launch
                         step; act_shared_taus (opt-in: 32 taus per launch instead of per env; tiled = environments in the MFMA columns, wave = wavefront
@@ -200,8 +204,14 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
     for (nc, no, md) in ((8, 10, 40.0), (8, 5, 25.0), (4, 6, 30.0)):
         worlds[f"{nc}_{no}"] = {prec: config1(nc, no, md, prec) for prec in ("f64", "mixed")}
     out["config1"] = dict(worlds, envs=n1, row="[launch pairs M/s, mn_rollout T=100 M/s, step kernel us]")
-    # (a) exact-f32 act kernel
+    # (a0) the loop with the episode resets IN FRONT of the act kernel (the default runs them under it: IQNAgent.reset_under_act)
     steps, warm = max(20, args.steps // 2), 10
+    if agent.reset_under_act:
+        agent.reset_under_act = False
+        dt, obs = _timed(device, loop_step, steps, warm, obs)
+        agent.reset_under_act = True
+        out["reset_in_front"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps}
+    # (a) exact-f32 act kernel
     ctx.set_variant(0)
     dt, obs = _timed(device, loop_step, steps, warm, obs, lambda: ctx.profile_begin(min(steps, 50)))
     act_ms, _ = ctx.profile_end()
@@ -357,6 +367,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra driver-timed legs (`also`) after the main timed region")
     ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2, 3), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout, 3 = split-f16 on 32x32x16 tiles")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
+    ap.add_argument("--reset-in-front", action="store_true", help="episode resets in front of the act kernel (mn_reset_done) instead of under it "
+                                                                  "(mn_reset_done_async + late rows; IQNAgent.reset_under_act, the default)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
                                                                "timed by the default run as also.act_shared_taus)")
@@ -421,6 +433,7 @@ def main():
         # (two ranks on one GPU exchange over gloo, i.e. through the host: not capturable -- eager events there)
         agent.use_fused_graph = args.graph_train and not (args.shared_learner and args.exchange == "collective" and args.ranks_per_gpu > 1)
         agent.shared_taus = args.shared_taus
+        agent.reset_under_act = not args.reset_in_front
         agent.exchange = args.exchange
         agent.use_fused_train = not args.torch_train
         if args.torch_act:
@@ -539,6 +552,11 @@ def main():
     timeouts = None
     if agent is not None and getattr(agent, "_fused", None) is not None:
         timeouts = agent._fused.timeouts()      # bounded waits that ran out (0: every step updated; a shared learner's ranks agree)
+    late_to = None
+    if agent is not None and agent.reset_under_act and agent.use_fused_act:
+        from distributional_rl_navigation_amd.iqn.fused_act import late_timeouts
+        env.join_reset()
+        late_to = late_timeouts(agent.qnetwork_local)      # act rows taken before their reset had finished (0: the reset launch ran beside the act kernel)
     also = {}
     if world == 1 and not args.no_also and agent is not None and fused and not roll and not args.torch_train and not args.torch_act:
         also = also_legs(args, env, agent, obs, device, total_timesteps, use_dist)
@@ -595,7 +613,10 @@ def main():
         rb = RESET_BYTES.get((args.cores, args.obstacles))
         if reset_launches and reset_ms > 0 and resets_per_step:
             gbs = (rb * resets_per_step / (reset_ms * 1e-3) / 1e9) if rb else None
-            env_roof["reset"] = {"kernel": "mn_reset_kernel", "launch_ms": reset_ms, "launches_timed": reset_launches, "resets_per_launch": resets_per_step,
+            under = agent is not None and agent.reset_under_act
+            rl = env.reset_launches
+            env_roof["reset"] = {"kernel": "mn_reset_under_act_kernel" if under else "mn_reset_kernel", "on_critical_path": not under,
+                                 "under_act_share": (rl[1] / max(1, rl[0] + rl[1])) if under else 0.0, "launch_ms": reset_ms, "launches_timed": reset_launches, "resets_per_launch": resets_per_step,
                                  "bytes_per_reset": rb, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,
                                  "traffic_mb_profiled": PMC_TRAFFIC_MB["reset_f64"] if (headline and args.precision == "f64") else None}
         out = {
@@ -622,6 +643,8 @@ def main():
                 "process_group": dist.get_backend() if use_dist else None, "ranks_per_gpu": rpg,
                 "eps": None if agent is None else (sum(eps_seen[-args.steps:]) / max(1, len(eps_seen[-args.steps:]))),
                 "act_variant": args.act_variant, "taus": "shared" if args.shared_taus else "per_env",
+                "resets": None if agent is None else ("under_next_act" if agent.reset_under_act else "in_front_of_act"),
+                "late_row_timeouts": late_to,
                 "launches_per_grad_step": agent._fused.launches_per_step() if (agent is not None and getattr(agent, "_fused", None) is not None) else None,
                 "ablation": bool(_capi.lib().mn_build_info() & 1),
             },

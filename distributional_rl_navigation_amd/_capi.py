@@ -66,6 +66,9 @@ SIGNATURES = [
     ("mn_rollout", C.c_int, [_vp, _i32, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _pf, _pf, _pf, _pu8, _pu8, _vp, _vp]),
     ("mn_random_actions", C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, _i32, _vp, _vp]),
     ("mn_reset_done", C.c_int, [_vp, _pf, _vp]),
+    ("mn_reset_done_async", C.c_int, [_vp, _pf, _vp, C.POINTER(_vp), C.POINTER(C.c_uint32)]),
+    ("mn_reset_join", C.c_int, [_vp, _vp]),
+    ("mn_set_reset_under_act_max", C.c_int, [_vp, _i32, C.POINTER(C.c_int64)]),
     ("mn_load_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _pf, _vp]),
     ("mn_get_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd]),
     ("mn_get_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
@@ -86,6 +89,8 @@ SIGNATURES = [
     ("mn_iqn_set_variant", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_grid", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_tau_mode", C.c_int, [_vp, _i32]),
+    ("mn_iqn_set_late_rows", C.c_int, [_vp, _vp, _vp, C.c_uint32, _i32]),
+    ("mn_iqn_late_timeouts", C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
     ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
     ("mn_iqn_train_step", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32,
                                     _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),

@@ -829,6 +829,8 @@ struct mn_iqn_ctx {
     bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
+    sp::LateRows late = {};                 // mn_iqn_set_late_rows: consumed by the next launch
+    uint32_t *late_status = nullptr;        // waits of late rows that ran out (device word)
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
@@ -853,6 +855,8 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(v32::iqn_qvals32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, false, sp::WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
@@ -906,6 +910,7 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->h1_sp);
     (void)hipFree(c->timg);
     (void)hipFree(c->taux);
+    (void)hipFree(c->late_status);
     if (moved) (void)hipSetDevice(cur);
     delete c;
     return MN_OK;
@@ -960,6 +965,41 @@ extern "C" int mn_iqn_profile_end(mn_iqn_ctx *c, void *stream, double *mean_ms, 
     return MN_OK;
 }
 
+// The acting kernel that takes late rows: split-f16, per-environment taus, no quantile capture, at most 64 rows per wavefront.
+static bool late_rows_supported(const mn_iqn_ctx *c, int n, bool quantiles) {
+    if (c->variant != 2 || c->tau_mode != 0 || quantiles || n <= 0) return false;
+    int blocks = (n + 7) / 8;
+    const int cap = c->max_blocks > 0 ? c->max_blocks : c->n_cu;
+    if (blocks > cap) blocks = cap;
+    return (long)n <= 64L * 8L * blocks;
+}
+
+// Rows of the next act launch whose observation is still being written by a reset launch on another stream (mn_reset_done_async):
+// `mask_dev` [n] (the step's done flags), `flags_dev` [n] / `tick` from mn_reset_done_async.  Returns MN_OK if the next launch of `n` rows will
+// take them (then launch it with nothing in between), 1 if this context's current form cannot -- the caller then joins the reset (mn_reset_join) first.
+extern "C" int mn_iqn_set_late_rows(mn_iqn_ctx *c, const uint8_t *mask_dev, const uint32_t *flags_dev, uint32_t tick, int32_t n) {
+    if (!c) return MN_ERR_INVALID;
+    c->late = sp::LateRows{};
+    if (!mask_dev && !flags_dev) return MN_OK;      // clear
+    if (!mask_dev || !flags_dev) return MN_ERR_INVALID;
+    if (!late_rows_supported(c, n, false)) return 1;
+    if (!c->late_status) {
+        if (hipMalloc(reinterpret_cast<void **>(&c->late_status), sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
+        if (hipMemset(c->late_status, 0, sizeof(uint32_t)) != hipSuccess) return MN_ERR_HIP;
+    }
+    c->late = sp::LateRows{mask_dev, flags_dev, tick, c->late_status};
+    return MN_OK;
+}
+
+// Waits for a late row that ran out since the context was made (0 in a healthy run; anything else: actions were computed on unfinished observations).
+extern "C" int mn_iqn_late_timeouts(mn_iqn_ctx *c, void *stream, uint32_t *out) {
+    if (!c || !out) return MN_ERR_INVALID;
+    *out = 0;
+    if (!c->late_status) return MN_OK;
+    if (hipMemcpyAsync(out, c->late_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MN_ERR_HIP;
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
 static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,
                       const float *explore_u_dev, float eps, int32_t *actions_dev, float *quantiles_dev, int32_t n,
                       int32_t num_taus, uint64_t *rng_state_dev, float *draws_dev, const float *cvar_row_dev, float cvar,
@@ -977,6 +1017,10 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     const int cap = c->max_blocks > 0 ? c->max_blocks : c->n_cu;
     if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
+    // late rows (mn_iqn_set_late_rows) belong to THIS launch only; a form that cannot honour them must never see them (the caller joined the reset instead)
+    const sp::LateRows late = c->late;
+    c->late = sp::LateRows{};
+    if (late.mask && !late_rows_supported(c, n, quantiles_dev != nullptr)) return MN_ERR_INVALID;
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
     // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 1 = exact-f32 32x32x2 kernel, 2 = split-f16 kernel
@@ -1046,9 +1090,12 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         else if (quantiles_dev)
             hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<true>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)nullptr);
+        else if (late.mask)
+            hipLaunchKernelGGL((sp::iqn_qvals_split_kernel<false, false, sp::WAVES, true>), dim3(blocks), dim3(512), sp::LDS_ACT_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)nullptr, late);
         else
-            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<false>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)nullptr);
+            hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<false>, dim3(blocks), dim3(512), sp::LDS_ACT_FLOATS * sizeof(float), s, obs_dev, taus_dev,
+                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, (float *)nullptr, (const float *)nullptr, sp::LateRows{});
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }

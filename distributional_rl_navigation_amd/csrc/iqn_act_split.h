@@ -81,6 +81,7 @@ constexpr int OFF_W4H = OFF_BE + F;                     // [2 kb][piece][64 l] x
 constexpr int OFF_FB = OFF_W4H + 2 * 2 * 64 * 4;        // [waves][208] per-wave scaled features
 constexpr int WAVES = 8;                                // one 512-thread workgroup per CU, two waves per SIMD
 constexpr int LDS_FLOATS = OFF_FB + WAVES * F;
+constexpr int LDS_ACT_FLOATS = OFF_W4H + WAVES * F;       // acting form (no quantile output): the feature buffers take the place of the output layer's MFMA operands
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS image of the split-f16 act kernel must fit the CU's 160 KB");
 static_assert(OFF_WS % 4 == 0 && OFF_WVG % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0 && OFF_CST % 4 == 0 && OFF_W4H % 4 == 0, "16-byte aligned blocks");
 constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;       // one thread per 32-bit word of the image
@@ -831,24 +832,45 @@ __device__ __forceinline__ void tail(const u32x4 *__restrict__ lds4, const f32x4
 //                16-row tile), the [n][32][9] quantile values are written out and Q is their mean.
 // SHARED = true : launch-shared taus (see stage_sh): `taus` is unused, `h1` is the launch's layer-1 constant (iqn_shared_prep_kernel).
 // NW = wavefronts per workgroup (one workgroup per CU): 8 = two per SIMD; the shared-tau form needs ~155 registers and also runs three per SIMD.
-template <bool QUANT, bool SHARED = false, int NW = WAVES>
+// LATE = true : rows whose observation is still being written when the launch starts (the episode resets of the vector step, running on
+//                another stream under this kernel: mn_reset_done_async) are taken LAST by their wavefront, each after its "row is final"
+//                word (`late_flag[e] == tick`, written by the reset wave behind its write-through row) has arrived; `late_mask` = the
+//                step's done flags.  Same arithmetic, same results; a wavefront handles at most 64 rows in this form (launch_act checks).
+struct LateRows {
+    const uint8_t *mask;       // [n] != 0: the row is rewritten by the reset running beside this launch
+    const uint32_t *flag;      // [n] == tick once it has been
+    uint32_t tick;
+    uint32_t *status;          // += 1 per wait that ran out (then the row is taken as it is: the caller raises)
+};
+constexpr uint64_t LATE_BOUND_TICKS = 50000000ull;      // 0.5 s of the 100 MHz counter
+
+template <bool QUANT, bool SHARED = false, int NW = WAVES, bool LATE = false>
 __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
                                                                  const uint32_t *__restrict__ packed, float *__restrict__ qvals,
                                                                  const float *__restrict__ explore_u, float eps,
                                                                  int32_t *__restrict__ actions, int n, uint64_t *__restrict__ rng_state,
-                                                                 float *__restrict__ quantiles, const float *__restrict__ h1 = nullptr) {
+                                                                 float *__restrict__ quantiles, const float *__restrict__ h1 = nullptr,
+                                                                 const LateRows late = {}) {
+    static_assert(!LATE || (!QUANT && !SHARED), "late rows: the acting form with per-environment taus");
+#ifndef SP_LATE_PRIO
+#define SP_LATE_PRIO 0
+#endif
+    if constexpr (LATE) __builtin_amdgcn_s_setprio(SP_LATE_PRIO);      // the reset wavefronts that share these SIMDs take the issue slots this kernel leaves
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by the prep kernel
+    // the acting form has no use for the output layer's MFMA operands (act_eval's quantiles): its feature buffers sit there, and the 4 KB
+    // that frees are what lets a reset workgroup (3.1 KB of LDS) share the CU with this one
+    constexpr int IMG = QUANT ? OFF_FB : OFF_W4H;
     {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(packed);
         u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
         if constexpr (SHARED) {      // the layer-1 constant takes the place of the layer-1 weights
             const u32x4 *hsrc = reinterpret_cast<const u32x4 *>(h1);
             for (int i = tid; i < H1_FLOATS / 4; i += blockDim.x) dst[i] = hsrc[i];
-            for (int i = W2_U4 + tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+            for (int i = W2_U4 + tid; i < IMG / 4; i += blockDim.x) dst[i] = src[i];
         } else {
-            for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
+            for (int i = tid; i < IMG / 4; i += blockDim.x) dst[i] = src[i];
         }
     }
     __syncthreads();
@@ -859,7 +881,7 @@ __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *_
     const u32x4 *lds4 = reinterpret_cast<const u32x4 *>(lds);
     LdsBase lb;
     // per-wave feature buffer: behind the image; shared-tau form: in the rest of the W1 region, behind the layer-1 constant
-    constexpr int FB0 = SHARED ? H1_FLOATS : OFF_FB;
+    constexpr int FB0 = SHARED ? H1_FLOATS : IMG;
     static_assert(!SHARED || H1_FLOATS + NW * F <= W2_U4 * 4, "feature buffers of the shared-tau kernel fit into the W1 region");
     static_assert(SHARED || NW <= WAVES, "feature buffers behind the image: WAVES of them");
     lb.w_lo = lane; lb.w_hi = lane + 4096; lb.fl = (OFF_B1 >> 2) + g; lb.fb = ((FB0 + wave * F) >> 2) + g;
@@ -886,10 +908,24 @@ __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *_
     CosJob cj;
     cj.hk0 = hk0;
     const int e_first = blockIdx.x * waves_per_block + wave, e_stride = gridDim.x * waves_per_block;
-    if (!SHARED && e_first < n) {
+    // LATE: the wave's rows as two bit sets (bit k = row e_first + k e_stride): final observations first, late ones last
+    [[maybe_unused]] unsigned long long rows_now = 0, rows_late = 0;
+    [[maybe_unused]] bool is_late = false;
+    int e0 = e_first;
+    if constexpr (LATE) {
+        const int e_l = e_first + lane * e_stride;
+        const bool v = e_l < n, l = v && late.mask[v ? e_l : 0] != 0;
+        const unsigned long long mv = __ballot(v), ml = __ballot(l);
+        rows_now = mv & ~ml; rows_late = ml;
+        if (rows_now) { const int k = __builtin_ctzll(rows_now); rows_now &= rows_now - 1; e0 = e_first + k * e_stride; }
+        else if (rows_late) { const int k = __builtin_ctzll(rows_late); rows_late &= rows_late - 1; e0 = e_first + k * e_stride; is_late = true; }
+        else e0 = n;
+        e0 = __builtin_amdgcn_readfirstlane(e0);
+    }
+    if (!SHARED && e0 < n) {
         float tau[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e_first * K_TAUS + 16 * nt + col];
+        for (int nt = 0; nt < NT; ++nt) tau[nt] = taus[(size_t)e0 * K_TAUS + 16 * nt + col];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -905,13 +941,23 @@ __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *_
                 cbl[kb][nt] = cat4(l[0], l[1], l[2], l[3]);
             }
     }
-    for (int e = e_first; e < n; e += e_stride) {
+    int e_follow = n;      // LATE: the row after `e` (n: none)
+    [[maybe_unused]] bool follow_late = false;
+    for (int e = e0; e < n; e = LATE ? e_follow : e + e_stride) {
         [[maybe_unused]] unsigned long long tk[16];
 #define SP_TICK(i) do { if (SP_ABL & 64) { __builtin_amdgcn_sched_barrier(0); tk[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
         SP_TICK(0);
         const float u_explore = (explore_u && eps > 0.f) ? explore_u[__builtin_amdgcn_readfirstlane(e)] : 2.0f;     // used ~10 us later
+        [[maybe_unused]] const bool late_row = is_late;
+        if constexpr (LATE) {
+            e_follow = n; follow_late = false;
+            if (rows_now) { const int k = __builtin_ctzll(rows_now); rows_now &= rows_now - 1; e_follow = e_first + k * e_stride; }
+            else if (rows_late) { const int k = __builtin_ctzll(rows_late); rows_late &= rows_late - 1; e_follow = e_first + k * e_stride; follow_late = true; }
+            e_follow = __builtin_amdgcn_readfirstlane(e_follow);
+            is_late = follow_late;
+        }
         if constexpr (!SHARED) {   // the next environment's taus (the last iteration re-reads its own: straight-line code); consumed from stage 5 on
-            const int e_nx = e + e_stride < n ? e + e_stride : e;
+            const int e_nx = LATE ? (e_follow < n ? e_follow : e) : (e + e_stride < n ? e + e_stride : e);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) cj.tau[nt] = taus[(size_t)e_nx * K_TAUS + 16 * nt + col];
         }
@@ -921,8 +967,23 @@ __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *_
         {
             const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
             float ov[28];
+            if (LATE && late_row) {      // (wave-uniform) wait for the reset wave's "row is final" word, then read the row past the caches
+                const uint32_t *fp = late.flag + __builtin_amdgcn_readfirstlane(e);
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != late.tick) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > LATE_BOUND_TICKS) {
+                        if (lane == 0) atomicAdd(late.status, 1u);
+                        break;
+                    }
+                }
+                const uint32_t x = __hip_atomic_load(reinterpret_cast<const uint32_t *>(orow) + (lane < OBS ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)x, i)) : 0.f;
+            } else {
 #pragma unroll
             for (int i = 0; i < 28; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
+            }
             EncState st;
             static_for<N_ENC_SUB>([&](auto I_) { enc_substep<decltype(I_)::value>(lds, ldsv, enc_w, enc_f, lane, ov, st); });
             sc = env_scale(st.bnd, a2, d2, a3, d3);

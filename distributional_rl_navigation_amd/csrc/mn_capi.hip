@@ -28,6 +28,16 @@ struct mn_handle {
     int prof_max = 0, prof_n = 0;
     std::vector<hipEvent_t> ev_reset;      // ... and around mn_reset_done (mn_profile_reset_end)
     int prof_reset_n = 0;
+    // mn_reset_done_async: the reset launch on the handle's own stream, under the caller's next act kernel
+    hipStream_t side = nullptr;
+    hipEvent_t ev_stepped = nullptr, ev_reset_end = nullptr;
+    uint32_t *ready = nullptr;             // [n] "first observation is final" words (value = tick of the reset that wrote it)
+    uint32_t tick = 0;
+    bool reset_pending = false;            // a reset launched by mn_reset_done_async has not been joined by the caller's stream yet
+    // decaying peak of the episodes the queue-driven reset launches start (mn_reset.hip: mn_note_count): device word + host-mapped copy (read without synchronising)
+    volatile uint32_t *seen_host = nullptr;
+    uint32_t *seen_dev = nullptr, *peak_dev = nullptr;
+    int32_t under_act_max = 384;           // mn_reset_done_async: above this peak the reset runs in front of the act kernel
 };
 
 static thread_local std::string g_create_err;
@@ -59,7 +69,19 @@ static int on_device(mn_handle *h) {
         snprintf(b, sizeof(b), "handle lives on HIP device %d but the calling thread's current device is %d", h->device, cur);
         return fail(h, MN_ERR_INVALID, b);
     }
+    // an asynchronous reset (mn_reset_done_async) that the caller's stream has not joined: whatever this entry point is about to do with the
+    // handle's state must come after it.  The per-step entry points join on their stream (join_reset) before they get here; the others wait on the host.
+    if (h->reset_pending) {
+        if (hipEventSynchronize(h->ev_reset_end) != hipSuccess) return fail(h, MN_ERR_HIP, "waiting for the asynchronous reset failed");
+        h->reset_pending = false;
+    }
     return MN_OK;
+}
+// stream-side join: everything enqueued on `s` from here on runs after the asynchronous reset
+static void join_reset(mn_handle *h, hipStream_t s) {
+    if (h && h->reset_pending) {
+        if (hipStreamWaitEvent(s, h->ev_reset_end, 0) == hipSuccess) h->reset_pending = false;
+    }
 }
 #define MN_ON_DEVICE(h) do { int _rc = on_device(h); if (_rc) return _rc; } while (0)
 
@@ -152,6 +174,10 @@ extern "C" int mn_destroy(mn_handle *h) {
     if (moved) (void)hipSetDevice(h->device);   // free on the owning device, then restore the caller's
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev_reset) (void)hipEventDestroy(e);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->ev_stepped) (void)hipEventDestroy(h->ev_stepped);
+    if (h->ev_reset_end) (void)hipEventDestroy(h->ev_reset_end);
+    if (h->seen_host) (void)hipHostFree((void *)h->seen_host);
     for (void *p : h->allocs) (void)hipFree(p);
     if (moved) (void)hipSetDevice(cur);
     delete h;
@@ -291,8 +317,9 @@ extern "C" int mn_reset(mn_handle *h, const uint8_t *mask_dev, float *obs_dev, v
 static int step_common(mn_handle *h, const int32_t *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
                        uint8_t *info_dev, const MnRing *ring, void *stream) {
     if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return MN_ERR_INVALID;
-    MN_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
+    join_reset(h, s);
+    MN_ON_DEVICE(h);
     const int parity = h->step_parity;
     const bool prof = h->prof_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev[2 * h->prof_n], s);
@@ -387,12 +414,82 @@ extern "C" int mn_set_debug_skip(mn_handle *h, int32_t mask) {
 }
 #endif
 
+// mn_reset_done on the handle's own stream, so that it runs UNDER whatever the caller enqueues next on `stream` -- in the training loop the act
+// kernel of the next vector step, which is told which rows are still being written (mn_iqn_set_late_rows: the step's done flags, `*ready_out`,
+// `*tick_out`) and takes them last.  The caller's stream is joined again by mn_reset_join, or by the next per-step entry point of this handle.
+// Beside the act kernel's workgroups a CU has room for ONE reset wavefront (LDS), which runs ~4 x slower there: that hides a few hundred resets
+// (a latency chain that leaves the chip idle when it runs alone) but not thousands.  So the launch goes under the act kernel only while the last
+// reset launch the host has seen started at most `under_act_max` episodes (mn_set_reset_under_act_max; the count arrives through a host-mapped word,
+// no synchronisation); otherwise this IS mn_reset_done and *ready_out is NULL.
+extern "C" int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, const uint32_t **ready_out, uint32_t *tick_out) {
+    if (!h || !obs_dev || !ready_out || !tick_out) return MN_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    join_reset(h, s);
+    MN_ON_DEVICE(h);
+    if (!h->side) {
+        MN_HIP(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        MN_HIP(h, hipEventCreateWithFlags(&h->ev_stepped, hipEventDisableTiming));
+        MN_HIP(h, hipEventCreateWithFlags(&h->ev_reset_end, hipEventDisableTiming));
+        int rc = dev_alloc(h, &h->ready, (size_t)h->A.npad);
+        if (rc) return rc;
+        void *hp = nullptr;
+        MN_HIP(h, hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped));
+        h->seen_host = (volatile uint32_t *)hp;
+        *h->seen_host = 0xffffffffu;      // nothing seen yet: the first launches run in front
+        MN_HIP(h, hipHostGetDevicePointer((void **)&h->seen_dev, hp, 0));
+        rc = dev_alloc(h, &h->peak_dev, 1);
+        if (rc) return rc;
+    }
+    *ready_out = nullptr;
+    *tick_out = 0;
+    // the estimate: the launches' own decaying peak of their episode counts, as of the last launch whose word has arrived (the host may run several
+    // launches ahead of the device) -- a burst of episode ends keeps the resets in front for ~20 vector steps
+    const uint32_t seen = *h->seen_host;
+    if (h->under_act_max < 0 || (h->under_act_max != 0x7fffffff && (seen == 0xffffffffu || seen > (uint32_t)h->under_act_max))) {
+        const bool prof = h->prof_reset_n < h->prof_max;
+        if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], s);
+        mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, s, h->peak_dev, h->seen_dev);
+        if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], s); h->prof_reset_n++; }
+        MN_HIP(h, hipGetLastError());
+        return MN_OK;
+    }
+    MN_HIP(h, hipEventRecord(h->ev_stepped, s));
+    MN_HIP(h, hipStreamWaitEvent(h->side, h->ev_stepped, 0));
+    h->tick += 1;
+    const bool prof = h->prof_reset_n < h->prof_max;
+    if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], h->side);
+    mn_launch_reset_under_act(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, h->A.queue, obs_dev, h->ready, h->tick, h->peak_dev, h->seen_dev, h->side);
+    if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], h->side); h->prof_reset_n++; }
+    MN_HIP(h, hipGetLastError());
+    MN_HIP(h, hipEventRecord(h->ev_reset_end, h->side));
+    h->reset_pending = true;
+    *ready_out = h->ready;
+    *tick_out = h->tick;
+    return MN_OK;
+}
+
+// under_act_max: mn_reset_done_async launches under the next act kernel while the decaying peak of the episodes started per reset launch (as of the last
+// launch seen) is at most this (default 384; 0x7fffffff: always, -1: never).  *last_seen: that peak (-1: none seen yet).
+extern "C" int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, int64_t *last_seen) {
+    if (!h) return MN_ERR_INVALID;
+    h->under_act_max = under_act_max;
+    if (last_seen) *last_seen = (h->seen_host && *h->seen_host != 0xffffffffu) ? (int64_t)*h->seen_host : -1;
+    return MN_OK;
+}
+
+extern "C" int mn_reset_join(mn_handle *h, void *stream) {
+    if (!h) return MN_ERR_INVALID;
+    join_reset(h, (hipStream_t)stream);
+    return h->reset_pending ? fail(h, MN_ERR_HIP, "hipStreamWaitEvent failed") : MN_OK;
+}
+
 extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
     if (!h || !obs_dev) return MN_ERR_INVALID;
+    join_reset(h, (hipStream_t)stream);
     MN_ON_DEVICE(h);
     const bool prof = h->prof_reset_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], (hipStream_t)stream);
-    mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream);
+    mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream, h->peak_dev, h->seen_dev);
     if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], (hipStream_t)stream); h->prof_reset_n++; }
     MN_HIP(h, hipGetLastError());
     return MN_OK;

@@ -99,8 +99,10 @@ void mn_launch_rollout_policy(const MnArrays &A, const MnDev &P, int precision, 
                               float *reward_trace, uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s);
 void mn_launch_planner_act(const float *obs, int n, int policy, const double *a, const double *w, int32_t *actions, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
+void mn_launch_reset_under_act(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, const int32_t *list_dev, float *obs,
+                               uint32_t *ready, uint32_t tick, uint32_t *peak_dev, uint32_t *peak_host, hipStream_t s);
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
-                     const int32_t *list_dev, int mode, float *obs, hipStream_t s);
+                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev = nullptr, uint32_t *peak_host = nullptr);
 void mn_launch_seed(const MnArrays &A, const uint32_t *seeds_dev, hipStream_t s);
 void mn_launch_mask_to_queue(const MnArrays &A, const uint8_t *mask, uint32_t *count, int32_t *list, hipStream_t s);
 void mn_launch_peek(const MnArrays &A, int first, int count, double *out_dev, hipStream_t s);

@@ -9,15 +9,44 @@
 
 namespace {
 
+// `seen` (may be NULL): {device word, host-mapped word}.  Every queue-driven reset launch updates a decaying peak of the number of episodes it starts,
+// peak <- max(count, peak - peak / 8), in the device word and copies it to the host-mapped one, which the host reads WITHOUT synchronising: its estimate
+// of how many episodes end per vector step (mn_reset_done_async decides with it where the next reset runs).  Launches of one handle are sequential.
+struct MnSeen { uint32_t *peak_dev; uint32_t *peak_host; };
+__device__ __forceinline__ void mn_note_count(const MnSeen seen, uint32_t count) {
+    if (seen.peak_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t p = *seen.peak_dev;
+        p -= p >> 3;
+        p = p > count ? p : count;
+        *seen.peak_dev = p;
+        __hip_atomic_store(seen.peak_host, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 template <typename M, bool PARITY>
 __global__ __launch_bounds__(MN_WAVE) void mn_reset_kernel(MnArrays A, MnDev P, const uint32_t *__restrict__ count_dev,
                                                            uint32_t count_host, const int32_t *__restrict__ list, int mode,
-                                                           float *__restrict__ obs_out) {
+                                                           float *__restrict__ obs_out, const MnSeen seen) {
     __shared__ MtLds S;
     __shared__ WorldLds W;
     const uint32_t count = count_dev ? *count_dev : count_host;
+    mn_note_count(seen, count);
     for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
         mn_reset_env<M, PARITY>(A, P, S, W, list ? list[qi] : (int)qi, mode, obs_out);
+}
+
+// The same kernel for mn_reset_done_async: it runs on the handle's side stream UNDER the act kernel of the next vector step, whose 512-thread
+// workgroups hold every CU with two wavefronts of 208 registers per SIMD and all but 5.8 KB of the LDS -- so this one is compiled for the 96 registers
+// that are left (five waves per SIMD as the occupancy target), its 3.1 KB of LDS fit, and every finished env announces its first observation (`ready`).
+template <typename M, bool PARITY>
+__global__ __launch_bounds__(MN_WAVE, 5) void mn_reset_under_act_kernel(MnArrays A, MnDev P, const uint32_t *__restrict__ count_dev,
+                                                                        const int32_t *__restrict__ list, float *__restrict__ obs_out,
+                                                                        uint32_t *__restrict__ ready, uint32_t tick, const MnSeen seen) {
+    __shared__ MtLds S;
+    __shared__ WorldLds W;
+    const uint32_t count = *count_dev;
+    mn_note_count(seen, count);
+    for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
+        mn_reset_env<M, PARITY>(A, P, S, W, list[qi], 0, obs_out, ready, tick);
 }
 
 // init_genrand (numpy legacy seeding): key[0] = seed, key[i] = 1812433253*(key[i-1]^(key[i-1]>>30)) + i
@@ -69,15 +98,27 @@ __global__ void mn_peek_kernel(MnArrays A, int first, int count, double *out) {
 }  // namespace
 
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
-                     const int32_t *list_dev, int mode, float *obs, hipStream_t s) {
+                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev, uint32_t *peak_host) {
+    const MnSeen seen = {peak_dev, peak_host};
     // enough waves to fill the chip several times over; each wave loops over queue entries
     uint32_t cap = count_dev ? (uint32_t)A.n : count_host;
     uint32_t blocks = cap < MN_RESET_MAX_BLOCKS ? cap : MN_RESET_MAX_BLOCKS;
     if (blocks == 0) return;
     if (precision == MN_PRECISION_F64)
-        hipLaunchKernelGGL((mn_reset_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs);
+        hipLaunchKernelGGL((mn_reset_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen);
     else
-        hipLaunchKernelGGL((mn_reset_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs);
+        hipLaunchKernelGGL((mn_reset_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen);
+}
+
+void mn_launch_reset_under_act(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, const int32_t *list_dev, float *obs,
+                               uint32_t *ready, uint32_t tick, uint32_t *peak_dev, uint32_t *peak_host, hipStream_t s) {
+    const MnSeen seen = {peak_dev, peak_host};
+    uint32_t blocks = (uint32_t)A.n < MN_RESET_MAX_BLOCKS ? (uint32_t)A.n : MN_RESET_MAX_BLOCKS;
+    if (blocks == 0) return;
+    if (precision == MN_PRECISION_F64)
+        hipLaunchKernelGGL((mn_reset_under_act_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, list_dev, obs, ready, tick, seen);
+    else
+        hipLaunchKernelGGL((mn_reset_under_act_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, list_dev, obs, ready, tick, seen);
 }
 
 void mn_launch_seed(const MnArrays &A, const uint32_t *seeds_dev, hipStream_t s) {

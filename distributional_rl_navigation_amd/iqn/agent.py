@@ -55,6 +55,10 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_multi_step = False                  # opt-in: the gradient steps of one training event as ONE persistent launch (mn_iqn_train_steps; bit-identical to the
                                                      # single steps).  One launch instead of G for the host; on the GPU 33.4 us per step against 32.4 for single fused steps
                                                      # (round 5: the parameter hand-off between steps costs what the launch boundary did) -- so not the default
+        self.reset_under_act = False                 # vec_step: the episode resets of a vector step run on the env's own stream UNDER the next step's act kernel (which takes
+                                                     # the finished envs' rows last) instead of in front of it: same results, ~28 us off every vector step's critical path.  The
+                                                     # `obs` vec_step returns then has rows still being written: hand it back to vec_step, or call `train_env.join_reset()` before
+                                                     # reading it.  On in learn_vec / train_iqn / bench.py; off by default for callers that look at `obs` between steps
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
         self._graph = None
         self._graph_bypass_logged = False
@@ -159,18 +163,22 @@ class IQNAgent(ReferenceLoopMixin):
         return out
 
     @torch.no_grad()
-    def act_batch(self, states, eps, cvar=1.0):
+    def act_batch(self, states, eps, cvar=1.0, late_env=None):
         """Batched eps-greedy act (agent.py:186-205 per row): states [n,26] f32 on device ->
         actions [n] int32 on device.  On the GPU this is ONE fused HIP kernel (network, mean over taus,
-        argmax, exploration); exploration draws come from a device generator."""
+        argmax, exploration); exploration draws come from a device generator.
+        `late_env`: the env whose `reset_done(under_next_act=True)` may still be writing rows of `states` (vec_step with `reset_under_act`):
+        the fused kernel takes those rows last; every other path waits for the reset first."""
         if states.is_cuda and self.use_fused_act:
             from .fused_act import fused_act
             if not self.use_library_rng:
-                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen, shared_taus=self.shared_taus)
+                return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, generator=self.gen, shared_taus=self.shared_taus, late_env=late_env)
             if self._act_rng is None:
                 from .fused_act import ActRng
                 self._act_rng = ActRng(self.gen.initial_seed(), states.device)
-            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, shared_taus=self.shared_taus)
+            return fused_act(self.qnetwork_local, states.contiguous(), eps, cvar, rng=self._act_rng, shared_taus=self.shared_taus, late_env=late_env)
+        if late_env is not None:
+            late_env.join_reset()
         q = self.qvals_batch(states, cvar)
         greedy = q.argmax(dim=1).to(torch.int32)
         if eps <= 0.0:
@@ -394,7 +402,7 @@ class IQNAgent(ReferenceLoopMixin):
     # ---- batched loop on the HIP vector env ----------------------------------------------------------
     def learn_vec(self, total_vector_steps, train_env, eval_env=None, eval_config=None, eval_freq=None,
                   eval_log_path=None, total_timesteps=None, world_size=1, cvar=1.0, verbose=True,
-                  train_every=None, on_step=None, report_timestep_scale=1.0, eval_adaptive=True):
+                  train_every=None, on_step=None, report_timestep_scale=1.0, eval_adaptive=True, reset_under_act=True):
         """Vectorised agent.py:94-173.  One iteration = one vector step of `train_env` (n_envs env
         steps): act_batch -> mn_step -> replay.add_batch -> mn_reset_done -> (every UPDATE_EVERY vector
         steps) sample + train.  `current_timestep` counts env steps over all ranks, so eps, the
@@ -413,6 +421,8 @@ class IQNAgent(ReferenceLoopMixin):
         ep_ret = torch.zeros(n, device=self.device)
         ep_len = torch.zeros(n, device=self.device)
         stats = dict(episodes=0, successes=0, collisions=0, timeouts=0, loss=None)
+        # this loop never looks at `obs` between two vector steps, so the resets can run under the next step's act kernel (see `reset_under_act`)
+        was_under_act, self.reset_under_act = self.reset_under_act, bool(reset_under_act)
         for it in range(total_vector_steps):
             eps = self.linear_eps(total_timesteps)
             evaluate_now = eval_env is not None and cadence_tick(self, train_every, eval_freq).evaluate      # (the state vec_step's own tick sees)
@@ -446,6 +456,9 @@ class IQNAgent(ReferenceLoopMixin):
                     self.qnetwork_local.save(eval_log_path)
             if on_step is not None:
                 on_step(it, stats)
+        self.reset_under_act = was_under_act
+        if hasattr(train_env, "join_reset"):
+            train_env.join_reset()
         self.check_learner()
         return stats
 
@@ -454,6 +467,11 @@ class IQNAgent(ReferenceLoopMixin):
         nothing, and with the mailbox exchange a peer's gradient did not arrive -- the ranks of a shared learner would drift apart silently otherwise."""
         if self._fused is not None and self._fused.owns(self):
             self._fused.check_timeouts()
+        if self.reset_under_act and self.device.type == "cuda" and self.use_fused_act:
+            from .fused_act import late_timeouts
+            k = late_timeouts(self.qnetwork_local)
+            if k:
+                raise RuntimeError(f"{k} act rows were taken before their episode reset had finished (mn_iqn_late_timeouts): the reset launch did not run beside the act kernel")
 
     def vec_step(self, train_env, obs, eps, cvar=1.0, train_every=None, per_iter=None):
         """One iteration of the vectorised loop: act_batch -> mn_step -> replay.add_batch ->
@@ -462,7 +480,8 @@ class IQNAgent(ReferenceLoopMixin):
         Returns (obs for the next act, reward, done, info, loss or None)."""
         train_every = self.UPDATE_EVERY if train_every is None else train_every
         per_iter = train_env.n_envs if per_iter is None else per_iter
-        actions = self.act_batch(obs, eps, cvar)
+        under_act = bool(self.reset_under_act) and obs.is_cuda and hasattr(train_env, "take_late_rows")
+        actions = self.act_batch(obs, eps, cvar, late_env=train_env if under_act or getattr(train_env, "late_rows", None) is not None else None)
         if obs.is_cuda and hasattr(train_env, "step_append") and self.n_step == 1:
             # mn_step_append: the step kernel itself writes (obs_t, a, r, obs_t+1 incl. terminal observations, done)
             # into the replay ring -- no separate append launch, obs_t+1 is not re-read
@@ -475,7 +494,8 @@ class IQNAgent(ReferenceLoopMixin):
                 self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         loss = None
         due = cadence_tick(self, train_every)      # iqn/cadence.py: agent.py:126-147's rule (+ the target cadence in gradient steps)
-        obs = train_env.reset_done()                                # first observations where done
+        # first observations where done; `reset_under_act`: on the env's own stream, under the next call's act kernel, which takes those rows last
+        obs = train_env.reset_done(under_next_act=True) if under_act else train_env.reset_done()
         if due.train:
             loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
         if due.sync:

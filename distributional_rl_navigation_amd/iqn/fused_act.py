@@ -155,9 +155,39 @@ class ActRng:
         return buf
 
 
+def _arm_late_rows(ctx, late_env, n, want_quantiles):
+    """`late_env`: a VecMarineNavEnv whose `reset_done(under_next_act=True)` is still running on its own stream while `states` (its
+    observation buffer) goes into this act launch.  The launch is told which rows are being rewritten (mn_iqn_set_late_rows) and takes them
+    last; a kernel form that cannot do that waits for the reset instead.  Returns True if the launch that follows must be joined afterwards."""
+    if late_env is None:
+        return False
+    lr = late_env.take_late_rows()
+    if lr is None:
+        return False
+    mask, ready, tick = lr
+    rc = 1 if want_quantiles else _capi.lib().mn_iqn_set_late_rows(ctx.h, _p(mask), C.c_void_p(ready), C.c_uint32(tick), n)
+    if rc == 1:
+        late_env.join_reset()
+        return False
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_iqn_set_late_rows failed ({rc})")
+    return True
+
+
+def late_timeouts(net):
+    """Waits of late rows that ran out in `net`'s act context (0 in a healthy run): C-ABI mn_iqn_late_timeouts.  Synchronises the stream."""
+    ctx = act_context(net)
+    out = C.c_uint32()
+    dev = next(net.parameters()).device
+    rc = _capi.lib().mn_iqn_late_timeouts(ctx.h, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.byref(out))
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_iqn_late_timeouts failed ({rc})")
+    return out.value
+
+
 @torch.no_grad()
 def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None, want_quantiles=False,
-              shared_taus=False):
+              shared_taus=False, late_env=None):
     """IQNAgent.act for states [n, 26] on the GPU in ONE kernel: encoders, cosine embedding, Hadamard
     product, hidden layers, mean over K = 32 taus, argmax and epsilon-greedy.
     Returns actions [n] int32; with want_qvals (actions, Q [n, 9]); with want_quantiles -- the batched
@@ -179,6 +209,7 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
     q = torch.empty(n, net.action_size, dtype=torch.float32, device=dev) if want_qvals else None
     quant = torch.empty(n, net.K, net.action_size, dtype=torch.float32, device=dev) if want_quantiles else None
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    joined_after = _arm_late_rows(ctx, late_env, n, want_quantiles)      # (after set_tau_mode: the form of THIS launch decides)
     if taus is None and rng is not None:
         cv_row = cvar.to(device=dev, dtype=torch.float32).contiguous() if torch.is_tensor(cvar) else None
         draws = rng.draws(n, net.K)
@@ -210,6 +241,8 @@ def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qv
                                     _p(actions), _p(quant), n, net.K, stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_act failed ({rc})")
+    if joined_after:      # later work on this stream (the next step reads every row) comes after the reset launch's end
+        late_env.join_reset()
     out = (actions,)
     if want_quantiles:
         out += (quant, t.clone().view(n, net.K, 1))       # (.clone(): the library's draw buffer is reused by the next call)

@@ -91,6 +91,8 @@ class VecMarineNavEnv:
         self.done = torch.zeros(self.n_envs, dtype=torch.uint8, device=dev)
         self.info = torch.zeros(self.n_envs, dtype=torch.uint8, device=dev)
         self._terminal_obs = None
+        self.late_rows = None      # reset_done(under_next_act=True)
+        self.reset_launches = [0, 0]      # ... how many of those calls the library ran [in front of, under] the next act kernel
 
     # ---- lifecycle ---------------------------------------------------------------------------
     def close(self):
@@ -259,16 +261,45 @@ class VecMarineNavEnv:
         self._check(self.L.mn_random_actions(int(action_seed), int(step), int(self.first_index), self.n_envs, _ptr(a), self._stream()))
         return a
 
-    def reset_done(self, keep_terminal_obs=False):
+    def reset_done(self, keep_terminal_obs=False, under_next_act=False):
         """The caller-side `if done: state = env.reset()` (agent.py:152-170) for the whole batch.
         Overwrites the rows of finished envs in ``self.obs`` with their first observation; with
-        keep_terminal_obs the pre-reset observations are preserved in ``self.terminal_obs``."""
+        keep_terminal_obs the pre-reset observations are preserved in ``self.terminal_obs``.
+        `under_next_act` (mn_reset_done_async): the reset runs on the handle's own stream, off the caller's critical path; ``self.late_rows``
+        = (done flags, "row is final" words, tick) is what the next act launch needs to take the finished envs' rows last
+        (`fused_act(..., late_rows=env.take_late_rows())`).  Until `join_reset()` -- or the next step / reset of this env -- the rows of
+        finished envs in ``self.obs`` must not be read by anything else on the caller's stream."""
         if keep_terminal_obs:
             if self._terminal_obs is None:
                 self._terminal_obs = torch.empty_like(self.obs)
             self._terminal_obs.copy_(self.obs)
-        self._check(self.L.mn_reset_done(self.h, _ptr(self.obs), self._stream()))
+        if under_next_act:
+            ready, tick = C.c_void_p(), C.c_uint32()
+            self._check(self.L.mn_reset_done_async(self.h, _ptr(self.obs), self._stream(), C.byref(ready), C.byref(tick)))
+            # (the library runs it in front after all -- ready NULL -- while many episodes end per vector step: set_reset_under_act_max)
+            self.late_rows = (self.done, ready.value, tick.value) if ready.value else None
+            self.reset_launches[1 if ready.value else 0] += 1
+        else:
+            self.late_rows = None
+            self._check(self.L.mn_reset_done(self.h, _ptr(self.obs), self._stream()))
         return self.obs
+
+    def set_reset_under_act_max(self, max_resets):
+        """`reset_done(under_next_act=True)` goes under the act kernel only while the decaying peak of the episodes started per reset launch is at most this
+        (default 384; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
+        last = C.c_int64()
+        self._check(self.L.mn_set_reset_under_act_max(self.h, int(max_resets), C.byref(last)))
+        return last.value
+
+    def take_late_rows(self):
+        """The pending `reset_done(under_next_act=True)`'s late rows for ONE act launch (None if there is none)."""
+        lr, self.late_rows = getattr(self, "late_rows", None), None
+        return lr
+
+    def join_reset(self):
+        """Everything enqueued on the current stream from here on runs after a pending `reset_done(under_next_act=True)`."""
+        self.late_rows = None
+        self._check(self.L.mn_reset_join(self.h, self._stream()))
 
     @property
     def terminal_obs(self):

@@ -192,6 +192,24 @@ int mn_random_actions(uint64_t action_seed, uint64_t step_index, uint64_t first_
  * resets exactly the envs the LAST mn_step flagged done and overwrites their rows of obs_dev
  * (which may or may not be the buffer given to mn_step). */
 int mn_reset_done(mn_handle *h, float *obs_dev, void *stream);
+/* The same reset OFF the caller's critical path: launched on a stream the handle owns (behind an event recorded on `stream`), so it runs
+ * under whatever the caller enqueues on `stream` next.  In the training loop that is the act kernel of the next vector step
+ * (agent.py:113-124: `state = next_state` / `env.reset()` then `act(state)`), which depends on the reset only through the rows of the
+ * finished envs: tell it which they are and how to recognise a finished row -- mn_iqn_set_late_rows(ctx, <the step's done_dev>, *ready_out,
+ * *tick_out, n) -- and it takes those rows last, each after `(*ready_out)[e] == *tick_out` (written by the reset wavefront behind its
+ * write-through row).  Results are those of mn_reset_done, bit for bit.  `stream` is joined again (everything enqueued later waits for the
+ * reset launch to end) by mn_reset_join or by the next mn_step / mn_step_append / mn_reset_done[_async] on it; every other entry point of
+ * the handle waits for it on the host.  Between this call and the join the caller must not read obs_dev rows of finished envs except
+ * through such an act launch.
+ * Beside the act kernel's workgroups a CU has room for one reset wavefront, which runs several times slower there: that hides a few hundred
+ * resets per vector step (alone, such a launch is a latency chain that leaves the chip idle), not thousands.  The call therefore launches under the
+ * act kernel only while the decaying peak of the episodes started per reset launch -- peak <- max(count, 7/8 peak), kept by the launches
+ * themselves and read by the host from a mapped word without synchronising -- is at most `under_act_max` (mn_set_reset_under_act_max:
+ * default 384; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on `stream` and *ready_out is NULL (no late rows).
+ * mn_set_reset_under_act_max also reports that peak as of the last launch seen (-1: none yet). */
+int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, const uint32_t **ready_out, uint32_t *tick_out);
+int mn_reset_join(mn_handle *h, void *stream);
+int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, int64_t *last_seen);
 
 /* MarineNavEnv.reset_with_eval_config (marinenav_env.py:467-555), world + pose fields, for `count`
  * consecutive envs starting at first_env.  Host arrays, row-major:
@@ -288,6 +306,15 @@ int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
  *   2: as 1, but always the wavefront-per-row form; 3: as 1, but always the environment-tiled form (A / B measurements, tests).
  * A row's result for GIVEN taus is the same function in both modes up to float32 rounding (tests). */
 int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
+/* Late rows of the NEXT act launch of this context (mn_reset_done_async): mask_dev [n] u8 != 0 marks the rows whose observation another
+ * stream is still writing, flags_dev [n] / tick say when a row is final (flags_dev[e] == tick; the row itself written through at agent
+ * scope before the word).  The launch takes those rows last and reads them past the caches; results equal those of a launch behind the
+ * reset.  Returns MN_OK if the next launch of n rows will honour it (launch it next on this context), 1 if the context's current form
+ * cannot (exact / 32x32 variants, launch-shared taus, quantile capture, more than 64 rows per wavefront): the caller joins the reset
+ * (mn_reset_join) instead.  NULL, NULL clears.  mn_iqn_late_timeouts: waits that ran out (0.5 s bound) since the context was made --
+ * anything but 0 means an action was computed on an unfinished row (synchronises `stream`). */
+int mn_iqn_set_late_rows(mn_iqn_ctx *c, const uint8_t *mask_dev, const uint32_t *flags_dev, uint32_t tick, int32_t n);
+int mn_iqn_late_timeouts(mn_iqn_ctx *c, void *stream, uint32_t *out);
 /* Measurement aid (bench.py: `gpu_clock_probe`): runs a pure stream of the act kernel's matrix instruction (v_mfma_f32_16x16x32_f16, two
  * waves per SIMD on every CU) for about target_ms milliseconds on `stream` and returns out[0] = elapsed ms (HIP events), out[1] = the clock
  * in GHz the matrix pipe sustained (16 cycles per instruction), out[2] = the clock by the waves' own counters (s_memtime ticks per

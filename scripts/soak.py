@@ -13,6 +13,7 @@ sched = dict(timesteps=[0, 1000000, 2000000], num_cores=[4, 6, 8], num_obstacles
 env = VecMarineNavEnv(n, seed=0, schedule=sched, timestep_scale=3e6 / (n * steps) * n, device="cuda:0")
 agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=100_000, device="cuda:0", seed=100, learning_starts=0, UPDATE_EVERY=update_every)
 agent.grad_steps_per_update = grad_steps
+agent.reset_under_act = True      # (the loop only looks at `obs` behind a device synchronisation)
 obs = env.reset()
 total = n * steps
 t0 = time.time(); mem0 = None; done_total = 0

@@ -53,6 +53,7 @@ def evaluate():
     return sum(r["successes"]), float(np.mean(r["rewards"]))
 
 
+agent.reset_under_act = True      # episode resets under the next step's act kernel while few episodes end per vector step (the library decides)
 obs = env.reset()
 t_train, it, next_eval = 0.0, 0, 0.0
 rows = []

@@ -1,0 +1,153 @@
+"""Episode resets UNDER the next vector step's act kernel (C-ABI mn_reset_done_async / mn_reset_join / mn_iqn_set_late_rows;
+`VecMarineNavEnv.reset_done(under_next_act=True)`, `IQNAgent.reset_under_act`): the reset launch runs on the env handle's own stream while
+the act kernel -- told which rows are being rewritten -- takes those rows last, each after its "row is final" word.  Same results as the
+reset IN FRONT of the act kernel (agent.py:113-124: `env.reset()` then `act(state)`), bit for bit, whatever share of the rows is late."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+def _loop(torch, n, precision, under_act, T, max_episode_steps=None, shared_taus=False, eps=0.3, train=True):
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    env = VecMarineNavEnv(n, seed=3, device=DEV, precision=precision)
+    if max_episode_steps is not None:
+        env.params.max_episode_steps = max_episode_steps
+    env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+    agent = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=3 * n, device=DEV, seed=11, learning_starts=0, UPDATE_EVERY=2 if train else 10 ** 9)
+    agent.shared_taus = shared_taus
+    agent.reset_under_act = under_act
+    env.set_reset_under_act_max(2 ** 31 - 1)      # however many episodes end (the library's default goes in front above 384 per vector step)
+    obs = env.reset()
+    trace = []
+    for t in range(T):
+        prev_late = env.late_rows is not None
+        obs, reward, done, info, loss = agent.vec_step(env, obs, eps)
+        assert (env.late_rows is not None) == under_act      # the reset of THIS step is pending / is not
+        if t and under_act:
+            assert prev_late                                   # ... and the previous one was consumed by this step's act launch
+        trace.append((reward.clone(), done.clone(), info.clone(), None if loss is None else float(loss)))
+    env.join_reset()
+    agent.check_learner()
+    m = agent.memory
+    out = dict(trace=trace, obs=obs.clone(), ring=(m.states.clone(), m.actions.clone(), m.rewards.clone(), m.next_states.clone(), m.dones.clone()),
+               params=torch.cat([p.detach().reshape(-1).clone() for p in agent.qnetwork_local.parameters()]), state=env.get_state(),
+               dones=int(sum(int(tr[1].sum()) for tr in trace)))
+    from distributional_rl_navigation_amd.iqn.fused_act import late_timeouts
+    assert late_timeouts(agent.qnetwork_local) == 0
+    env.close()
+    return out
+
+
+def _same(torch, a, b):
+    for (r0, d0, i0, l0), (r1, d1, i1, l1) in zip(a["trace"], b["trace"]):
+        assert torch.equal(r0, r1) and torch.equal(d0, d1) and torch.equal(i0, i1) and l0 == l1
+    assert torch.equal(a["obs"], b["obs"]) and torch.equal(a["params"], b["params"])
+    for x, y in zip(a["ring"], b["ring"]):
+        assert torch.equal(x, y)
+    for x, y in zip(a["state"], b["state"]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n,precision", [(4096, "f64"), (5000, "mixed"), (65536, "f64")])
+def test_loop_with_resets_under_the_act_kernel_equals_the_plain_loop(torch, n, precision):
+    """act -> step + append -> reset -> (train) for 40 vector steps with the resets in front of the act kernel and under it: rewards, done /
+    info codes, losses, observations, replay ring, learned parameters, env state and counters identical."""
+    a = _loop(torch, n, precision, False, 40)
+    b = _loop(torch, n, precision, True, 40)
+    assert a["dones"] > 0
+    _same(torch, a, b)
+
+
+def test_every_row_late(torch):
+    """max_episode_steps = 3: ALL envs finish in the same vector step, so every row of the following act launch is a late row (and every
+    wavefront of the reset launch has to find room beside the act kernel's workgroups)."""
+    a = _loop(torch, 8192, "f64", False, 10, max_episode_steps=3, train=False)
+    b = _loop(torch, 8192, "f64", True, 10, max_episode_steps=3, train=False)
+    assert a["dones"] >= 2 * 8192
+    _same(torch, a, b)
+
+
+def test_forms_without_late_rows_wait_for_the_reset(torch):
+    """Launch-shared taus (another kernel form) cannot take late rows: the act call joins the reset first -- same results as the plain loop."""
+    a = _loop(torch, 4096, "f64", False, 20, shared_taus=True)
+    b = _loop(torch, 4096, "f64", True, 20, shared_taus=True)
+    _same(torch, a, b)
+
+
+def test_c_abi_contract(torch):
+    import ctypes as C
+    from distributional_rl_navigation_amd import _capi
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.fused_act import act_context
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    L = _capi.lib()
+    env = VecMarineNavEnv(256, seed=0, device=DEV, precision="f64")
+    env.reset()
+    env.set_reset_under_act_max(2 ** 31 - 1)
+    ready, tick = C.c_void_p(), C.c_uint32()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.mn_reset_done_async(None, p(env.obs), s, C.byref(ready), C.byref(tick)) != 0
+    assert L.mn_reset_done_async(env.h, None, s, C.byref(ready), C.byref(tick)) != 0
+    assert L.mn_reset_done_async(env.h, p(env.obs), s, None, C.byref(tick)) != 0
+    assert L.mn_reset_join(None, s) != 0 and L.mn_reset_join(env.h, s) == 0      # nothing pending: a no-op
+    env.step(torch.zeros(256, dtype=torch.int32, device=DEV))
+    assert L.mn_reset_done_async(env.h, p(env.obs), s, C.byref(ready), C.byref(tick)) == 0 and ready.value and tick.value == 1
+    s0, e0, t0 = env.get_state()      # a host accessor with a reset pending: waits for it
+    assert L.mn_reset_join(env.h, s) == 0
+    agent = IQNAgent(26, 9, device=DEV, seed=1)
+    ctx = act_context(agent.qnetwork_local)
+    assert L.mn_iqn_set_late_rows(None, p(env.done), ready, 1, 256) != 0
+    assert L.mn_iqn_set_late_rows(ctx.h, p(env.done), None, 1, 256) < 0
+    assert L.mn_iqn_set_late_rows(ctx.h, p(env.done), ready, 1, 256) == 0
+    assert L.mn_iqn_set_late_rows(ctx.h, None, None, 0, 0) == 0               # clear
+    assert L.mn_iqn_set_late_rows(ctx.h, p(env.done), ready, 1, 64 * 8 * 256 + 8) == 1      # more than 64 rows per wavefront: join instead
+    ctx.set_variant(0)
+    assert L.mn_iqn_set_late_rows(ctx.h, p(env.done), ready, 1, 256) == 1     # the exact-f32 kernel has no such form
+    ctx.set_variant(2)
+    out = C.c_uint32(7)
+    assert L.mn_iqn_late_timeouts(ctx.h, s, C.byref(out)) == 0 and out.value == 0
+    env.close()
+
+
+def test_many_episode_ends_go_in_front(torch):
+    """The library's own rule: while the decaying peak (x 7/8 per call) of the episode counts of the reset launches seen is above `under_act_max`, the next
+    mn_reset_done_async runs in front of the act kernel (ready_out NULL, no late rows) -- and goes back under it when the counts have fallen."""
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    n = 4096
+    env = VecMarineNavEnv(n, seed=0, device=DEV, precision="f64")
+    env.params.max_episode_steps = 2
+    env.set_attrs(num_cores=4, num_obs=6, min_start_goal_dis=30.0)
+    assert env.set_reset_under_act_max(1000) == -1      # nothing seen yet
+    env.reset()
+    a = torch.zeros(n, dtype=torch.int32, device=DEV)
+    modes, counts = [], []
+    for t in range(6):
+        if t == 3:
+            env.params.max_episode_steps = 1000      # from here on (almost) no episode ends
+            env.set_attrs(num_cores=4, num_obs=6)
+        env.step(a)
+        env.reset_done(under_next_act=True)
+        modes.append(env.late_rows is not None)
+        env.join_reset()
+        torch.cuda.synchronize()
+        counts.append(env.set_reset_under_act_max(1000))      # the launches' decaying peak of their episode counts
+        if t <= 2:
+            assert counts[-1] == int(env.done.sum())
+    for t in range(30):
+        env.step(a); env.reset_done(under_next_act=True); modes.append(env.late_rows is not None); env.join_reset(); torch.cuda.synchronize()
+    # step 0: nothing seen -> in front (0 episodes seen afterwards); steps 1, 2: under; all 4 096 episodes end in step 2 (max_episode_steps = 2: the third step
+    # of an episode); from then on the peak decays from 4 096 and is <= 1 000 after 11 more launches
+    assert modes[:3] == [False, True, True] and counts[:4] == [0, 0, n, n - n // 8] and not any(modes[3:13]) and all(modes[16:]), (modes, counts)
+    env.close()
