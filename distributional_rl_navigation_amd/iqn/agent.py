@@ -480,7 +480,10 @@ class IQNAgent(ReferenceLoopMixin):
         Returns (obs for the next act, reward, done, info, loss or None)."""
         train_every = self.UPDATE_EVERY if train_every is None else train_every
         per_iter = train_env.n_envs if per_iter is None else per_iter
-        under_act = bool(self.reset_under_act) and obs.is_cuda and hasattr(train_env, "take_late_rows")
+        under_act = bool(self.reset_under_act) and obs.is_cuda and hasattr(train_env, "take_late_rows") and self.use_fused_act
+        if under_act:      # only the default acting form takes late rows: with any other the reset stays in front (no cross-stream events for nothing)
+            from .fused_act import late_rows_possible
+            under_act = late_rows_possible(self.qnetwork_local, obs.shape[0], self.shared_taus)
         actions = self.act_batch(obs, eps, cvar, late_env=train_env if under_act or getattr(train_env, "late_rows", None) is not None else None)
         if obs.is_cuda and hasattr(train_env, "step_append") and self.n_step == 1:
             # mn_step_append: the step kernel itself writes (obs_t, a, r, obs_t+1 incl. terminal observations, done)

@@ -90,6 +90,7 @@ class ActContext:
         rc = _capi.lib().mn_iqn_set_grid(self.h, int(max_workgroups))
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_grid failed ({rc})")
+        self.__dict__.pop("_late_ok", None)      # (late_rows_possible: rows per wavefront follow the grid)
 
     def refresh(self, net):
         """Rebuild the cached weight image now (current stream) if it is stale -- see mn_iqn_refresh."""
@@ -172,6 +173,26 @@ def _arm_late_rows(ctx, late_env, n, want_quantiles):
     if rc:
         raise _capi.MarineNavHipError(f"mn_iqn_set_late_rows failed ({rc})")
     return True
+
+
+def late_rows_possible(net, n, shared_taus=False):
+    """Whether an act launch of `n` rows of `net` takes late rows (the split-f16 kernel with per-row taus, at most 64 rows per wavefront): what
+    `IQNAgent.vec_step` asks before it puts an episode reset under the next act kernel -- for any other form the reset stays in front."""
+    if shared_taus:
+        return False
+    ctx = act_context(net)
+    key = (int(n), ctx.variant)
+    cache = ctx.__dict__.setdefault("_late_ok", {})
+    if key not in cache:
+        probe = torch.zeros(1, dtype=torch.int32, device=ctx.device)      # (pointers are not dereferenced by the query)
+        mode, ctx.tau_mode = ctx.tau_mode, None
+        ctx.set_tau_mode(0)
+        rc = _capi.lib().mn_iqn_set_late_rows(ctx.h, _p(probe), _p(probe), C.c_uint32(0), int(n))
+        _capi.lib().mn_iqn_set_late_rows(ctx.h, None, None, C.c_uint32(0), 0)
+        if mode is not None:
+            ctx.set_tau_mode(mode)
+        cache[key] = rc == 0
+    return cache[key]
 
 
 def late_timeouts(net):

@@ -18,7 +18,12 @@ out = ("# %s: bench.py --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only -
        "# BASELINE configs[2] -- 65 536 envs + IQN training, 1 gradient step every 4 vector steps, float64 env kernels, per-env taus (the default), one batch / one stream.\n"
        "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is ONE launch: iqn_train_fwdbwd<XCHG = false, FUSED = true, MULTI = false>\n"
        "# (target / local / reduction + clip + Adam workgroup roles, XCD-grouped).  mn_reset_kernel's average contains the initial all-env resets (max column); in the loop: bench.py's live row.\n") % RT
+out += ("# Episode resets: mn_reset_under_act_kernel on the env handle's own stream, beside the act kernel's workgroups (iqn_qvals_split_kernel<.., LATE = true> takes the finished\n"
+        "# envs' rows last) while few episodes end per vector step; mn_reset_kernel / the LATE = false act kernel are the launches of the first vector steps, which the library keeps\n"
+        "# in front (nothing seen yet, then the decaying peak of the start-up burst).\n")
 out += body('prof_loop_summary.txt').rstrip() + '\n\n'
+if os.path.exists(M + 'prof_loop_reset_in_front_summary.txt'):
+    out += "# the same command with --reset-in-front (mn_reset_done on the caller's stream, every vector step waits for it):\n" + body('prof_loop_reset_in_front_summary.txt').rstrip() + '\n\n'
 out += ("# PMC passes (separate runs, one counter each: rocprofv3 --kernel-trace --pmc <counter>; the same command with --steps 24 --warmup 8 --update-every 1 --grad-steps 4),\n"
         "# mean per launch; FETCH_SIZE / WRITE_SIZE in KB of 1000 B; HBM bytes = 2 x FETCH_SIZE (gfx950 correction, profiles/r01_pmc_calibration.txt) + WRITE_SIZE\n")
 out += pm.rstrip() + '\n'
@@ -83,6 +88,13 @@ out += ("# (2) RANKS_PER_GPU=2 bash scripts/scale.sh 2 -- bench.py's world > 1 b
         "#     rows show that the path runs and what it costs on one device, not scaling.  all_reduce_ms here is the gloo all-reduce through the host.\n")
 out += body('scale_two_ranks_one_gpu.txt').rstrip() + '\n'
 open(P + 'scale.txt', 'w').write(out)
-shutil.copy(M + 'reset_scaling.txt', '/tmp/reset_scaling_session.txt')
+if os.path.exists(M + 'reset_under_act_ab.txt'):
+    t = open(P + 'reset_under_act.txt').read() if os.path.exists(P + 'reset_under_act.txt') else ''
+    lines = t.split('\n')
+    i0 = next((i for i, l in enumerate(lines) if l.startswith('max_episode_steps')), None)
+    i1 = max((i for i, l in enumerate(lines) if l.startswith('max_episode_steps')), default=None)
+    if i0 is not None:
+        lines[i0:i1 + 1] = [l for l in body('reset_under_act_ab.txt').split('\n') if l.startswith('max_episode_steps')]
+        open(P + 'reset_under_act.txt', 'w').write('\n'.join(lines))
 j = json.load(open(M + 'bench_default.json'))
 print(j['value'] / 1e6, j['ms_per_step'], j['roofline']['launch_ms'], j['roofline_env_step']['launch_ms'])

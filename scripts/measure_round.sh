@@ -10,6 +10,7 @@ python bench.py --shared-taus --cpu-steps 0 --no-also --no-learner-only > $O/ben
 python scripts/learner_bench.py 3000 > $O/learner_bench.txt 2>&1
 python scripts/train_multi_phase_timing.py 16 100 > $O/train_multi_phase_timing.txt 2>&1
 python scripts/reset_scaling.py f64 > $O/reset_scaling.txt 2>&1
+python scripts/reset_under_act_ab.py 200 > $O/reset_under_act_ab.txt 2>&1
 python scripts/experiment_sweep.py > $O/experiment_sweep.txt 2>&1
 OUT=$O/scale bash scripts/scale.sh 1 > $O/scale_n1.txt 2>&1
 OUT=$O/scale2 RANKS_PER_GPU=2 bash scripts/scale.sh 2 > $O/scale_two_ranks_one_gpu.txt 2>&1
@@ -20,6 +21,7 @@ prof() { # name, bench args
   python $R/scripts/prof_summary.py $(find $O/prof_$name -name "*kernel_stats.csv" | head -1) 14 > $O/prof_${name}_summary.txt
 }
 prof loop --steps 100 --warmup 20
+prof loop_reset_in_front --steps 100 --warmup 20 --reset-in-front
 prof shared --shared-taus --steps 100 --warmup 20
 prof g16 --steps 60 --warmup 10 --update-every 1 --grad-steps 16 --eps 0.05
 for form in 1 2 3 16; do

@@ -33,8 +33,8 @@ def _loop(torch, n, precision, under_act, T, max_episode_steps=None, shared_taus
     for t in range(T):
         prev_late = env.late_rows is not None
         obs, reward, done, info, loss = agent.vec_step(env, obs, eps)
-        assert (env.late_rows is not None) == under_act      # the reset of THIS step is pending / is not
-        if t and under_act:
+        assert (env.late_rows is not None) == (under_act and not shared_taus)      # the reset of THIS step is pending / is not
+        if t and under_act and not shared_taus:
             assert prev_late                                   # ... and the previous one was consumed by this step's act launch
         trace.append((reward.clone(), done.clone(), info.clone(), None if loss is None else float(loss)))
     env.join_reset()
@@ -78,11 +78,33 @@ def test_every_row_late(torch):
     _same(torch, a, b)
 
 
-def test_forms_without_late_rows_wait_for_the_reset(torch):
-    """Launch-shared taus (another kernel form) cannot take late rows: the act call joins the reset first -- same results as the plain loop."""
+def test_forms_without_late_rows_keep_the_reset_in_front(torch):
+    """Launch-shared taus (another kernel form) cannot take late rows: vec_step leaves the reset in front (`late_rows_possible`), and an act call that
+    is handed a pending reset it cannot honour joins it first -- same results as the plain loop either way."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
     a = _loop(torch, 4096, "f64", False, 20, shared_taus=True)
     b = _loop(torch, 4096, "f64", True, 20, shared_taus=True)
     _same(torch, a, b)
+    # the join path: a pending reset handed to an act launch of the shared-tau form / of the exact-f32 variant
+    outs = []
+    for pending in (False, True):
+        env = VecMarineNavEnv(2048, seed=5, device=DEV, precision="f64")
+        env.set_reset_under_act_max(2 ** 31 - 1)
+        agent = IQNAgent(26, 9, device=DEV, seed=4)
+        agent.shared_taus = True
+        obs = env.reset()
+        acts = []
+        for t in range(12):
+            a_ = agent.act_batch(obs, 0.2, late_env=env)
+            assert env.late_rows is None
+            acts.append(a_.clone())
+            env.step(a_)
+            obs = env.reset_done(under_next_act=pending)
+        env.join_reset()
+        outs.append((torch.stack(acts), obs.clone()))
+        env.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_c_abi_contract(torch):
