@@ -492,6 +492,18 @@ def main():
         from distributional_rl_navigation_amd.iqn.fused_act import act_context
         act_context(agent.qnetwork_local).set_variant(args.act_variant)
     obs = run_steps(args.warmup, obs)
+    resets_note = None
+    if agent is not None and agent.reset_under_act and fused and not roll:
+        # the under-act resets need the reset launch to run BESIDE the act kernel (own hardware queue, room on the CUs): make sure of it before the timed
+        # region -- a dozen more untimed steps with every reset forced under the act kernel, then the late-row waits must all have been served
+        from distributional_rl_navigation_amd.iqn.fused_act import late_timeouts
+        env.set_reset_under_act_max(2 ** 31 - 1)
+        obs = run_steps(12, obs)
+        env.join_reset()
+        env.set_reset_under_act_max(384)
+        if late_timeouts(agent.qnetwork_local):
+            agent.reset_under_act = False
+            resets_note = "in_front_of_act (the reset launch did not run beside the act kernel on this box: late rows timed out)"
     g0 = agent.grad_steps if agent else 0
     clock_before = gpu_clock_probe(device) if (rank == 0 and not args.no_clock_probe) else None      # ~50 ms of matrix load, outside the timed region
     # HIP-event pairs are recorded around the first n_prof act / step / reset launches of the FIRST window; not around all of them, because the event records
@@ -643,7 +655,7 @@ def main():
                 "process_group": dist.get_backend() if use_dist else None, "ranks_per_gpu": rpg,
                 "eps": None if agent is None else (sum(eps_seen[-args.steps:]) / max(1, len(eps_seen[-args.steps:]))),
                 "act_variant": args.act_variant, "taus": "shared" if args.shared_taus else "per_env",
-                "resets": None if agent is None else ("under_next_act" if agent.reset_under_act else "in_front_of_act"),
+                "resets": None if agent is None else (resets_note or ("under_next_act" if agent.reset_under_act else "in_front_of_act")),
                 "late_row_timeouts": late_to,
                 "launches_per_grad_step": agent._fused.launches_per_step() if (agent is not None and getattr(agent, "_fused", None) is not None) else None,
                 "ablation": bool(_capi.lib().mn_build_info() & 1),
