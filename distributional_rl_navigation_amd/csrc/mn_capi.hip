@@ -748,6 +748,7 @@ extern "C" int mn_profile_begin(mn_handle *h, int32_t max_launches) {
 extern "C" int mn_profile_reset_end(mn_handle *h, void *stream, double *mean_ms, int32_t *launches) {
     if (!h) return MN_ERR_INVALID;
     MN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    if (h->side) MN_HIP(h, hipStreamSynchronize(h->side));      // (launches of mn_reset_done_async are timed on the handle's own stream)
     double sum = 0.0;
     for (int i = 0; i < h->prof_reset_n; ++i) {
         float ms = 0.f;
