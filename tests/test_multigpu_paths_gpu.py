@@ -371,6 +371,9 @@ def test_bench_shared_learner_line(torch, exchange):
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["grad_steps_per_sec"] > 0 and j["timeouts"] == 0
     assert j["all_reduce_ms"] > 0 and j["windows"]["n"] == 2 and j["windows"]["min"] <= j["value"] <= j["windows"]["max"]
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
+    # the episode resets ran under the act kernel (an RCCL communicator in the process: the handle's stream needs a hardware queue of its own) and every late row was served
+    assert j["config"]["resets"] == "under_next_act" and j["config"]["late_row_timeouts"] == 0
+    assert j["roofline_env_step"]["reset"]["on_critical_path"] is False and j["also"]["reset_in_front"]["value"] > 0
 
 
 @pytest.mark.parametrize("config", ["c3", "c4", "c4m"])
@@ -395,6 +398,7 @@ def test_bench_world_size_2_branch_runs_under_torch_distributed_run(torch, confi
     assert abs(j["value"] - 2 * 65536 * steps / (j["ms_per_step"] * 1e-3 * steps)) <= 2e-3 * j["value"]
     assert j["windows"]["n"] == 3 and j["windows"]["min"] <= j["value"] <= j["windows"]["max"]
     assert j["timeouts"] == 0 and j["grad_steps_per_sec"] > 0
+    assert j["config"]["resets"] == "under_next_act" and j["config"]["late_row_timeouts"] == 0
     if config == "c3":
         assert j["config"]["learner"] == "independent" and j["all_reduce_ms"] is None
     else:
