@@ -500,7 +500,7 @@ def main():
         env.set_reset_under_act_max(2 ** 31 - 1)
         obs = run_steps(12, obs)
         env.join_reset()
-        env.set_reset_under_act_max(384)
+        env.set_reset_under_act_max(1200)
         if late_timeouts(agent.qnetwork_local):
             agent.reset_under_act = False
             resets_note = "in_front_of_act (the reset launch did not run beside the act kernel on this box: late rows timed out)"

@@ -37,7 +37,7 @@ struct mn_handle {
     // decaying peak of the episodes the queue-driven reset launches start (mn_reset.hip: mn_note_count): device word + host-mapped copy (read without synchronising)
     volatile uint32_t *seen_host = nullptr;
     uint32_t *seen_dev = nullptr, *peak_dev = nullptr;
-    int32_t under_act_max = 384;           // mn_reset_done_async: above this peak the reset runs in front of the act kernel
+    int32_t under_act_max = 1200;          // mn_reset_done_async: above this peak the reset runs in front of the act kernel
 };
 
 static thread_local std::string g_create_err;
@@ -474,7 +474,7 @@ extern "C" int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, c
 }
 
 // under_act_max: mn_reset_done_async launches under the next act kernel while the decaying peak of the episodes started per reset launch (as of the last
-// launch seen) is at most this (default 384; 0x7fffffff: always, -1: never).  *last_seen: that peak (-1: none seen yet).
+// launch seen) is at most this (default 1200; 0x7fffffff: always, -1: never).  *last_seen: that peak (-1: none seen yet).
 extern "C" int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, int64_t *last_seen) {
     if (!h) return MN_ERR_INVALID;
     h->under_act_max = under_act_max;

@@ -286,7 +286,7 @@ class VecMarineNavEnv:
 
     def set_reset_under_act_max(self, max_resets):
         """`reset_done(under_next_act=True)` goes under the act kernel only while the decaying peak of the episodes started per reset launch is at most this
-        (default 384; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
+        (default 1200; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
         last = C.c_int64()
         self._check(self.L.mn_set_reset_under_act_max(self.h, int(max_resets), C.byref(last)))
         return last.value

@@ -205,7 +205,7 @@ int mn_reset_done(mn_handle *h, float *obs_dev, void *stream);
  * resets per vector step (alone, such a launch is a latency chain that leaves the chip idle), not thousands.  The call therefore launches under the
  * act kernel only while the decaying peak of the episodes started per reset launch -- peak <- max(count, 7/8 peak), kept by the launches
  * themselves and read by the host from a mapped word without synchronising -- is at most `under_act_max` (mn_set_reset_under_act_max:
- * default 384; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on `stream` and *ready_out is NULL (no late rows).
+ * default 1200; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on `stream` and *ready_out is NULL (no late rows).
  * mn_set_reset_under_act_max also reports that peak as of the last launch seen (-1: none yet). */
 int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, const uint32_t **ready_out, uint32_t *tick_out);
 int mn_reset_join(mn_handle *h, void *stream);

@@ -27,7 +27,7 @@ def _loop(torch, n, precision, under_act, T, max_episode_steps=None, shared_taus
     agent = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=3 * n, device=DEV, seed=11, learning_starts=0, UPDATE_EVERY=2 if train else 10 ** 9)
     agent.shared_taus = shared_taus
     agent.reset_under_act = under_act
-    env.set_reset_under_act_max(2 ** 31 - 1)      # however many episodes end (the library's default goes in front above 384 per vector step)
+    env.set_reset_under_act_max(2 ** 31 - 1)      # however many episodes end (the library's default goes in front above a decaying peak of 1 200 per vector step)
     obs = env.reset()
     trace = []
     for t in range(T):
