@@ -369,6 +369,8 @@ def main():
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     ap.add_argument("--reset-in-front", action="store_true", help="episode resets in front of the act kernel (mn_reset_done) instead of under it "
                                                                   "(mn_reset_done_async + late rows; IQNAgent.reset_under_act, the default)")
+    ap.add_argument("--reset-under-act-max", type=int, default=1200, help="mn_set_reset_under_act_max: resets go under the act kernel while the launches' decaying peak of "
+                                                                          "episode ends per vector step is at most this (the library's default)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
                                                                "timed by the default run as also.act_shared_taus)")
@@ -500,7 +502,7 @@ def main():
         env.set_reset_under_act_max(2 ** 31 - 1)
         obs = run_steps(12, obs)
         env.join_reset()
-        env.set_reset_under_act_max(1200)
+        env.set_reset_under_act_max(args.reset_under_act_max)
         if late_timeouts(agent.qnetwork_local):
             agent.reset_under_act = False
             resets_note = "in_front_of_act (the reset launch did not run beside the act kernel on this box: late rows timed out)"

@@ -497,12 +497,16 @@ class IQNAgent(ReferenceLoopMixin):
                 self.memory.add_batch(obs, actions, reward, next_obs, done.float())
         loss = None
         due = cadence_tick(self, train_every)      # iqn/cadence.py: agent.py:126-147's rule (+ the target cadence in gradient steps)
-        # first observations where done; `reset_under_act`: on the env's own stream, under the next call's act kernel, which takes those rows last
-        obs = train_env.reset_done(under_next_act=True) if under_act else train_env.reset_done()
+        # first observations where done (`reset_under_act`: on the env's own stream, under the next call's act kernel, which takes those rows last -- launched BEHIND the
+        # training event: a reset wavefront finds room beside an act workgroup, not beside a gradient step's, whose launches it would only hold up)
+        if not under_act:
+            obs = train_env.reset_done()
         if due.train:
             loss = self.train_steps_from_memory(self.grad_steps_per_update)      # 1 = the reference's cadence (agent.py:129-133)
         if due.sync:
             self._sync_target()
+        if under_act:
+            obs = train_env.reset_done(under_next_act=True)
         if self.current_timestep >= self.learning_starts:
             self.learning_timestep += 1
         self.current_timestep += per_iter
