@@ -7,6 +7,7 @@ n = 65536
 env = VecMarineNavEnv(n, seed=0, device="cuda:0")
 env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
 agent = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=100_000, device="cuda:0", seed=100, learning_starts=0)
+agent.reset_under_act = os.environ.get("UNDER", "1") == "1"
 obs = env.reset()
 for _ in range(20):
     obs = agent.vec_step(env, obs, 1.0, 1.0, per_iter=n)[0]
