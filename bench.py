@@ -21,7 +21,7 @@ means is written HERE, not in the line.
                         PMC figure of the same kernel (2 x FETCH_SIZE + WRITE_SIZE per launch, profiles/), clock_ghz / kilocycles: the launch in
                         cycles of the clock `clock` measured (a box-independent figure)
   roofline_env_step     `mn_step_kernel<double, ..., APPEND>` (HBM-bound by the north-star): (406 + 328) B per env-step x envs / launch_ms over
-                        8 TB/s; frac_step_only counts SURVEY 8(d)'s 406 B alone.  reset: `mn_reset_kernel` of the same vector steps, live events:
+                        8 TB/s; frac_step_only counts SURVEY 8(d)'s 406 B alone.  reset_kernel: `mn_reset_kernel` of the same vector steps, live events:
                         launch_ms, resets per launch (counted over 16 extra steps after the timed region), bytes per reset = 4 B x MT19937 words an
                         episode start consumes + the tables / pose / first observation it writes (RESET_BYTES), frac of 8 TB/s; on_critical_path false:
                         the launch ran on the env handle's own stream UNDER the next vector step's act kernel (config.resets; its launch_ms is then the
@@ -629,7 +629,7 @@ def main():
             gbs = (rb * resets_per_step / (reset_ms * 1e-3) / 1e9) if rb else None
             under = agent is not None and agent.reset_under_act
             rl = env.reset_launches
-            env_roof["reset"] = {"kernel": "mn_reset_under_act_kernel" if under else "mn_reset_kernel", "on_critical_path": not under,
+            env_roof["reset_kernel"] = {"kernel": "mn_reset_under_act_kernel" if under else "mn_reset_kernel", "on_critical_path": not under,
                                  "under_act_share": (rl[1] / max(1, rl[0] + rl[1])) if under else 0.0, "launch_ms": reset_ms, "launches_timed": reset_launches, "resets_per_launch": resets_per_step,
                                  "bytes_per_reset": rb, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,
                                  "traffic_mb_profiled": PMC_TRAFFIC_MB["reset_f64"] if (headline and args.precision == "f64") else None}

@@ -373,7 +373,7 @@ def test_bench_shared_learner_line(torch, exchange):
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
     # the episode resets ran under the act kernel (an RCCL communicator in the process: the handle's stream needs a hardware queue of its own) and every late row was served
     assert j["config"]["resets"] == "under_next_act" and j["config"]["late_row_timeouts"] == 0
-    assert j["roofline_env_step"]["reset"]["on_critical_path"] is False and j["also"]["reset_in_front"]["value"] > 0
+    assert j["roofline_env_step"]["reset_kernel"]["on_critical_path"] is False and j["also"]["reset_in_front"]["value"] > 0
 
 
 @pytest.mark.parametrize("config", ["c3", "c4", "c4m"])
