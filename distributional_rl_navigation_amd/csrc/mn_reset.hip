@@ -34,19 +34,21 @@ __global__ __launch_bounds__(MN_WAVE) void mn_reset_kernel(MnArrays A, MnDev P, 
         mn_reset_env<M, PARITY>(A, P, S, W, list ? list[qi] : (int)qi, mode, obs_out);
 }
 
-// The same kernel for mn_reset_done_async: it runs on the handle's side stream UNDER the act kernel of the next vector step, whose 512-thread
+// The same body for mn_reset_done_async: it runs on the handle's side stream UNDER the act kernel of the next vector step, whose 512-thread
 // workgroups hold every CU with two wavefronts of 208 registers per SIMD and all but 5.8 KB of the LDS -- so this one is compiled for the 96 registers
-// that are left (five waves per SIMD as the occupancy target), its 3.1 KB of LDS fit, and every finished env announces its first observation (`ready`).
+// that are left on every SIMD (five waves per SIMD as the occupancy target) and keeps the MT19937 block in device memory (MtInPlace: 0.6 KB of LDS per
+// wave instead of 3.1), so that FOUR reset wavefronts fit beside an act workgroup, one per SIMD (round 5: one per CU); every finished env announces its
+// first observation (`ready`).
 template <typename M, bool PARITY>
 __global__ __launch_bounds__(MN_WAVE, 5) void mn_reset_under_act_kernel(MnArrays A, MnDev P, const uint32_t *__restrict__ count_dev,
                                                                         const int32_t *__restrict__ list, float *__restrict__ obs_out,
                                                                         uint32_t *__restrict__ ready, uint32_t tick, const MnSeen seen) {
-    __shared__ MtLds S;
+    __shared__ MtCarryLds S;
     __shared__ WorldLds W;
     const uint32_t count = *count_dev;
     mn_note_count(seen, count);
     for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
-        mn_reset_env<M, PARITY>(A, P, S, W, list[qi], 0, obs_out, ready, tick);
+        mn_reset_env<M, PARITY, MtInPlace>(A, P, S, W, list[qi], 0, obs_out, ready, tick);
 }
 
 // init_genrand (numpy legacy seeding): key[0] = seed, key[i] = 1812433253*(key[i-1]^(key[i-1]>>30)) + i

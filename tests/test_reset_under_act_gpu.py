@@ -78,6 +78,43 @@ def test_every_row_late(torch):
     _same(torch, a, b)
 
 
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+def test_reset_with_the_rng_block_in_device_memory_equals_the_lds_form(torch, precision):
+    """The under-act reset kernel reads each env's MT19937 row in place and regenerates it out of registers (MtInPlace, csrc/mn_reset_body.h) where the
+    kernel in front of the act launch copies it into LDS.  12 consecutive resets of every env (max_episode_steps = 1: each one consumes ~300 of the 624
+    words of a block, so every env crosses ~5 block boundaries, with 0-6 words carried over) through both: worlds, poses, first observations and the
+    stream position (the next double every env would draw) identical."""
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    outs = []
+    for under in (False, True):
+        env = VecMarineNavEnv(3000, seed=17, device=DEV, precision=precision)
+        env.params.max_episode_steps = 1
+        env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+        env.set_reset_under_act_max(2 ** 31 - 1)
+        obs = env.reset()
+        a = torch.zeros(3000, dtype=torch.int32, device=DEV)
+        first = []
+        for t in range(12):
+            env.step(a)
+            env.step(a)                      # the second step of an episode times out: every env is done
+            assert int(env.done.sum()) == 3000
+            obs = env.reset_done(under_next_act=under)
+            assert (env.late_rows is not None) == under
+            env.join_reset()
+            torch.cuda.synchronize()
+            first.append(obs.clone())
+        worlds = env.get_worlds()
+        outs.append((torch.stack(first), env.peek_next_double(), env.get_state(), worlds))
+        assert env.reset_launches == ([0, 12] if under else [0, 0])      # (counts reset_done(under_next_act=True) calls: [ran in front, ran under])
+        env.close()
+    (o0, p0, s0, w0), (o1, p1, s1, w1) = outs
+    assert torch.equal(o0, o1) and np.array_equal(p0, p1)
+    for x, y in zip(s0, s1):
+        assert np.array_equal(x, y)
+    for x, y in zip(w0, w1):
+        assert np.array_equal(x["cores"], y["cores"]) and np.array_equal(x["obstacles"], y["obstacles"])
+
+
 def test_forms_without_late_rows_keep_the_reset_in_front(torch):
     """Launch-shared taus (another kernel form) cannot take late rows: vec_step leaves the reset in front (`late_rows_possible`), and an act call that
     is handed a pending reset it cannot honour joins it first -- same results as the plain loop either way."""
