@@ -33,6 +33,8 @@ means is written HERE, not in the line.
   also.*                other configurations timed by the same run (N = 1): config1 = BASELINE configs[1] (4 096 envs, random policy, kernels only) per
                         world size (cores_obstacles) and arithmetic: [launch-pair M env steps/s, mn_rollout T=100 M env steps/s, step kernel us];
                         reset_in_front = the loop with the episode resets in front of the act kernel instead of under it (config.resets);
+                        late_curriculum = the same loop where the end of a training run lives (eps 0.05, ~2 300 episode ends per vector step: resets_per_launch;
+                        under_act_share of its reset launches; .reset_in_front = that regime with the resets in front of the act kernel);
                         act_exact_f32 = the loop with the exact-f32 MFMA act kernel; shared_learner_ws1 = learner alone, grad-steps/s: one launch per
                         step, the RCCL all-reduce at world size 1 eager / inside captured 16-step graphs, the mailbox exchange inside the one-launch
                         step; act_shared_taus (opt-in: 32 taus per launch instead of per env; tiled = environments in the MFMA columns, wave = wavefront
@@ -305,6 +307,33 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
                               "frac_algorithmic_remaining": ACT_SHARED_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
                               "frac_algorithmic_full_network": ACT_FLOP_PER_ENV_STEP * rate / F16_MFMA_PEAK_TFLOPS if rate else None,
                               "frac_issued": ACT_SHARED_MFMA_FLOP * rate / F16_MFMA_PEAK_TFLOPS if rate else None}
+    # (a'') the main loop in the regime the END of a training run is in: eps 0.05 and ~2 300 episode ends per vector step (scripts/soak.py: the curriculum's steady
+    # state; the headline's eps ~ 1 start has ~300).  Forced here with a short episode limit and episode ages spread uniformly (no burst): 65 536 / 40 time-outs
+    # per step on top of the collisions / goals of the untrained policy.  Same kernels, same cadence as `value`.
+    if agent.reset_under_act:
+        import numpy as np
+        L_late = 40
+        env.join_reset()
+        env.params.max_episode_steps = L_late
+        env.set_attrs()
+        env.set_state(episode_timesteps=np.random.RandomState(0).randint(0, L_late, size=n))
+        late_step = lambda o: agent.vec_step(env, o, 0.05, args.cvar, per_iter=n)[0]
+        steps = max(20, args.steps)
+        rl0 = list(env.reset_launches)
+        dt, obs = _timed(device, late_step, steps, 40, obs)
+        rl1 = [b - a for a, b in zip(rl0, env.reset_launches)]
+        agent.reset_under_act = False
+        dt_f, obs = _timed(device, late_step, steps, 10, obs)
+        agent.reset_under_act = True
+        env.join_reset()
+        cnt = []
+        for _ in range(8):
+            a = agent.act_batch(obs, 0.05, args.cvar)
+            env.step(a); cnt.append(env.last_done_count()); obs = env.reset_done()
+        env.params.max_episode_steps = 1000
+        env.set_attrs()
+        out["late_curriculum"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "eps": 0.05, "resets_per_launch": sum(cnt) / len(cnt),
+                                  "under_act_share": rl1[1] / max(1, rl1[0] + rl1[1]), "reset_in_front": n * steps / dt_f}
     # (b) the cadence that trains
     ue, gs = agent.UPDATE_EVERY, agent.grad_steps_per_update
     agent.UPDATE_EVERY, agent.grad_steps_per_update = 1, 16
@@ -369,8 +398,8 @@ def main():
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     ap.add_argument("--reset-in-front", action="store_true", help="episode resets in front of the act kernel (mn_reset_done) instead of under it "
                                                                   "(mn_reset_done_async + late rows; IQNAgent.reset_under_act, the default)")
-    ap.add_argument("--reset-under-act-max", type=int, default=1200, help="mn_set_reset_under_act_max: resets go under the act kernel while the launches' decaying peak of "
-                                                                          "episode ends per vector step is at most this (the library's default)")
+    ap.add_argument("--reset-under-act-max", type=int, default=None, help="mn_set_reset_under_act_max: resets go under the act kernel while the launches' decaying peak of "
+                                                                          "episode ends per vector step is at most this (default: the library's, 6000)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
                                                                "timed by the default run as also.act_shared_taus)")
@@ -497,14 +526,17 @@ def main():
     resets_note = None
     if agent is not None and agent.reset_under_act and fused and not roll:
         # the under-act resets need the reset launch to run BESIDE the act kernel (own hardware queue, room on the CUs): make sure of it before the timed
-        # region -- a dozen more untimed steps with every reset forced under the act kernel, then the late-row waits must all have been served
-        from distributional_rl_navigation_amd.iqn.fused_act import late_timeouts
-        env.set_reset_under_act_max(2 ** 31 - 1)
-        obs = run_steps(12, obs)
-        env.join_reset()
-        env.set_reset_under_act_max(args.reset_under_act_max)
-        if late_timeouts(agent.qnetwork_local):
-            agent.reset_under_act = False
+        # region, the way IQNAgent.learn_vec does -- a dozen more untimed steps with every reset forced under the act kernel (iqn/agent.py: UnderActGuard); if
+        # a late row's wait ran out the loop goes back to resets in front and the line says so
+        from distributional_rl_navigation_amd.iqn.agent import UnderActGuard
+        if args.reset_under_act_max is not None:
+            env.set_reset_under_act_max(args.reset_under_act_max)
+        guard = UnderActGuard(agent, env, preflight=12, poll_every=0)
+        for i in range(12):
+            obs = run_steps(1, obs)
+            guard.after_step(i)
+        guard.close()
+        if guard.fallback is not None:
             resets_note = "in_front_of_act (the reset launch did not run beside the act kernel on this box: late rows timed out)"
     g0 = agent.grad_steps if agent else 0
     clock_before = gpu_clock_probe(device) if (rank == 0 and not args.no_clock_probe) else None      # ~50 ms of matrix load, outside the timed region
@@ -515,6 +547,7 @@ def main():
     if fused:
         act_context(agent.qnetwork_local).profile_begin(n_prof)
     window_s = []
+    rl_before = list(env.reset_launches)
     for w in range(max(1, args.windows)):
         fence()
         t0 = time.perf_counter()
@@ -528,6 +561,7 @@ def main():
         window_s.append(el)
     elapsed = statistics.median(window_s)
     reset_ms, reset_launches = env.profile_reset_end()
+    rl_timed = [b - a for a, b in zip(rl_before, env.reset_launches)]      # reset launches of the timed windows: [in front of, under] the act kernel
     step_kernel_ms, launches = env.profile_end()
     act_ms, act_launches = 0.0, 0
     if fused:
@@ -628,7 +662,7 @@ def main():
         if reset_launches and reset_ms > 0 and resets_per_step:
             gbs = (rb * resets_per_step / (reset_ms * 1e-3) / 1e9) if rb else None
             under = agent is not None and agent.reset_under_act
-            rl = env.reset_launches
+            rl = rl_timed
             env_roof["reset_kernel"] = {"kernel": "mn_reset_under_act_kernel" if under else "mn_reset_kernel", "on_critical_path": not under,
                                  "under_act_share": (rl[1] / max(1, rl[0] + rl[1])) if under else 0.0, "launch_ms": reset_ms, "launches_timed": reset_launches, "resets_per_launch": resets_per_step,
                                  "bytes_per_reset": rb, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,

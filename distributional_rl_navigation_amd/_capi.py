@@ -69,6 +69,7 @@ SIGNATURES = [
     ("mn_reset_done_async", C.c_int, [_vp, _pf, _vp, C.POINTER(_vp), C.POINTER(C.c_uint32)]),
     ("mn_reset_join", C.c_int, [_vp, _vp]),
     ("mn_set_reset_under_act_max", C.c_int, [_vp, _i32, C.POINTER(C.c_int64)]),
+    ("mn_debug_side_delay_us", C.c_int, [_vp, _i32]),
     ("mn_load_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd, _pf, _vp]),
     ("mn_get_worlds", C.c_int, [_vp, _i32, _i32, _pi32, _pd, _pi32, _pd, _pi32, _pd, _pd, _pd, _pd, _pd, _pd]),
     ("mn_get_state", C.c_int, [_vp, _i32, _i32, _pd, _pi32, _pi64]),
@@ -91,6 +92,8 @@ SIGNATURES = [
     ("mn_iqn_set_tau_mode", C.c_int, [_vp, _i32]),
     ("mn_iqn_set_late_rows", C.c_int, [_vp, _vp, _vp, C.c_uint32, _i32]),
     ("mn_iqn_late_timeouts", C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
+    ("mn_iqn_late_timeouts_peek", C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    ("mn_iqn_set_late_bound_ms", C.c_int, [_vp, C.c_double]),
     ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
     ("mn_iqn_train_step", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32,
                                     _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),

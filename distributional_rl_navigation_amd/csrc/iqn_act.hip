@@ -831,6 +831,9 @@ struct mn_iqn_ctx {
     int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
     sp::LateRows late = {};                 // mn_iqn_set_late_rows: consumed by the next launch
     uint32_t *late_status = nullptr;        // waits of late rows that ran out (device word)
+    volatile uint32_t *late_status_host = nullptr;      // ... and the host-mapped copy the kernel keeps of it (mn_iqn_late_timeouts_peek: no synchronisation)
+    uint32_t *late_status_host_dev = nullptr;
+    uint64_t late_bound_ticks = sp::LATE_BOUND_TICKS;    // mn_iqn_set_late_bound_ms
     std::vector<hipEvent_t> ev;
     int prof_max = 0, prof_n = 0;
 };
@@ -911,6 +914,7 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     (void)hipFree(c->timg);
     (void)hipFree(c->taux);
     (void)hipFree(c->late_status);
+    if (c->late_status_host) (void)hipHostFree((void *)c->late_status_host);
     if (moved) (void)hipSetDevice(cur);
     delete c;
     return MN_OK;
@@ -983,11 +987,16 @@ extern "C" int mn_iqn_set_late_rows(mn_iqn_ctx *c, const uint8_t *mask_dev, cons
     if (!mask_dev && !flags_dev) return MN_OK;      // clear
     if (!mask_dev || !flags_dev) return MN_ERR_INVALID;
     if (!late_rows_supported(c, n, false)) return 1;
-    if (!c->late_status) {
-        if (hipMalloc(reinterpret_cast<void **>(&c->late_status), sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
-        if (hipMemset(c->late_status, 0, sizeof(uint32_t)) != hipSuccess) return MN_ERR_HIP;
+    if (!c->late_status) {      // (all or nothing: the context only keeps the words once every allocation has succeeded)
+        uint32_t *st = nullptr;
+        void *hp = nullptr, *hd = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&st), sizeof(uint32_t)) != hipSuccess) return MN_ERR_ALLOC;
+        if (hipMemset(st, 0, sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) { (void)hipFree(st); return MN_ERR_ALLOC; }
+        *(volatile uint32_t *)hp = 0u;
+        if (hipHostGetDevicePointer(&hd, hp, 0) != hipSuccess) { (void)hipFree(st); (void)hipHostFree(hp); return MN_ERR_HIP; }
+        c->late_status = st; c->late_status_host = (volatile uint32_t *)hp; c->late_status_host_dev = (uint32_t *)hd;
     }
-    c->late = sp::LateRows{mask_dev, flags_dev, tick, c->late_status};
+    c->late = sp::LateRows{mask_dev, flags_dev, tick, c->late_status, c->late_status_host_dev, c->late_bound_ticks};
     return MN_OK;
 }
 
@@ -998,6 +1007,21 @@ extern "C" int mn_iqn_late_timeouts(mn_iqn_ctx *c, void *stream, uint32_t *out) 
     if (!c->late_status) return MN_OK;
     if (hipMemcpyAsync(out, c->late_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return MN_ERR_HIP;
     return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MN_OK : MN_ERR_HIP;
+}
+
+// The same count as the launches executed so far have left it in a host-mapped word: no synchronisation, so a training loop can look every few
+// vector steps (a launch still in flight is not counted yet).
+extern "C" int mn_iqn_late_timeouts_peek(mn_iqn_ctx *c, uint32_t *out) {
+    if (!c || !out) return MN_ERR_INVALID;
+    *out = c->late_status_host ? *c->late_status_host : 0u;
+    return MN_OK;
+}
+
+// Bound of a late row's wait in milliseconds (default 500; tests use a short one).  Applies to launches armed after the call.
+extern "C" int mn_iqn_set_late_bound_ms(mn_iqn_ctx *c, double ms) {
+    if (!c || !(ms > 0.0) || ms > 60000.0) return MN_ERR_INVALID;
+    c->late_bound_ticks = (uint64_t)(ms * 1.0e5);      // 100 MHz counter
+    return MN_OK;
 }
 
 static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev, const float *const *weights, float *qvals_dev,

@@ -840,7 +840,9 @@ struct LateRows {
     const uint8_t *mask;       // [n] != 0: the row is rewritten by the reset running beside this launch
     const uint32_t *flag;      // [n] == tick once it has been
     uint32_t tick;
-    uint32_t *status;          // += 1 per wait that ran out (then the row is taken as it is: the caller raises)
+    uint32_t *status;          // += 1 per wait that ran out (then the row is taken as it is: the caller falls back to resets in front / raises)
+    uint32_t *status_host;     // host-mapped copy of that count, which the host reads without synchronising (mn_iqn_late_timeouts_peek)
+    uint64_t bound_ticks;      // the bound of a wait in ticks of the 100 MHz counter (mn_iqn_set_late_bound_ms; default 0.5 s)
 };
 constexpr uint64_t LATE_BOUND_TICKS = 50000000ull;      // 0.5 s of the 100 MHz counter
 
@@ -972,8 +974,8 @@ __global__ __launch_bounds__(64 * NW) void iqn_qvals_split_kernel(const float *_
                 const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
                 while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != late.tick) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > LATE_BOUND_TICKS) {
-                        if (lane == 0) atomicAdd(late.status, 1u);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > late.bound_ticks) {
+                        if (lane == 0) __hip_atomic_store(late.status_host, atomicAdd(late.status, 1u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                 }

@@ -37,7 +37,9 @@ struct mn_handle {
     // decaying peak of the episodes the queue-driven reset launches start (mn_reset.hip: mn_note_count): device word + host-mapped copy (read without synchronising)
     volatile uint32_t *seen_host = nullptr;
     uint32_t *seen_dev = nullptr, *peak_dev = nullptr;
-    int32_t under_act_max = 1200;          // mn_reset_done_async: above this peak the reset runs in front of the act kernel
+    int32_t under_act_max = MN_RESET_UNDER_ACT_MAX_DEFAULT;      // mn_reset_done_async: above this peak the reset runs in front of the act kernel
+    bool async_ready = false;              // side stream, events, `ready`, the peak words: all there
+    int32_t side_delay_us = 0;             // mn_debug_side_delay_us (tests): a sleeping kernel in front of every reset launch on the side stream
 };
 
 static thread_local std::string g_create_err;
@@ -214,7 +216,8 @@ extern "C" int mn_create(int32_t n_envs, const mn_params *p, mn_handle **out) {
     ALLOC(qcx, np * MN_MAX_CORES) ALLOC(qcy, np * MN_MAX_CORES) ALLOC(qcg, np * MN_MAX_CORES)
     ALLOC(qox, np * MN_MAX_OBS) ALLOC(qoy, np * MN_MAX_OBS) ALLOC(qor, np * MN_MAX_OBS)
     ALLOC(mt, np * 624) ALLOC(mt_pos, np)
-    ALLOC(queue_count, 2) ALLOC(queue, np)
+    A.qcap = (int32_t)(((np >> 6) + MN_QSHARDS - 1) / MN_QSHARDS * 64);
+    ALLOC(queue_count, 2 * MN_QWORDS) ALLOC(queue, (size_t)MN_QSHARDS * A.qcap)
     // (obs64 / rew64 -- float64 copies of the last observation rows / rewards -- are allocated and written only after mn_enable_obs64)
 #undef ALLOC
     if ((rc = dev_alloc(h, &h->seeds_dev, np)) || (rc = dev_alloc(h, &h->mask_count, 1)) ||
@@ -426,24 +429,26 @@ extern "C" int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, c
     hipStream_t s = (hipStream_t)stream;
     join_reset(h, s);
     MN_ON_DEVICE(h);
-    if (!h->side) {
+    if (!h->async_ready) {
         // a stream of ANOTHER priority gets a hardware queue of its own: created with the default priority it can end up sharing the queue of the caller's
         // stream (HIP deals streams out over a few queues; with an RCCL communicator in the process it did), and then the reset launch simply runs in front of
         // the act kernel again, behind two cross-stream events (measured: 0.380 instead of 0.360 ms per vector step)
+        // (every piece is created if it is not there yet -- a call that failed half way is completed by the next one -- and `async_ready` is set last)
         int prio_lo = 0, prio_hi = 0;
         MN_HIP(h, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        MN_HIP(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi));
-        MN_HIP(h, hipEventCreateWithFlags(&h->ev_stepped, hipEventDisableTiming));
-        MN_HIP(h, hipEventCreateWithFlags(&h->ev_reset_end, hipEventDisableTiming));
-        int rc = dev_alloc(h, &h->ready, (size_t)h->A.npad);
-        if (rc) return rc;
-        void *hp = nullptr;
-        MN_HIP(h, hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped));
-        h->seen_host = (volatile uint32_t *)hp;
-        *h->seen_host = 0xffffffffu;      // nothing seen yet: the first launches run in front
-        MN_HIP(h, hipHostGetDevicePointer((void **)&h->seen_dev, hp, 0));
-        rc = dev_alloc(h, &h->peak_dev, 1);
-        if (rc) return rc;
+        if (!h->side) MN_HIP(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi));
+        if (!h->ev_stepped) MN_HIP(h, hipEventCreateWithFlags(&h->ev_stepped, hipEventDisableTiming));
+        if (!h->ev_reset_end) MN_HIP(h, hipEventCreateWithFlags(&h->ev_reset_end, hipEventDisableTiming));
+        if (!h->ready) { int rc = dev_alloc(h, &h->ready, (size_t)h->A.npad); if (rc) return rc; }
+        if (!h->seen_host) {
+            void *hp = nullptr;
+            MN_HIP(h, hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped));
+            *(volatile uint32_t *)hp = 0xffffffffu;      // nothing seen yet: the first launches run in front
+            h->seen_host = (volatile uint32_t *)hp;
+        }
+        if (!h->seen_dev) MN_HIP(h, hipHostGetDevicePointer((void **)&h->seen_dev, (void *)h->seen_host, 0));
+        if (!h->peak_dev) { int rc = dev_alloc(h, &h->peak_dev, 1); if (rc) return rc; }
+        h->async_ready = true;
     }
     *ready_out = nullptr;
     *tick_out = 0;
@@ -453,7 +458,7 @@ extern "C" int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, c
     if (h->under_act_max < 0 || (h->under_act_max != 0x7fffffff && (seen == 0xffffffffu || seen > (uint32_t)h->under_act_max))) {
         const bool prof = h->prof_reset_n < h->prof_max;
         if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], s);
-        mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, s, h->peak_dev, h->seen_dev);
+        mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity * MN_QWORDS, 0, h->A.queue, 0, obs_dev, s, h->peak_dev, h->seen_dev, true);
         if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], s); h->prof_reset_n++; }
         MN_HIP(h, hipGetLastError());
         return MN_OK;
@@ -463,7 +468,8 @@ extern "C" int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, c
     h->tick += 1;
     const bool prof = h->prof_reset_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], h->side);
-    mn_launch_reset_under_act(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, h->A.queue, obs_dev, h->ready, h->tick, h->peak_dev, h->seen_dev, h->side);
+    if (h->side_delay_us > 0) mn_launch_sleep((uint32_t)h->side_delay_us, h->side);
+    mn_launch_reset_under_act(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity * MN_QWORDS, h->A.queue, obs_dev, h->ready, h->tick, h->peak_dev, h->seen_dev, h->side);
     if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], h->side); h->prof_reset_n++; }
     MN_HIP(h, hipGetLastError());
     MN_HIP(h, hipEventRecord(h->ev_reset_end, h->side));
@@ -482,6 +488,14 @@ extern "C" int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, i
     return MN_OK;
 }
 
+// Test hook: every reset launch mn_reset_done_async puts on the handle's own stream is preceded there by a kernel that sleeps `us` microseconds -- a reset
+// launch that does NOT run beside the act kernel (shared hardware queue, no room on the CUs), without needing such a box.  0 switches it off.
+extern "C" int mn_debug_side_delay_us(mn_handle *h, int32_t us) {
+    if (!h || us < 0 || us > 10000000) return MN_ERR_INVALID;
+    h->side_delay_us = us;
+    return MN_OK;
+}
+
 extern "C" int mn_reset_join(mn_handle *h, void *stream) {
     if (!h) return MN_ERR_INVALID;
     join_reset(h, (hipStream_t)stream);
@@ -494,7 +508,7 @@ extern "C" int mn_reset_done(mn_handle *h, float *obs_dev, void *stream) {
     MN_ON_DEVICE(h);
     const bool prof = h->prof_reset_n < h->prof_max;
     if (prof) (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n], (hipStream_t)stream);
-    mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream, h->peak_dev, h->seen_dev);
+    mn_launch_reset(h->A, h->P, h->params.precision, h->A.queue_count + h->last_parity * MN_QWORDS, 0, h->A.queue, 0, obs_dev, (hipStream_t)stream, h->peak_dev, h->seen_dev, true);
     if (prof) { (void)hipEventRecord(h->ev_reset[2 * h->prof_reset_n + 1], (hipStream_t)stream); h->prof_reset_n++; }
     MN_HIP(h, hipGetLastError());
     return MN_OK;
@@ -504,8 +518,9 @@ extern "C" int mn_last_done_count(mn_handle *h, void *stream, int32_t *out) {
     if (!h || !out) return MN_ERR_INVALID;
     MN_ON_DEVICE(h);
     MN_HIP(h, hipStreamSynchronize((hipStream_t)stream));
-    uint32_t v = 0;
-    MN_HIP(h, hipMemcpy(&v, h->A.queue_count + h->last_parity, 4, hipMemcpyDeviceToHost));
+    uint32_t w[MN_QWORDS], v = 0;      // the shard counters of the last step's done-queue
+    MN_HIP(h, hipMemcpy(w, h->A.queue_count + h->last_parity * MN_QWORDS, sizeof(w), hipMemcpyDeviceToHost));
+    for (int sh = 0; sh < MN_QSHARDS; ++sh) v += w[sh * MN_QSTRIDE];
     *out = (int32_t)v;
     return MN_OK;
 }

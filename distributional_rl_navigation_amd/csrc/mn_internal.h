@@ -41,10 +41,16 @@ struct MnArrays {
     // mn_enable_trajectory): what marinenav_env.py:211-212 appends to robot.trajectory
     double *traj;
     int32_t traj_n;
-    // done-queue filled by the step kernel, drained by the reset kernel
-    uint32_t *queue_count;  // [2], alternating per step
-    int32_t *queue;         // [npad]
+    // done-queue filled by the step kernel, drained by the reset kernel.  SHARDED: env e pushes into shard (e >> 6) % MN_QSHARDS (wave-uniform for every lanes-per-env
+    // mapping), every shard has its own counter on its own 128-byte line -- one counter for all (round 1-5) made a vector step with ~2 000 episode ends 11 us longer:
+    // that many returning atomics on ONE address are served one after the other (profiles/r06_done_queue.txt)
+    uint32_t *queue_count;  // [2][MN_QSHARDS * MN_QSTRIDE], alternating per step; shard s at word s * MN_QSTRIDE
+    int32_t *queue;         // [MN_QSHARDS][qcap]
+    int32_t qcap;           // entries per shard = ceil(npad / (64 * MN_QSHARDS)) * 64: every env of the shard can be in it
 };
+#define MN_QSHARDS 32
+#define MN_QSTRIDE 32
+#define MN_QWORDS (MN_QSHARDS * MN_QSTRIDE)
 
 // Host-derived constants (computed once in double with the host libm so that the generated world
 // tables are bit-identical to the numpy reference).
@@ -99,10 +105,12 @@ void mn_launch_rollout_policy(const MnArrays &A, const MnDev &P, int precision, 
                               float *reward_trace, uint8_t *done_trace, uint8_t *info_trace, int32_t *action_trace, hipStream_t s);
 void mn_launch_planner_act(const float *obs, int n, int policy, const double *a, const double *w, int32_t *actions, hipStream_t s);
 // mode 0: full reset (RNG); mode 1: pose-only (keeps the loaded world, no RNG)
+// (mn_launch_reset: `sharded` = count_dev / list_dev are the handle's done-queue of one step -- MN_QSHARDS counters and lists; otherwise one counter, one list)
 void mn_launch_reset_under_act(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, const int32_t *list_dev, float *obs,
                                uint32_t *ready, uint32_t tick, uint32_t *peak_dev, uint32_t *peak_host, hipStream_t s);
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
-                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev = nullptr, uint32_t *peak_host = nullptr);
+                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev = nullptr, uint32_t *peak_host = nullptr, bool sharded = false);
 void mn_launch_seed(const MnArrays &A, const uint32_t *seeds_dev, hipStream_t s);
 void mn_launch_mask_to_queue(const MnArrays &A, const uint8_t *mask, uint32_t *count, int32_t *list, hipStream_t s);
 void mn_launch_peek(const MnArrays &A, int first, int count, double *out_dev, hipStream_t s);
+void mn_launch_sleep(uint32_t us, hipStream_t s);

@@ -22,16 +22,40 @@ __device__ __forceinline__ void mn_note_count(const MnSeen seen, uint32_t count)
         __hip_atomic_store(seen.peak_host, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// The handle's done-queue of one step as a reset wavefront reads it (mn_internal.h: MN_QSHARDS lists, each with its own counter).  open(): lane s < 32 reads
+// shard s's count, `incl` = inclusive prefix sum over the shards (kept in one register), returns the total.  at(qi): the qi-th finished env overall.
+struct MnDoneQueue {
+    uint32_t incl;
+    __device__ __forceinline__ uint32_t open(const uint32_t *__restrict__ counts) {
+        const int lane = threadIdx.x & (MN_WAVE - 1);
+        uint32_t v = lane < MN_QSHARDS ? counts[lane * MN_QSTRIDE] : 0u;
+#pragma unroll
+        for (int off = 1; off < MN_QSHARDS; off <<= 1) {
+            const uint32_t t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        incl = v;
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, MN_QSHARDS - 1);
+    }
+    __device__ __forceinline__ int at(const int32_t *__restrict__ lists, int qcap, uint32_t qi) const {
+        const int lane = threadIdx.x & (MN_WAVE - 1);
+        const int sh = __popcll(__ballot(lane < MN_QSHARDS && incl <= qi));      // shards that end at or before entry qi
+        const uint32_t before = sh ? (uint32_t)__builtin_amdgcn_readlane((int)incl, __builtin_amdgcn_readfirstlane(sh - 1)) : 0u;
+        return lists[(size_t)sh * qcap + (qi - before)];
+    }
+};
+
 template <typename M, bool PARITY>
 __global__ __launch_bounds__(MN_WAVE) void mn_reset_kernel(MnArrays A, MnDev P, const uint32_t *__restrict__ count_dev,
                                                            uint32_t count_host, const int32_t *__restrict__ list, int mode,
-                                                           float *__restrict__ obs_out, const MnSeen seen) {
+                                                           float *__restrict__ obs_out, const MnSeen seen, int qcap) {
     __shared__ MtLds S;
     __shared__ WorldLds W;
-    const uint32_t count = count_dev ? *count_dev : count_host;
+    MnDoneQueue Q;
+    const uint32_t count = qcap ? Q.open(count_dev) : (count_dev ? *count_dev : count_host);      // qcap != 0: the sharded done-queue
     mn_note_count(seen, count);
     for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
-        mn_reset_env<M, PARITY>(A, P, S, W, list ? list[qi] : (int)qi, mode, obs_out);
+        mn_reset_env<M, PARITY>(A, P, S, W, qcap ? Q.at(list, qcap, qi) : (list ? list[qi] : (int)qi), mode, obs_out);
 }
 
 // The same body for mn_reset_done_async: it runs on the handle's side stream UNDER the act kernel of the next vector step, whose 512-thread
@@ -45,10 +69,11 @@ __global__ __launch_bounds__(MN_WAVE, 5) void mn_reset_under_act_kernel(MnArrays
                                                                         uint32_t *__restrict__ ready, uint32_t tick, const MnSeen seen) {
     __shared__ MtCarryLds S;
     __shared__ WorldLds W;
-    const uint32_t count = *count_dev;
+    MnDoneQueue Q;
+    const uint32_t count = Q.open(count_dev);
     mn_note_count(seen, count);
     for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x)
-        mn_reset_env<M, PARITY, MtInPlace>(A, P, S, W, list[qi], 0, obs_out, ready, tick);
+        mn_reset_env<M, PARITY, MtInPlace>(A, P, S, W, Q.at(list, A.qcap, qi), 0, obs_out, ready, tick);
 }
 
 // init_genrand (numpy legacy seeding): key[0] = seed, key[i] = 1812433253*(key[i-1]^(key[i-1]>>30)) + i
@@ -100,16 +125,17 @@ __global__ void mn_peek_kernel(MnArrays A, int first, int count, double *out) {
 }  // namespace
 
 void mn_launch_reset(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, uint32_t count_host,
-                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev, uint32_t *peak_host) {
+                     const int32_t *list_dev, int mode, float *obs, hipStream_t s, uint32_t *peak_dev, uint32_t *peak_host, bool sharded) {
+    const int qcap = sharded ? A.qcap : 0;
     const MnSeen seen = {peak_dev, peak_host};
     // enough waves to fill the chip several times over; each wave loops over queue entries
     uint32_t cap = count_dev ? (uint32_t)A.n : count_host;
     uint32_t blocks = cap < MN_RESET_MAX_BLOCKS ? cap : MN_RESET_MAX_BLOCKS;
     if (blocks == 0) return;
     if (precision == MN_PRECISION_F64)
-        hipLaunchKernelGGL((mn_reset_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen);
+        hipLaunchKernelGGL((mn_reset_kernel<double, true>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen, qcap);
     else
-        hipLaunchKernelGGL((mn_reset_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen);
+        hipLaunchKernelGGL((mn_reset_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, count_host, list_dev, mode, obs, seen, qcap);
 }
 
 void mn_launch_reset_under_act(const MnArrays &A, const MnDev &P, int precision, const uint32_t *count_dev, const int32_t *list_dev, float *obs,
@@ -122,6 +148,13 @@ void mn_launch_reset_under_act(const MnArrays &A, const MnDev &P, int precision,
     else
         hipLaunchKernelGGL((mn_reset_under_act_kernel<float, false>), dim3(blocks), dim3(MN_WAVE), 0, s, A, P, count_dev, list_dev, obs, ready, tick, seen);
 }
+
+// one wavefront that does nothing for `us` microseconds (mn_debug_side_delay_us)
+__global__ void mn_sleep_kernel(uint32_t us) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(64);
+}
+void mn_launch_sleep(uint32_t us, hipStream_t s) { hipLaunchKernelGGL(mn_sleep_kernel, dim3(1), dim3(MN_WAVE), 0, s, us); }
 
 void mn_launch_seed(const MnArrays &A, const uint32_t *seeds_dev, hipStream_t s) {
     hipLaunchKernelGGL(mn_seed_kernel, dim3((A.n + 255) / 256), dim3(256), 0, s, A, seeds_dev);

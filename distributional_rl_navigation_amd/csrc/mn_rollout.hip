@@ -65,7 +65,7 @@ __global__ __launch_bounds__(MN_WAVE, MN_ROLLOUT_MIN_WAVES(L)) void mn_rollout_k
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / L, q = tid % L;
     const size_t n = (size_t)A.n;
-    if (tid == 0) { A.queue_count[0] = 0u; A.queue_count[1] = 0u; }   // nothing is left for a later mn_reset_done
+    if (tid < 2 * MN_QSHARDS) A.queue_count[tid * MN_QSTRIDE] = 0u;   // (both parities' shard counters) nothing is left for a later mn_reset_done
     const MnRing none = {};
 
     Lane ln;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(MN_WAVE, 1) void mn_rollout_policy_kernel(MnArrays 
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = tid / L, q = tid % L, slot = (threadIdx.x & (MN_WAVE - 1)) / L;
     const size_t n = (size_t)A.n;
-    if (tid == 0) { A.queue_count[0] = 0u; A.queue_count[1] = 0u; }
+    if (tid < 2 * MN_QSHARDS) A.queue_count[tid * MN_QSTRIDE] = 0u;
     const MnRing none = {};
     MnPlanTabs tabs;
 #pragma unroll

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
     const int e = tid / L;        // environment (< npad: the grid covers exactly npad * L lanes)
     const int q = tid % L;        // lane within the env's group
 
-    if (tid == 0) A.queue_count[parity ^ 1] = 0u;  // counter the NEXT step will fill
+    if (tid < MN_QSHARDS) A.queue_count[(parity ^ 1) * MN_QWORDS + tid * MN_QSTRIDE] = 0u;  // counters the NEXT step will fill
 
     Lane ln;
     ln.load(A, e, q);
@@ -43,17 +43,18 @@ __global__ __launch_bounds__(MN_STEP_BLOCK, 2) void mn_step_kernel(MnArrays A, M
         done_out[e] = (uint8_t)o.done;
         info_out[e] = (uint8_t)o.info;
     }
-    // done-queue: one atomic per wave
+    // done-queue: one atomic per wave, on the counter of the wave's shard (its 64 / L envs lie in one aligned group of 64: mn_internal.h)
     {
         const bool mine = ln.active && o.done && q == 0;
         const unsigned long long m = __ballot(mine);
         if (m) {
             const int lane = threadIdx.x & (MN_WAVE - 1);
             const int leader = __ffsll((long long)m) - 1;
+            const int sh = __shfl((e >> 6) & (MN_QSHARDS - 1), leader);
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(&A.queue_count[parity], (unsigned)__popcll(m));
+            if (lane == leader) base = atomicAdd(&A.queue_count[parity * MN_QWORDS + sh * MN_QSTRIDE], (unsigned)__popcll(m));
             base = __shfl(base, leader);
-            if (mine) A.queue[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            if (mine) A.queue[(size_t)sh * A.qcap + base + __popcll(m & ((1ull << lane) - 1ull))] = e;
         }
     }
 }

@@ -10,6 +10,7 @@ one flat 35 785-float gradient bucket, one all_reduce per grad step.
 import json
 import os
 import random
+import sys
 
 import numpy as np
 import torch
@@ -24,6 +25,69 @@ from .replay_buffer import ReplayBuffer
 def calculate_huber_loss(td_errors, k=1.0):
     """agent.py:401-407, element-wise Huber with threshold k."""
     return torch.where(td_errors.abs() <= k, 0.5 * td_errors.pow(2), k * (td_errors.abs() - 0.5 * k))
+
+
+class UnderActGuard:
+    """Keeps `IQNAgent.reset_under_act` honest on the box the loop actually runs on.
+
+    Episode resets under the next act kernel (mn_reset_done_async) need the reset launch to run BESIDE that kernel: a hardware queue of its own and room
+    on the CUs next to the act workgroups.  HIP promises neither (another ROCm release, a partitioned or shared GPU).  When it does not happen, every late
+    row waits out its bound and is then taken as it is.  So the first `preflight` vector steps of a loop run with EVERY reset forced under the act kernel
+    (whatever the library's episode-count rule would decide), the late-row waits that ran out are read after step 2 and after the last preflight step,
+    and -- if there were any -- the loop goes back to resets in front of the act kernel with one line on stderr instead of failing at its first evaluation
+    point.  After that the count is looked at every `poll_every` steps without synchronising (mn_iqn_late_timeouts_peek).  Call `after_step(i)` behind
+    vector step i = 0, 1, ...; `close()` restores the library's rule if the loop ends inside the preflight.
+    The preflight steps ARE steps of the run: with the resets served in time their results are those of resets in front, bit for bit; if not, a dozen
+    vector steps at the start of a run chose some actions from unfinished observation rows (at eps ~ 1, where the choice is random anyway)."""
+
+    def __init__(self, agent, env, preflight=12, poll_every=64, log=None):
+        self.agent, self.env = agent, env
+        self.preflight, self.poll_every = int(preflight), int(poll_every)
+        self.log = log
+        self.fallback = None      # dict(step=, timeouts=) once the loop has gone back to resets in front
+        self.active = bool(agent.reset_under_act) and agent.device.type == "cuda" and agent.use_fused_act and hasattr(env, "set_reset_under_act_max")
+        self._restore = None
+        if self.active:
+            self._seen0 = agent._late_acknowledged      # (time-outs an earlier loop of this agent has already answered with its fallback do not count again)
+            if self.preflight > 0:
+                self._restore = env.reset_under_act_max
+                env.set_reset_under_act_max(2 ** 31 - 1)
+
+    def _end_preflight(self):
+        if self._restore is not None:
+            self.env.set_reset_under_act_max(self._restore)
+            self._restore = None
+
+    def _fall_back(self, step, k):
+        self.agent.reset_under_act = False
+        self.env.join_reset()
+        self._end_preflight()
+        self.fallback = dict(step=int(step), timeouts=int(k))
+        self.agent._late_acknowledged = self._seen0 + int(k)
+        self.active = False
+        msg = (f"reset_under_act: {k} act rows were taken before their episode reset had finished (by vector step {step}): the reset launch does not run beside the act "
+               "kernel on this device -- episode resets go in front of the act kernel from here on (mn_reset_done)")
+        (self.log or (lambda m: print(m, file=sys.stderr, flush=True)))(msg)
+
+    def after_step(self, i):
+        if not self.active:
+            return
+        from .fused_act import late_timeouts, late_timeouts_peek
+        if i < self.preflight:
+            if i == 1 or i == self.preflight - 1:
+                self.env.join_reset()
+                k = late_timeouts(self.agent.qnetwork_local) - self._seen0      # (synchronises: twice per loop)
+                if k > 0:
+                    return self._fall_back(i, k)
+                if i == self.preflight - 1:
+                    self._end_preflight()
+        elif self.poll_every > 0 and (i - self.preflight) % self.poll_every == self.poll_every - 1:
+            k = late_timeouts_peek(self.agent.qnetwork_local) - self._seen0
+            if k > 0:
+                self._fall_back(i, k)
+
+    def close(self):
+        self._end_preflight()
 
 
 class IQNAgent(ReferenceLoopMixin):
@@ -60,6 +124,8 @@ class IQNAgent(ReferenceLoopMixin):
                                                      # `obs` vec_step returns then has rows still being written: hand it back to vec_step, or call `train_env.join_reset()` before
                                                      # reading it.  On in learn_vec / train_iqn / bench.py; off by default for callers that look at `obs` between steps
         self.use_train_graph = False                 # opt-in: grad step replayed from a captured hipGraph (measured: no gain, the step is bound by kernel time, not launches)
+        self._late_acknowledged = 0                  # late-row time-outs of the act context that a loop has already answered by going back to resets in front (UnderActGuard)
+        self.under_act_fallback = None               # learn_vec: dict(step, timeouts) if that happened in the last loop
         self._graph = None
         self._graph_bypass_logged = False
         # GPU: the whole optimizer step as five HIP kernels (csrc/iqn_train.hip: sample, forward+backward, reduce, norm,
@@ -421,45 +487,56 @@ class IQNAgent(ReferenceLoopMixin):
         ep_ret = torch.zeros(n, device=self.device)
         ep_len = torch.zeros(n, device=self.device)
         stats = dict(episodes=0, successes=0, collisions=0, timeouts=0, loss=None)
-        # this loop never looks at `obs` between two vector steps, so the resets can run under the next step's act kernel (see `reset_under_act`)
+        # this loop never looks at `obs` between two vector steps, so the resets can run under the next step's act kernel (see `reset_under_act`) -- checked on this
+        # device by the loop's first steps (UnderActGuard: falls back to resets in front with one log line if the reset launch does not run beside the act kernel)
         was_under_act, self.reset_under_act = self.reset_under_act, bool(reset_under_act)
-        for it in range(total_vector_steps):
-            eps = self.linear_eps(total_timesteps)
-            evaluate_now = eval_env is not None and cadence_tick(self, train_every, eval_freq).evaluate      # (the state vec_step's own tick sees)
-            obs, reward, done, info, loss = self.vec_step(train_env, obs, eps, cvar, train_every, per_iter)
-            if loss is not None:
-                stats["loss"] = loss
-            if verbose:
-                ep_ret += (train_env.discount ** ep_len) * reward
-                ep_len += 1
-                d = done.bool()
-                stats["episodes"] += int(d.sum())
-                stats["successes"] += int((info == 4).sum())
-                stats["collisions"] += int((info == 3).sum())
-                stats["timeouts"] += int((info == 2).sum())
-                ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
-            if evaluate_now:
-                self.check_learner()      # (a device synchronisation; the evaluation below is one anyway)
-                res = self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
-                if eval_adaptive:
-                    self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
-                # agent.py:140-148 keeps the LATEST network at every evaluation point; the batched run also keeps the BEST greedy evaluation so far beside it
-                # (`best_*`: ~1 run in 12 ends on a checkpoint far below its own best -- profiles/r05_learning_curve.txt)
-                score = (int(sum(res["successes"])), float(np.mean(res["rewards"])))
-                if self.best_eval is None or score > self.best_eval["score"]:
-                    self.best_eval = dict(score=score, timestep=self.eval_timesteps["greedy"][-1], grad_steps=self.grad_steps, vector_step=it)
+        guard = UnderActGuard(self, train_env)
+        self.under_act_fallback = None
+        try:
+            for it in range(total_vector_steps):
+                eps = self.linear_eps(total_timesteps)
+                evaluate_now = eval_env is not None and cadence_tick(self, train_every, eval_freq).evaluate      # (the state vec_step's own tick sees)
+                obs, reward, done, info, loss = self.vec_step(train_env, obs, eps, cvar, train_every, per_iter)
+                guard.after_step(it)
+                if loss is not None:
+                    stats["loss"] = loss
+                if verbose:
+                    ep_ret += (train_env.discount ** ep_len) * reward
+                    ep_len += 1
+                    d = done.bool()
+                    stats["episodes"] += int(d.sum())
+                    stats["successes"] += int((info == 4).sum())
+                    stats["collisions"] += int((info == 3).sum())
+                    stats["timeouts"] += int((info == 2).sum())
+                    ep_ret.masked_fill_(d, 0.0); ep_len.masked_fill_(d, 0.0)
+                if evaluate_now:
+                    self.check_learner()      # (a device synchronisation; the evaluation below is one anyway)
+                    res = self.evaluation_vec(eval_env, eval_config, greedy=True, eval_log_path=eval_log_path)
+                    if eval_adaptive:
+                        self.evaluation_vec(eval_env, eval_config, greedy=False, eval_log_path=eval_log_path)
+                    # agent.py:140-148 keeps the LATEST network at every evaluation point; the batched run also keeps the BEST greedy evaluation so far beside it
+                    # (`best_*`: ~1 run in 12 ends on a checkpoint far below its own best -- profiles/r05_learning_curve.txt)
+                    score = (int(sum(res["successes"])), float(np.mean(res["rewards"])))
+                    if self.best_eval is None or score > self.best_eval["score"]:
+                        self.best_eval = dict(score=score, timestep=self.eval_timesteps["greedy"][-1], grad_steps=self.grad_steps, vector_step=it)
+                        if eval_log_path is not None:
+                            self.qnetwork_local.save(eval_log_path, prefix="best_")
+                            with open(os.path.join(eval_log_path, "best_evaluation.json"), "w") as f:
+                                json.dump(dict(successes=score[0], n_worlds=len(res["successes"]), mean_return=score[1], **{k: v for k, v in self.best_eval.items() if k != "score"}), f)
                     if eval_log_path is not None:
-                        self.qnetwork_local.save(eval_log_path, prefix="best_")
-                        with open(os.path.join(eval_log_path, "best_evaluation.json"), "w") as f:
-                            json.dump(dict(successes=score[0], n_worlds=len(res["successes"]), mean_return=score[1], **{k: v for k, v in self.best_eval.items() if k != "score"}), f)
-                if eval_log_path is not None:
-                    self.qnetwork_local.save(eval_log_path)
-            if on_step is not None:
-                on_step(it, stats)
-        self.reset_under_act = was_under_act
-        if hasattr(train_env, "join_reset"):
-            train_env.join_reset()
-        self.check_learner()
+                        self.qnetwork_local.save(eval_log_path)
+                if on_step is not None:
+                    on_step(it, stats)
+            # the end-of-run look at the bounded waits happens while `reset_under_act` still says how this loop ran (every rank, evaluation env or not)
+            if hasattr(train_env, "join_reset"):
+                train_env.join_reset()
+            self.check_learner()
+        finally:
+            guard.close()
+            self.under_act_fallback = guard.fallback
+            self.reset_under_act = was_under_act
+            if hasattr(train_env, "join_reset"):
+                train_env.join_reset()
         return stats
 
     def check_learner(self):
@@ -469,8 +546,8 @@ class IQNAgent(ReferenceLoopMixin):
             self._fused.check_timeouts()
         if self.reset_under_act and self.device.type == "cuda" and self.use_fused_act:
             from .fused_act import late_timeouts
-            k = late_timeouts(self.qnetwork_local)
-            if k:
+            k = late_timeouts(self.qnetwork_local) - self._late_acknowledged
+            if k > 0:
                 raise RuntimeError(f"{k} act rows were taken before their episode reset had finished (mn_iqn_late_timeouts): the reset launch did not run beside the act kernel")
 
     def vec_step(self, train_env, obs, eps, cvar=1.0, train_every=None, per_iter=None):

@@ -206,6 +206,22 @@ def late_timeouts(net):
     return out.value
 
 
+def late_timeouts_peek(net):
+    """The same count WITHOUT synchronising (mn_iqn_late_timeouts_peek: what the launches executed so far have reported through a host-mapped word)."""
+    out = C.c_uint32()
+    rc = _capi.lib().mn_iqn_late_timeouts_peek(act_context(net).h, C.byref(out))
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_iqn_late_timeouts_peek failed ({rc})")
+    return out.value
+
+
+def set_late_bound_ms(net, ms):
+    """Bound of a late row's wait for its reset (mn_iqn_set_late_bound_ms; default 500 ms)."""
+    rc = _capi.lib().mn_iqn_set_late_bound_ms(act_context(net).h, C.c_double(ms))
+    if rc:
+        raise _capi.MarineNavHipError(f"mn_iqn_set_late_bound_ms failed ({rc})")
+
+
 @torch.no_grad()
 def fused_act(net, states, eps=0.0, cvar=1.0, taus=None, generator=None, want_qvals=False, rng=None, want_quantiles=False,
               shared_taus=False, late_env=None):

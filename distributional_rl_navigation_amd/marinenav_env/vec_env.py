@@ -92,6 +92,7 @@ class VecMarineNavEnv:
         self.info = torch.zeros(self.n_envs, dtype=torch.uint8, device=dev)
         self._terminal_obs = None
         self.late_rows = None      # reset_done(under_next_act=True)
+        self.reset_under_act_max = self.RESET_UNDER_ACT_MAX_DEFAULT
         self.reset_launches = [0, 0]      # ... how many of those calls the library ran [in front of, under] the next act kernel
 
     # ---- lifecycle ---------------------------------------------------------------------------
@@ -284,12 +285,19 @@ class VecMarineNavEnv:
             self._check(self.L.mn_reset_done(self.h, _ptr(self.obs), self._stream()))
         return self.obs
 
-    def set_reset_under_act_max(self, max_resets):
+    RESET_UNDER_ACT_MAX_DEFAULT = 6000      # = MN_RESET_UNDER_ACT_MAX_DEFAULT (include/marinenav_hip.h)
+
+    def set_reset_under_act_max(self, max_resets=None):
         """`reset_done(under_next_act=True)` goes under the act kernel only while the decaying peak of the episodes started per reset launch is at most this
-        (default 1200; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
+        (None: the library's default, 6000; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
         last = C.c_int64()
-        self._check(self.L.mn_set_reset_under_act_max(self.h, int(max_resets), C.byref(last)))
+        self.reset_under_act_max = self.RESET_UNDER_ACT_MAX_DEFAULT if max_resets is None else int(max_resets)
+        self._check(self.L.mn_set_reset_under_act_max(self.h, self.reset_under_act_max, C.byref(last)))
         return last.value
+
+    def debug_side_delay_us(self, us):
+        """Test hook (mn_debug_side_delay_us): every reset launch under the act kernel is held back by `us` microseconds on the handle's own stream."""
+        self._check(self.L.mn_debug_side_delay_us(self.h, int(us)))
 
     def take_late_rows(self):
         """The pending `reset_done(under_next_act=True)`'s late rows for ONE act launch (None if there is none)."""

@@ -174,11 +174,19 @@ def _worker_device(requested, i, n_gpu):
     return requested
 
 
-def _trial_worker(device, params, n_envs, kw):
+def _trial_worker(device, params, n_envs, kw, sharers=1):
+    """One trial in a pool worker.  `sharers`: how many workers run on this worker's GPU at a time.  The one-launch gradient step needs every one of its
+    workgroups resident at once and plans for the whole device; two such launches of two processes on one GPU would starve each other (bounded waits run
+    out, the step is skipped): with company, the worker plans for its share of the CUs (mn_iqn_train_set_cu_limit -> the two- / three-launch forms, same
+    results); whether the episode resets still find room beside the act kernel is checked by the loop's own first steps (iqn/agent.py: UnderActGuard)."""
     import torch
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is not None:      # (an un-indexed or non-CUDA device has no current-device to set)
         torch.cuda.set_device(dev)
+    if sharers > 1 and dev.type == "cuda":
+        from . import _capi
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        _capi.lib().mn_iqn_train_set_cu_limit(max(8, cus // sharers - 8))
     return run_trial(device, params, n_envs, verbose=False, **kw)
 
 
@@ -232,7 +240,10 @@ def main(argv=None):
         import multiprocessing as mp
         n_gpu = max(1, torch.cuda.device_count())
         with mp.get_context("spawn").Pool(processes=args.num_procs) as pool:
-            jobs = [pool.apply_async(_trial_worker, (_worker_device(args.device, i, n_gpu), p, args.n_envs, kw)) for i, p in enumerate(trials)]
+            devs = [_worker_device(args.device, i, n_gpu) for i in range(len(trials))]
+            # workers that can be on one GPU at a time: the pool runs `num_procs` trials at once, worker i on devs[i]
+            sharers = max(1, max(sum(1 for d in devs[:args.num_procs] if d == x) for x in set(devs[:args.num_procs]))) if trials else 1
+            jobs = [pool.apply_async(_trial_worker, (devs[i], p, args.n_envs, kw, sharers)) for i, p in enumerate(trials)]
             pool.close()
             for j in jobs:
                 j.get()

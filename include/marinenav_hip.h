@@ -201,15 +201,20 @@ int mn_reset_done(mn_handle *h, float *obs_dev, void *stream);
  * reset launch to end) by mn_reset_join or by the next mn_step / mn_step_append / mn_reset_done[_async] on it; every other entry point of
  * the handle waits for it on the host.  Between this call and the join the caller must not read obs_dev rows of finished envs except
  * through such an act launch.
- * Beside the act kernel's workgroups a CU has room for one reset wavefront, which runs several times slower there: that hides a few hundred
- * resets per vector step (alone, such a launch is a latency chain that leaves the chip idle), not thousands.  The call therefore launches under the
- * act kernel only while the decaying peak of the episodes started per reset launch -- peak <- max(count, 7/8 peak), kept by the launches
- * themselves and read by the host from a mapped word without synchronising -- is at most `under_act_max` (mn_set_reset_under_act_max:
- * default 1200; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on `stream` and *ready_out is NULL (no late rows).
- * mn_set_reset_under_act_max also reports that peak as of the last launch seen (-1: none yet). */
+ * Beside the act kernel's workgroups a CU has room for FOUR reset wavefronts (one per SIMD: 96 registers each; the kernel that runs there reads the env's
+ * MT19937 row in place instead of copying it into LDS), which run several times slower there: that hides the resets of a few thousand episodes per vector
+ * step (alone, such a launch is a latency chain that leaves most of the chip idle; measured cross-over ~8 000 steadily arriving per 65 536-env step),
+ * not a burst of tens of thousands.  The call therefore launches under the act kernel only while the decaying peak of the episodes started per reset
+ * launch -- peak <- max(count, 7/8 peak), kept by the launches themselves and read by the host from a mapped word without synchronising -- is at most
+ * `under_act_max` (mn_set_reset_under_act_max: default MN_RESET_UNDER_ACT_MAX_DEFAULT; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on
+ * `stream` and *ready_out is NULL (no late rows).  mn_set_reset_under_act_max also reports that peak as of the last launch seen (-1: none yet).
+ * mn_debug_side_delay_us (test hook): a kernel that sleeps `us` microseconds in front of every such launch on the handle's stream, i.e. a reset
+ * launch that does not run beside the act kernel -- what the callers' fallback (late-row timeouts -> resets in front) is tested with. */
+#define MN_RESET_UNDER_ACT_MAX_DEFAULT 6000
 int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, const uint32_t **ready_out, uint32_t *tick_out);
 int mn_reset_join(mn_handle *h, void *stream);
 int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, int64_t *last_seen);
+int mn_debug_side_delay_us(mn_handle *h, int32_t us);
 
 /* MarineNavEnv.reset_with_eval_config (marinenav_env.py:467-555), world + pose fields, for `count`
  * consecutive envs starting at first_env.  Host arrays, row-major:
@@ -311,10 +316,15 @@ int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
  * scope before the word).  The launch takes those rows last and reads them past the caches; results equal those of a launch behind the
  * reset.  Returns MN_OK if the next launch of n rows will honour it (launch it next on this context), 1 if the context's current form
  * cannot (exact / 32x32 variants, launch-shared taus, quantile capture, more than 64 rows per wavefront): the caller joins the reset
- * (mn_reset_join) instead.  NULL, NULL clears.  mn_iqn_late_timeouts: waits that ran out (0.5 s bound) since the context was made --
- * anything but 0 means an action was computed on an unfinished row (synchronises `stream`). */
+ * (mn_reset_join) instead.  NULL, NULL clears.  mn_iqn_late_timeouts: waits that ran out (0.5 s bound; mn_iqn_set_late_bound_ms, in (0, 60 000] ms,
+ * for launches armed afterwards) since the context was made -- anything but 0 means an action was computed on an unfinished row, i.e. the reset
+ * launch did not run beside the act kernel on this box: the caller goes back to mn_reset_done (synchronises `stream`).  mn_iqn_late_timeouts_peek:
+ * the same count as far as the launches executed so far have reported it through a host-mapped word -- no synchronisation, for a look every few
+ * vector steps. */
 int mn_iqn_set_late_rows(mn_iqn_ctx *c, const uint8_t *mask_dev, const uint32_t *flags_dev, uint32_t tick, int32_t n);
 int mn_iqn_late_timeouts(mn_iqn_ctx *c, void *stream, uint32_t *out);
+int mn_iqn_late_timeouts_peek(mn_iqn_ctx *c, uint32_t *out);
+int mn_iqn_set_late_bound_ms(mn_iqn_ctx *c, double ms);
 /* Measurement aid (bench.py: `gpu_clock_probe`): runs a pure stream of the act kernel's matrix instruction (v_mfma_f32_16x16x32_f16, two
  * waves per SIMD on every CU) for about target_ms milliseconds on `stream` and returns out[0] = elapsed ms (HIP events), out[1] = the clock
  * in GHz the matrix pipe sustained (16 cycles per instruction), out[2] = the clock by the waves' own counters (s_memtime ticks per

@@ -22,6 +22,9 @@ ap.add_argument("--target-mult", type=float, default=1.0)
 ap.add_argument("--eps-floor", type=float, default=0.05)
 ap.add_argument("--shared-taus", action="store_true")
 ap.add_argument("--multi-step", action="store_true")
+ap.add_argument("--replay", type=int, default=100_000, help="replay ring rows (the bench keeps BASELINE's 100 000)")
+ap.add_argument("--grad-steps", type=int, default=None, help="gradient steps per vector step (default: 16 per 65 536 envs)")
+ap.add_argument("--tag", default="", help="label printed in the header line")
 args = ap.parse_args()
 
 import torch
@@ -29,7 +32,7 @@ from distributional_rl_navigation_amd.train_iqn import run_trial
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_iqn_seed3_greedy_curve.npz"))
 seeds = [int(x) for x in args.seed_list.split(",")] if args.seed_list else list(range(args.first_seed, args.first_seed + args.seeds))
-print(f"# {len(seeds)} seeds {seeds}; {args.envs} envs, {args.evals} evaluation points, target copy x{args.target_mult}, eps floor {args.eps_floor}, "
+print(f"# {args.tag + ': ' if args.tag else ''}{len(seeds)} seeds {seeds}; {args.envs} envs, replay ring {args.replay} rows, {args.evals} evaluation points, target copy x{args.target_mult}, eps floor {args.eps_floor}, "
       f"acting taus {'shared per launch' if args.shared_taus else 'per env'}", flush=True)
 curves, finals, bests, walls = [], [], [], []
 if args.multi_step:
@@ -45,7 +48,7 @@ for sd in seeds:
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             d = run_trial("cuda:0", params, args.envs, verbose=False, n_evals=args.evals, target_sync_mult=args.target_mult, final_eps=args.eps_floor,
-                          eval_adaptive=False, shared_taus=args.shared_taus)
+                          eval_adaptive=False, shared_taus=args.shared_taus, replay=args.replay, grad_steps=args.grad_steps)
         torch.cuda.synchronize()
         walls.append(time.time() - t0)
         ev = np.load(os.path.join(d, "greedy_evaluations.npz"), allow_pickle=True)
@@ -68,4 +71,12 @@ for i in range(n_pts):
 f = np.array(finals, dtype=np.float64); b = np.array([x[:2] for x in bests], dtype=np.float64)
 print(f"\n# last evaluation over {len(seeds)} runs: successes {f[:, 0].mean():.2f} +- {f[:, 0].std(ddof=1):.2f} /30, mean return {f[:, 1].mean():.2f} +- {f[:, 1].std(ddof=1):.2f}; worst {f[:, 0].min():.0f}/30, {f[:, 1].min():.2f}")
 print(f"# best_* checkpoint over {len(seeds)} runs: successes {b[:, 0].mean():.2f} +- {b[:, 0].std(ddof=1):.2f} /30, mean return {b[:, 1].mean():.2f} +- {b[:, 1].std(ddof=1):.2f}; worst {b[:, 0].min():.0f}/30, {b[:, 1].min():.2f}")
+first = [next((i for i, v in enumerate(c[1]) if v >= 26), None) for c in curves]
+reached = [f_ for f_ in first if f_ is not None]
+if reached:
+    frac = [(f_ + 1) / len(c[1]) for f_, c in zip(first, curves) if f_ is not None]
+    print(f"# first evaluation with >= 26/30 (the reference's final): reached by {len(reached)}/{len(curves)} runs, median at {np.median(frac):.2f} of the run = {np.median(frac) * np.mean(walls):.1f} s of wall clock")
+last3 = np.array([[np.mean(c[1][-3:]), np.mean(c[2][-3:])] for c in curves])
+print(f"# mean of each run's last 3 evaluations: successes median {np.median(last3[:, 0]):.1f} [q25 {np.percentile(last3[:, 0], 25):.1f}, q75 {np.percentile(last3[:, 0], 75):.1f}], return median {np.median(last3[:, 1]):.1f} [q25 {np.percentile(last3[:, 1], 25):.1f}, q75 {np.percentile(last3[:, 1], 75):.1f}]; "
+      f"last evaluation: successes median {np.median(f[:, 0]):.1f}, return median {np.median(f[:, 1]):.1f}")
 print(f"# reference (one seed): final 26/30, 69.25; best of its 300 evaluations 29/30, 83.23.  wall clock per run here: {np.mean(walls):.1f} s incl. {args.evals} evaluations")

@@ -26,12 +26,19 @@ for L in [int(x) for x in os.environ.get("LS", "1000,400,260,200,160,130,100,64"
         for _ in range(40):
             obs = agent.vec_step(env, obs, 0.9)[0]
         torch.cuda.synchronize()
+        prof = os.environ.get("PROFILE") == "1"      # HIP events around the first 50 act / step / reset launches (costs ~18 us of stream time per instrumented step)
+        if prof:
+            from distributional_rl_navigation_amd.iqn.fused_act import act_context
+            env.profile_begin(50); act_context(agent.qnetwork_local).profile_begin(50)
         t0 = time.perf_counter()
         for _ in range(steps):
             obs = agent.vec_step(env, obs, 0.9)[0]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         env.join_reset()
+        if prof:
+            r_ms, _ = env.profile_reset_end(); s_ms, _ = env.profile_end(); a_ms, _ = act_context(agent.qnetwork_local).profile_end()
+            print(f"    L {L} {'under' if under else 'front'}: act launch {1e3 * a_ms:.1f} us, step kernel {1e3 * s_ms:.1f} us, reset launch {1e3 * r_ms:.1f} us", flush=True)
         cnt = []
         for _ in range(8):
             a = agent.act_batch(obs, 0.9)

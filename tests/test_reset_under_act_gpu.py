@@ -144,6 +144,85 @@ def test_forms_without_late_rows_keep_the_reset_in_front(torch):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def _learn_vec_run(torch, under, steps, max_episode_steps=None, on_step=None, before=None):
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    env = VecMarineNavEnv(4096, seed=2, device=DEV, precision="f64")
+    if max_episode_steps is not None:
+        env.params.max_episode_steps = max_episode_steps
+    env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+    agent = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=3 * 4096, device=DEV, seed=5, learning_starts=0, UPDATE_EVERY=2)
+    if before is not None:
+        before(env, agent)
+    agent.learn_vec(total_vector_steps=steps, train_env=env, verbose=False, reset_under_act=under,
+                    on_step=(lambda it, st: on_step(it, env, agent)) if on_step else None)
+    out = dict(params=torch.cat([p.detach().reshape(-1).clone() for p in agent.qnetwork_local.parameters()]), obs=env.obs.clone(), state=env.get_state(),
+               launches=list(env.reset_launches), fallback=agent.under_act_fallback, max_after=env.reset_under_act_max, flag_after=agent.reset_under_act)
+    env.close()
+    return out
+
+
+def test_learn_vec_preflight_healthy_box(torch):
+    """learn_vec's first 12 vector steps force every reset under the act kernel and read the late-row time-outs (UnderActGuard): on a box where the reset
+    launch runs beside the act kernel nothing happens -- no fallback, the library's rule restored, same parameters / observations / env state as the loop
+    with the resets in front."""
+    a = _learn_vec_run(torch, False, 40, max_episode_steps=5)
+    b = _learn_vec_run(torch, True, 40, max_episode_steps=5)
+    assert b["fallback"] is None and a["fallback"] is None
+    assert b["launches"][1] == 40 and a["launches"] == [0, 0]
+    assert b["max_after"] == 6000 and b["flag_after"] is False      # (the agent's own default is restored behind the loop)
+    assert torch.equal(a["params"], b["params"]) and torch.equal(a["obs"], b["obs"])
+    for x, y in zip(a["state"], b["state"]):
+        assert np.array_equal(x, y)
+
+
+def test_learn_vec_falls_back_when_the_reset_does_not_run_beside_the_act_kernel(torch):
+    """The no-co-residency case, simulated: a kernel that sleeps 20 ms in front of every reset launch on the env's own stream (mn_debug_side_delay_us), late rows
+    that wait 1 ms at most (mn_iqn_set_late_bound_ms).  Every env finishes at every step (max_episode_steps = 0), so the second act launch of the loop finds all
+    its rows unfinished: the preflight sees the time-outs after vector step 1, says so once, and the loop carries on with the resets in front of the act kernel --
+    no exception at the end, nothing under the act kernel after the fallback."""
+    from distributional_rl_navigation_amd.iqn.fused_act import set_late_bound_ms, late_timeouts
+
+    def hold(env, agent):
+        set_late_bound_ms(agent.qnetwork_local, 1.0)
+        env.debug_side_delay_us(20000)
+    r = _learn_vec_run(torch, True, 30, max_episode_steps=0, before=hold)
+    assert r["fallback"] is not None and r["fallback"]["step"] == 1 and r["fallback"]["timeouts"] > 0
+    assert r["launches"] == [0, 2]                      # vector steps 0 and 1 went under the act kernel, none after
+    assert r["max_after"] == 6000
+    assert torch.isfinite(r["params"]).all()
+
+    # ... and when it starts to happen in the middle of a run (after the preflight): found by the unsynchronised look every 64 vector steps
+    def later(it, env, agent):
+        if it == 20:
+            set_late_bound_ms(agent.qnetwork_local, 1.0)
+            env.debug_side_delay_us(20000)
+    r = _learn_vec_run(torch, True, 90, max_episode_steps=0, on_step=later)
+    assert r["fallback"] is not None and r["fallback"]["step"] == 75 and r["fallback"]["timeouts"] > 0
+    assert r["launches"] == [0, 76]
+
+
+def test_check_learner_raises_for_callers_without_the_guard(torch):
+    """A caller that drives vec_step itself with reset_under_act and never looks gets the old behaviour: check_learner() raises."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    from distributional_rl_navigation_amd.iqn.fused_act import set_late_bound_ms
+    from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
+    env = VecMarineNavEnv(4096, seed=2, device=DEV, precision="f64")
+    env.params.max_episode_steps = 0
+    env.set_attrs(num_cores=8, num_obs=10, min_start_goal_dis=40.0)
+    agent = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=3 * 4096, device=DEV, seed=5, learning_starts=0, UPDATE_EVERY=10 ** 9)
+    agent.reset_under_act = True
+    set_late_bound_ms(agent.qnetwork_local, 1.0)
+    env.debug_side_delay_us(20000)
+    obs = env.reset()
+    for _ in range(3):
+        obs = agent.vec_step(env, obs, 0.5)[0]
+    env.join_reset()
+    with pytest.raises(RuntimeError, match="before their episode reset had finished"):
+        agent.check_learner()
+    env.close()
+
+
 def test_c_abi_contract(torch):
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
@@ -177,6 +256,12 @@ def test_c_abi_contract(torch):
     ctx.set_variant(2)
     out = C.c_uint32(7)
     assert L.mn_iqn_late_timeouts(ctx.h, s, C.byref(out)) == 0 and out.value == 0
+    out = C.c_uint32(7)
+    assert L.mn_iqn_late_timeouts_peek(ctx.h, C.byref(out)) == 0 and out.value == 0
+    assert L.mn_iqn_late_timeouts_peek(None, C.byref(out)) != 0 and L.mn_iqn_late_timeouts_peek(ctx.h, None) != 0
+    assert L.mn_iqn_set_late_bound_ms(ctx.h, C.c_double(0.0)) != 0 and L.mn_iqn_set_late_bound_ms(ctx.h, C.c_double(1e9)) != 0
+    assert L.mn_iqn_set_late_bound_ms(None, C.c_double(1.0)) != 0 and L.mn_iqn_set_late_bound_ms(ctx.h, C.c_double(500.0)) == 0
+    assert L.mn_debug_side_delay_us(None, 1) != 0 and L.mn_debug_side_delay_us(env.h, -1) != 0 and L.mn_debug_side_delay_us(env.h, 0) == 0
     env.close()
 
 
