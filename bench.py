@@ -38,10 +38,8 @@ means is written HERE, not in the line.
                         act_exact_f32 = the loop with the exact-f32 MFMA act kernel; shared_learner_ws1 = learner alone, grad-steps/s: one launch per
                         step, the RCCL all-reduce at world size 1 eager / inside captured 16-step graphs, the mailbox exchange inside the one-launch
                         step; act_shared_taus (opt-in: 32 taus per launch instead of per env; tiled = environments in the MFMA columns, wave = wavefront
-                        per env); train_cadence = what train_iqn runs: 16 gradient steps per vector step, eps 0.05 (_multi_step: the 16 steps of an event as one
-                        persistent launch, opt-in)
-  learner_only          back-to-back gradient steps, grad-steps/s: fused_hip (one launch per step), fused_hip_g16 (persistent 16-step launches: what a training
-                        event of train_iqn is), eager PyTorch, hipGraph of PyTorch
+                        per env); train_cadence = what train_iqn runs: 16 gradient steps per vector step, eps 0.05
+  learner_only          back-to-back gradient steps, grad-steps/s: fused_hip (one launch per step), eager PyTorch, hipGraph of PyTorch
 """
 import argparse
 import json
@@ -341,10 +339,6 @@ def also_legs(args, env, agent, obs, device, total_timesteps, dist_up):
     train_step = lambda o: agent.vec_step(env, o, 0.05, args.cvar, train_every=1, per_iter=n)[0]
     dt, act_ms = shared_leg(train_step, steps, 10)
     out["train_cadence_shared_taus"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt, "act_launch_ms": act_ms}
-    agent.use_multi_step = True      # the 16 steps of an event as ONE persistent launch (opt-in)
-    dt, obs = _timed(device, train_step, steps, 10, obs)
-    agent.use_multi_step = False
-    out["train_cadence_multi_step"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt}
     dt, obs = _timed(device, train_step, steps, 10, obs)
     out["train_cadence"] = {"value": n * steps / dt, "ms_per_step": 1e3 * dt / steps, "grad_steps_per_sec": 16 * steps / dt,
                             "grad_steps_per_vector_step": 16, "launches_per_grad_step": agent._fused.launches_per_step()}
@@ -394,7 +388,7 @@ def main():
                     help="env kernels: f64 (everything float64, 1e-9; default when an IQN is in the loop) or mixed (float32 field / sonar "
                          "decisions; default with --no-learner)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra driver-timed legs (`also`) after the main timed region")
-    ap.add_argument("--act-variant", type=int, default=2, choices=(0, 1, 2, 3), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32, 1 = its v_mfma_f32_32x32x2_f32 re-layout, 3 = split-f16 on 32x32x16 tiles")
+    ap.add_argument("--act-variant", type=int, default=2, choices=(0, 2), help="acting kernel: 2 = split-f16 MFMA at float32 accuracy (default), 0 = exact-f32 v_mfma_f32_16x16x4_f32")
     ap.add_argument("--separate-append", action="store_true", help="mn_step + mn_replay_append as two launches instead of the fused mn_step_append")
     ap.add_argument("--reset-in-front", action="store_true", help="episode resets in front of the act kernel (mn_reset_done) instead of under it "
                                                                   "(mn_reset_done_async + late rows; IQNAgent.reset_under_act, the default)")
@@ -627,18 +621,6 @@ def main():
                 agent.train_from_memory()
             torch.cuda.synchronize(device)
             learner_only[mode] = reps / (time.perf_counter() - t1)
-            if mode == "fused_hip" and not (agent.distributed and agent.exchange == "collective"):
-                # the same steps as persistent 16-step launches (mn_iqn_train_steps: what a training event of train_iqn is)
-                agent.use_multi_step = True
-                for _ in range(3):
-                    agent.train_steps_from_memory(16)
-                torch.cuda.synchronize(device)
-                t1 = time.perf_counter()
-                for _ in range(40):
-                    agent.train_steps_from_memory(16)
-                torch.cuda.synchronize(device)
-                learner_only["fused_hip_g16"] = 40 * 16 / (time.perf_counter() - t1)
-                agent.use_multi_step = False
         agent.use_fused_train = was_fused
 
     result_line = None
@@ -702,18 +684,18 @@ def main():
         }
         if fused and act_ms > 0:
             alg_tf = ACT_FLOP_PER_ENV_STEP * n / (act_ms * 1e-3) / 1e12
-            if args.act_variant in (2, 3):
-                issued = (ACT_SHARED_MFMA_FLOP if args.shared_taus else ACT_SPLIT_MFMA_FLOP) if args.act_variant == 2 else 198 * 32768
+            if args.act_variant == 2:
+                issued = ACT_SHARED_MFMA_FLOP if args.shared_taus else ACT_SPLIT_MFMA_FLOP
                 tf, peak = issued * n / (act_ms * 1e-3) / 1e12, F16_MFMA_PEAK_TFLOPS
-                kern = ("iqn_qvals_tiled_kernel" if (args.shared_taus and n >= 65536) else "iqn_qvals_split_kernel") if args.act_variant == 2 else "iqn_qvals_split32_kernel"
+                kern = "iqn_qvals_tiled_kernel" if (args.shared_taus and n >= 65536) else "iqn_qvals_split_kernel"
             else:
                 tf, peak = alg_tf, F32_MFMA_PEAK_TFLOPS
-                kern = "iqn_qvals32_kernel" if args.act_variant == 1 else "iqn_qvals_kernel"
+                kern = "iqn_qvals_kernel"
             clocks = [c for c in (clock_before, clock_after) if c]
             ghz = sum(clocks) / len(clocks) if clocks else None
             out["roofline"] = {
                 "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "frac_algorithmic": alg_tf / peak,
-                "traffic": None, "traffic_mb_profiled": PMC_TRAFFIC_MB["act_split" if args.act_variant in (2, 3) else "act_exact"] if n == 65536 else None,
+                "traffic": None, "traffic_mb_profiled": PMC_TRAFFIC_MB["act_split" if args.act_variant == 2 else "act_exact"] if n == 65536 else None,
                 "launch_ms": act_ms, "launches_timed": act_launches, "env_steps_per_launch": n,
                 "clock_ghz": ghz, "kilocycles": act_ms * 1e-3 * ghz * 1e6 if ghz else None,
             }

@@ -97,10 +97,6 @@ SIGNATURES = [
     ("mn_iqn_train_workspace_init", C.c_int, [_vp, _i32, _vp]),
     ("mn_iqn_train_step", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32,
                                     _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),
-    ("mn_iqn_train_steps", C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32, _i32,
-                                     _dbl, _dbl, _dbl, _dbl, _dbl, _vp]),
-    ("mn_iqn_train_steps_xchg", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _i32, _i32,
-                                          _dbl, _dbl, _dbl, _dbl, _dbl, C.c_float, _vp]),
     ("mn_rollout_policy", C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mn_planner_act", C.c_int, [_vp, _i32, _i32, _pd, _pd, _vp, _vp]),
     ("mn_dqn_image_floats", C.c_int64, []),

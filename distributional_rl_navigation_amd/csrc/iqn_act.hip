@@ -414,323 +414,7 @@ __global__ __launch_bounds__(512, 2) void iqn_qvals_kernel(const float *__restri
 }
 
 
-// =====================================================================================================================
-// The same network, the same register-chained transposed layers, on the v_mfma_f32_32x32x2_f32 shape -- an EXPERIMENT kept
-// selectable (mn_iqn_set_variant(ctx, 1)), not the default.  A pure stream of 32x32x2 sustains 4-6 % more than 16x16x4 on
-// this chip (profiles/r01_mfma_rate.txt) and all 32 taus of an environment are ONE column tile, so round 1 listed this
-// re-layout as the remaining lever.  Measured in round 2 (profiles/r02_act_kernel_variants.txt): 1024 us per 65 536 envs
-// against 998 us for the 16x16x4 kernel -- identical MFMA busy cycles (2.013 G), 2.5 % more elapsed cycles, the same
-// clock: inside this kernel the matrix pipe is shared by two waves that also run VALU epilogues, and the 64-cycle
-// instructions interleave with them less finely than 32-cycle ones; the micro-benchmark's advantage does not carry over.
-//
-// C / D layout of 32x32x2: lane l = (g = l >> 5, c = l & 31) holds column c (= tau c) and rows 8 j + 4 g + r in register
-// 4 j + r (j, r = 0..3).  A operand: A[row = l & 31][k = l >> 5]; B operand: B[k = l >> 5][col = l & 31].  As before the
-// k order of a dot product is free, so MFMA step (t, j, r) of the NEXT layer is defined to consume the input-feature pair
-// {32 t + 8 j + r, 32 t + 8 j + 4 + r} -- register 4 j + r of C tile t in the two lane halves: a layer's accumulators ARE
-// the next layer's B operands.
-//
-// 208 = 6 x 32 + 16.  Features 0..191 run as six 32-row tiles.  The last 16 features of layer 1 run as ONE 16x16x4 tile
-// pair (no padding: a padded 32-row tile would cost 3.3 % extra matrix work and eat the gain): its B operands are the same
-// cosines -- a lane's own for the 16-column tile that contains its tau, its partner's (lane ^ 16, one ds_bpermute each)
-// for the other -- and its 16x16 results (lane (g4, c16): rows 4 g4 + r, tau 16 nt + c16) are turned into 32x32 B operands
-// by a 2 x 2 bit transpose between lane bits (5, 4) and the (register, tile) index: one v_permlane16_swap + one
-// v_permlane32_swap per register pair, 8 instructions per environment, no LDS.  Layer 2 then consumes them as 8 more
-// K = 2 steps per 32-row tile.  MFMA work per env: 448 x 32x32x2 + 32 x 16x16x4 = 960 x 2048 FLOP exactly as before.
-namespace v32 {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int NT32 = 6;                              // full 32-row feature tiles
-constexpr int OFF_W1 = 0;                            // [6 t][8 s4][64 l][4]   W1[32t + (l&31)][2(4 s4 + i) + (l>>5)]
-constexpr int OFF_W1L = OFF_W1 + NT32 * 32 * 64;     // [4 m4][64 l][4]        W1[192 + (l&15)][4(4 m4 + i) + 2((l>>4)&1) + (l>>5)]
-constexpr int OFF_W2 = OFF_W1L + 16 * 64;            // [2 mt][6 t][4 j][64 l][4 r]  W2[32mt + (l&31)][32t + 8j + 4(l>>5) + r]
-constexpr int OFF_W2L = OFF_W2 + 2 * NT32 * 16 * 64; // [2 mt][2 a][64 l][4 r]       W2[32mt + (l&31)][192 + 8a + 4(l>>5) + r]
-constexpr int OFF_W3 = OFF_W2L + 2 * 8 * 64;         // [2 mt][2 t2][4 j][64 l][4 r] W3[32mt + (l&31)][32t2 + 8j + 4(l>>5) + r]
-constexpr int OFF_W4 = OFF_W3 + 2 * 2 * 16 * 64;     // [9][64] output layer, nn.Linear layout
-constexpr int OFF_B1 = OFF_W4 + A_OUT * H;           // [208]
-constexpr int OFF_B2 = OFF_B1 + F;                   // [64]
-constexpr int OFF_B3 = OFF_B2 + H;                   // [64]
-constexpr int OFF_B4 = OFF_B3 + H;                   // [16]
-constexpr int OFF_WE = OFF_B4 + 16;                  // [7 i4][208 f][4]: block-diagonal encoder weights
-constexpr int OFF_BE = OFF_WE + OBS4 * F * 4;        // [208] encoder biases
-constexpr int OFF_FB = OFF_BE + F;                   // [8 waves][208] per-wave feature buffer
-constexpr int LDS_FLOATS = OFF_FB + 8 * F;
-static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS image of the 32x32x2 act kernel must fit the CU's 160 KB");
-static_assert(OFF_W1L % 4 == 0 && OFF_W2 % 4 == 0 && OFF_W2L % 4 == 0 && OFF_W3 % 4 == 0 && OFF_W4 % 4 == 0 && OFF_B1 % 4 == 0 &&
-              OFF_B2 % 4 == 0 && OFF_B3 % 4 == 0 && OFF_B4 % 4 == 0 && OFF_WE % 4 == 0 && OFF_BE % 4 == 0 && OFF_FB % 4 == 0, "16-byte aligned blocks");
-constexpr int PACK_BLOCKS = (OFF_FB + 255) / 256;
-
-__device__ __forceinline__ float pack_element32(const IqnWeights &w, int i) {
-    if (i < OFF_W4) {
-        const int r = i & 3, l = (i >> 2) & 63, g = l >> 5, row = l & 31;
-        if (i < OFF_W1L) {           // [t][s4][l][i]
-            const int q = i >> 8, s4 = q & 7, t = q >> 3;
-            return w.W1[(32 * t + row) * N_COS + 2 * (4 * s4 + r) + g];
-        } else if (i < OFF_W2) {     // leftover layer 1: [m4][l][i], 16x16x4 A operand
-            const int m4 = (i - OFF_W1L) >> 8, g4 = l >> 4;
-            return w.W1[(192 + (l & 15)) * N_COS + 4 * (4 * m4 + r) + 2 * (g4 & 1) + (g4 >> 1)];
-        } else if (i < OFF_W2L) {    // [mt][t][j][l][r]
-            const int q = (i - OFF_W2) >> 8, j = q & 3, t = (q >> 2) % NT32, mt = (q >> 2) / NT32;
-            return w.W2[(32 * mt + row) * F + 32 * t + 8 * j + 4 * g + r];
-        } else if (i < OFF_W3) {     // [mt][a][l][r]
-            const int q = (i - OFF_W2L) >> 8, a = q & 1, mt = q >> 1;
-            return w.W2[(32 * mt + row) * F + 192 + 8 * a + 4 * g + r];
-        }                            // [mt][t2][j][l][r]
-        const int q = (i - OFF_W3) >> 8, j = q & 3, t2 = (q >> 2) & 1, mt = q >> 3;
-        return w.W3[(32 * mt + row) * H + 32 * t2 + 8 * j + 4 * g + r];
-    }
-    if (i < OFF_B1) return w.W4[i - OFF_W4];
-    if (i < OFF_B2) return w.b1[i - OFF_B1];
-    if (i < OFF_B3) return w.b2[i - OFF_B2];
-    if (i < OFF_B4) return w.b3[i - OFF_B3];
-    if (i < OFF_WE) return (i - OFF_B4) < A_OUT ? w.b4[i - OFF_B4] : 0.f;
-    if (i < OFF_BE) {
-        const int k = i - OFF_WE, cc = k & 3, f = (k >> 2) % F, i4 = (k >> 2) / F;
-        const int inp = 4 * i4 + cc;
-        return inp < OBS ? enc_weight(w, f, inp) : 0.f;
-    }
-    const int f = i - OFF_BE;
-    return f < 16 ? w.ve_b[f] : (f < 32 ? w.ge_b[f - 16] : w.se_b[f - 32]);
-}
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
-}
-
-__global__ __launch_bounds__(512, 2) void iqn_qvals32_kernel(const float *__restrict__ obs, const float *__restrict__ taus,
-                                                             const float *__restrict__ packed, float *__restrict__ qvals,
-                                                             const float *__restrict__ explore_u, float eps,
-                                                             int32_t *__restrict__ actions, int n,
-                                                             uint64_t *__restrict__ rng_state) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x;
-    if (rng_state && blockIdx.x == 0 && tid == 0) rng_state[1] += 1;   // the draws of this call were made by iqn_prep_kernel
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(packed);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
-        for (int i = tid; i < OFF_FB / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, g = lane >> 5, c = lane & 31, g4 = lane >> 4, hbit = g4 & 1;
-    const int wave = tid >> 6, waves_per_block = blockDim.x >> 6;
-    const f32x4 *ldsv = reinterpret_cast<const f32x4 *>(lds);
-    const float hk0 = 0.5f * (float)g;      // phase in revolutions of cos(pi tau k), k = 2 s + g: tau * (s + g / 2)
-
-    for (int e = blockIdx.x * waves_per_block + wave; e < n; e += gridDim.x * waves_per_block) {
-        const float tau = taus[(size_t)e * K_TAUS + c];
-        // layer-1 B operands: cos(tau * pis[k]) for k = 2 s + g  (model.py:155); same phases as the 16x16x4 kernel
-        float cb[32];
-#pragma unroll
-        for (int s = 0; s < 32; ++s) cb[s] = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(tau * (hk0 + (float)s)));
-
-        // ---- observation encoders (model.py:170-173), as in the 16x16x4 kernel
-        {
-            const float *orow = obs + (size_t)__builtin_amdgcn_readfirstlane(e) * OBS;
-            float ov[OBS4 * 4];
-#pragma unroll
-            for (int i = 0; i < OBS4 * 4; ++i) ov[i] = i < OBS ? orow[i] : 0.f;
-            float *fb = lds + OFF_FB + wave * F;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = lane + 64 * j;
-                if (f < F) {
-                    float a = lds[OFF_BE + f];
-#pragma unroll
-                    for (int i4 = 0; i4 < OBS4; ++i4) {
-                        const f32x4 wv = ldsv[(OFF_WE >> 2) + i4 * F + f];
-                        a += wv[0] * ov[4 * i4] + wv[1] * ov[4 * i4 + 1] + wv[2] * ov[4 * i4 + 2] + wv[3] * ov[4 * i4 + 3];
-                    }
-                    fb[f] = a;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        const f32x4 *fbv = reinterpret_cast<const f32x4 *>(lds + OFF_FB + wave * F);   // feature float4 index (32 t + 8 j + 4 g) / 4
-
-        f32x16 acc2[2] = {zero16(), zero16()};
-        // ---- layers 1 + 2 fused over the six 32-row feature tiles, software-pipelined (layer-1 MFMAs of tile t + 1 are
-        // issued before the bias / ReLU / Hadamard epilogue of tile t)
-        f32x4 left[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // layer-1 leftover tile (features 192..207), 16x16 layout
-        f32x16 acc1 = zero16();
-#pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-            const f32x4 a = ldsv[(OFF_W1 >> 2) + s4 * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc1 = mfma32(a[i], cb[4 * s4 + i], acc1);
-        }
-#pragma unroll
-        for (int t = 0; t < NT32; ++t) {
-            f32x16 nxt = zero16();
-            if (t + 1 < NT32) {
-#pragma unroll
-                for (int s4 = 0; s4 < 8; ++s4) {
-                    const f32x4 a = ldsv[(OFF_W1 >> 2) + ((t + 1) * 8 + s4) * 64 + lane];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) nxt = mfma32(a[i], cb[4 * s4 + i], nxt);
-                }
-            } else {
-                // leftover 16 features: 16x16x4, k(m, g4) = 4 m + 2 (g4 & 1) + (g4 >> 1) = 2 (2 m + h) + g: the lane's own
-                // cos for the tile that holds its tau (nt == h), its partner's (lane ^ 16) for the other tile
-#pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) {
-                    const f32x4 a = ldsv[(OFF_W1L >> 2) + m4 * 64 + lane];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = 4 * m4 + i;
-                        const float own = hbit ? cb[2 * m + 1] : cb[2 * m];            // cos(pi tau_own (4 m + 2 h + g))
-                        const float got = __shfl_xor(hbit ? cb[2 * m] : cb[2 * m + 1], 16);   // the partner's k has the OTHER h
-                        left[0] = mfma(a[i], hbit ? got : own, left[0]);               // tile 0: taus 0..15
-                        left[1] = mfma(a[i], hbit ? own : got, left[1]);               // tile 1: taus 16..31
-                    }
-                }
-            }
-            f32x16 h1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 fv = fbv[8 * t + 2 * j + g];                               // features[e][32 t + 8 j + 4 g + r]
-                const f32x4 bias = ldsv[(OFF_B1 >> 2) + 8 * t + 2 * j + g];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc1[4 * j + r] + bias[r];
-                    h1[4 * j + r] = (v > 0.f ? v : 0.f) * fv[r];
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 a = ldsv[(OFF_W2 >> 2) + ((mt * NT32 + t) * 4 + j) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc2[mt] = mfma32(a[r], h1[4 * j + r], acc2[mt]);
-                }
-            acc1 = nxt;
-        }
-        // ---- leftover features through layer 2: epilogue in the 16x16 layout (lane (g4, c16): features 192 + 4 g4 + r, tau
-        // 16 nt + c16), then the 2 x 2 bit transpose (lane bit 4 <-> tile index, lane bit 5 <-> register pair index) that
-        // leaves Y[a][r] = h1[192 + 8 a + 4 g + r][tau c] in lane (g, c): the B operands of 8 more K = 2 steps per tile
-        {
-            const f32x4 fv = fbv[48 + g4];
-            const f32x4 bias = ldsv[(OFF_B1 >> 2) + 48 + g4];
-            float y[2][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = left[0][r] + bias[r], v1 = left[1][r] + bias[r];
-                float x0 = (v0 > 0.f ? v0 : 0.f) * fv[r], x1 = (v1 > 0.f ? v1 : 0.f) * fv[r];
-                // v_permlane16_swap: lane bit 4 <-> tile index; v_permlane32_swap: lane bit 5 <-> pair index.  Written as
-                // inline assembly on purpose: with the two builtins chained, hipcc (ROCm 7.2) loses track of the second
-                // result of the second swap (it copies the FIRST result into the register it then uses as the second:
-                // seen in the ISA, and as wrong Q-values for features 200..207).  Both instructions write both operands;
-                // the s_nops are the VALU -> DPP-class and VALU -> MFMA-operand wait states hipcc cannot see inside asm.
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 7"
-                             : "+v"(x0), "+v"(x1));
-                y[0][r] = x0;
-                y[1][r] = x1;
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int a_ = 0; a_ < 2; ++a_) {
-                    const f32x4 a = ldsv[(OFF_W2L >> 2) + (mt * 2 + a_) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc2[mt] = mfma32(a[r], y[a_][r], acc2[mt]);
-                }
-        }
-
-        // ---- layer 2 epilogue, layer 3 ---------------------------------------------------------------
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 bias = ldsv[(OFF_B2 >> 2) + 8 * mt + 2 * j + g];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float v = acc2[mt][4 * j + r] + bias[r]; acc2[mt][4 * j + r] = v > 0.f ? v : 0.f; }
-            }
-        f32x16 acc3[2] = {zero16(), zero16()};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 a = ldsv[(OFF_W3 >> 2) + ((mt * 2 + t2) * 4 + j) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc3[mt] = mfma32(a[r], acc2[t2][4 * j + r], acc3[mt]);
-                }
-        }
-        // ---- layer 3 epilogue + mean over the 32 taus before the linear output layer (model.py:185,190), as before:
-        // after half_sum32 every lane of half g holds sum_tau h3[32 mt + 8 j + 4 g + r]; lane (g, c < 9) forms the part of
-        // action c that comes from its 32 features and the two halves are added with one cross-half shuffle
-        // (row_sum16 leaves the sum over the 16 taus of this lane's ROW in every lane of the row; the output layer is linear,
-        // so each row forms its own partial dot product with W4[action = lane & 15] and the four rows -- two per half, two
-        // halves -- are added with two cross-row shuffles at the end)
-        float part = 0.f;
-        const int c16 = lane & 15;
-        const int arow = c16 < A_OUT ? c16 : A_OUT - 1;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 bias = ldsv[(OFF_B3 >> 2) + 8 * mt + 2 * j + g];
-                const f32x4 w4 = ldsv[(OFF_W4 >> 2) + arow * (H / 4) + 8 * mt + 2 * j + g];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc3[mt][4 * j + r] + bias[r];
-                    part = fmaf(w4[r], row_sum16(v > 0.f ? v : 0.f), part);
-                }
-            }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        const float qv = part * (1.0f / K_TAUS) + lds[OFF_B4 + c16];     // Q(s, action = lane), valid for lane < 9
-        if (qvals && lane < A_OUT) qvals[(size_t)e * A_OUT + lane] = qv;
-        // ---- IQNAgent.act epilogue (agent.py:199-203): argmax, epsilon-greedy ------------------------
-        if (actions) {
-            float best = -INFINITY;
-            int arg = 0;
-#pragma unroll
-            for (int a = 0; a < A_OUT; ++a) {
-                const float v = __shfl(qv, a);
-                if (v > best) { best = v; arg = a; }
-            }
-            if (lane == 0) {
-                int act = arg;
-                if (explore_u && eps > 0.f) {
-                    const float u = explore_u[e];            // greedy iff u > eps (agent.py:200)
-                    if (!(u > eps)) { act = (int)(u / eps * (float)A_OUT); act = act > A_OUT - 1 ? A_OUT - 1 : act; }
-                }
-                actions[e] = act;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void iqn_pack32_kernel(IqnWeights w, float *__restrict__ packed) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < OFF_FB) packed[i] = pack_element32(w, i);
-}
-
-// weight image of THIS layout (when stale) + the call's random numbers in one launch, like iqn_prep_kernel
-__global__ __launch_bounds__(256) void iqn_prep32_kernel(IqnWeights w, float *__restrict__ packed, const uint64_t *__restrict__ rng_state,
-                                                         float *__restrict__ draws, int n, const float *__restrict__ cvar_row,
-                                                         float cvar, int pack_blocks) {
-    if ((int)blockIdx.x < pack_blocks) {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i < OFF_FB) packed[i] = pack_element32(w, i);
-        return;
-    }
-    draw_block(rng_state, draws, n, cvar_row, cvar, pack_blocks);
-}
-
-}  // namespace v32
-
 #include "iqn_act_split.h"
-#include "iqn_act_split32.h"
 #include "iqn_act_tiled.h"
 
 // ---- what clock does THIS GPU sustain under f16 matrix load?  (mn_probe_mfma_clock; round 4)
@@ -817,16 +501,14 @@ extern "C" int mn_probe_mfma_clock(double target_ms, double *out, void *stream) 
 struct mn_iqn_ctx {
     int device = -1;
     int n_cu = 0;
-    float *packed = nullptr;       // weight image of the 16x16x4 kernel (act_eval's quantile variant, variant 1)
-    float *packed32 = nullptr;     // weight image of the 32x32x2 kernel (default acting path)
+    float *packed = nullptr;       // weight image of the exact-f32 16x16x4 kernel (variant 0)
     uint32_t *packed_sp = nullptr; // weight image of the split-f16 kernel (iqn_act_split.h)
-    uint32_t *packed_sp32 = nullptr;   // ... and of its 32x32x16 form (iqn_act_split32.h)
     float *consts_sp = nullptr;    // its scale / bound constants
     float *h1_sp = nullptr;        // the launch's layer-1 constant [32 taus x 208] of the shared-tau kernels (mn_iqn_set_tau_mode) + 32 block maxima
     uint32_t *timg = nullptr;      // tiled shared-tau kernel (iqn_act_tiled.h): T = W2 h1 as hi / lo f16 pairs, and its auxiliary float block
     float *taux = nullptr;
     int tau_mode = 0;              // 0 = every environment its own 32 taus (the reference's per-call draw), 1 = one set of 32 per launch
-    bool dirty = true, dirty32 = true, dirty_sp = true, dirty_sp32 = true;
+    bool dirty = true, dirty_sp = true;
     int variant = MN_IQN_VARIANT_DEFAULT;   // mn_iqn_set_variant
     int max_blocks = 0;                     // mn_iqn_set_grid: 0 = one persistent workgroup per CU
     sp::LateRows late = {};                 // mn_iqn_set_late_rows: consumed by the next launch
@@ -855,8 +537,6 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
                             LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(iqn_qvals_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(v32::iqn_qvals32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            v32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::LDS_FLOATS * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, false, sp::WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -868,26 +548,20 @@ extern "C" int mn_iqn_create(mn_iqn_ctx **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sp::OFF_FB * (int)sizeof(float)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(sp::iqn_qvals_split_kernel<true, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sp::OFF_FB * (int)sizeof(float)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sp32::iqn_qvals_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sp32::LDS_FLOATS * (int)sizeof(float)) != hipSuccess)
+                            sp::OFF_FB * (int)sizeof(float)) != hipSuccess)
         return MN_ERR_HIP;
     mn_iqn_ctx *c = new mn_iqn_ctx();
     c->device = dev;
     c->n_cu = prop.multiProcessorCount;
     if (hipMalloc(reinterpret_cast<void **>(&c->packed), OFF_FB * sizeof(float)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->packed32), v32::OFF_FB * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->packed_sp), sp::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->packed_sp32), sp32::OFF_FB * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->consts_sp), sp::N_CONST_BUF * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->h1_sp), (sp::H1_FLOATS + 32) * sizeof(float)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->timg), sp::T_WORDS * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->taux), sp::TA_FLOATS * sizeof(float)) != hipSuccess ||
         hipMemset(c->consts_sp, 0, sp::N_CONST_BUF * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(c->packed);
-        (void)hipFree(c->packed32);
         (void)hipFree(c->packed_sp);
-        (void)hipFree(c->packed_sp32);
         (void)hipFree(c->consts_sp);
         (void)hipFree(c->h1_sp);
         (void)hipFree(c->timg);
@@ -906,9 +580,7 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
     if (moved) (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->packed);
-    (void)hipFree(c->packed32);
     (void)hipFree(c->packed_sp);
-    (void)hipFree(c->packed_sp32);
     (void)hipFree(c->consts_sp);
     (void)hipFree(c->h1_sp);
     (void)hipFree(c->timg);
@@ -923,14 +595,12 @@ extern "C" int mn_iqn_destroy(mn_iqn_ctx *c) {
 extern "C" int mn_iqn_weights_changed(mn_iqn_ctx *c) {
     if (!c) return MN_ERR_INVALID;
     c->dirty = true;
-    c->dirty32 = true;
     c->dirty_sp = true;
-    c->dirty_sp32 = true;
     return MN_OK;
 }
 
 extern "C" int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant) {
-    if (!c || variant < 0 || variant > 3) return MN_ERR_INVALID;
+    if (!c || (variant != 0 && variant != 2)) return MN_ERR_INVALID;      // (1 and 3 were the 32x32 re-layouts of the two kernels: measured slower, removed in round 6)
     c->variant = variant;
     return MN_OK;
 }
@@ -1047,11 +717,8 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
     if (late.mask && !late_rows_supported(c, n, quantiles_dev != nullptr)) return MN_ERR_INVALID;
     const bool prof = c->prof_n < c->prof_max;
     if (prof) (void)hipEventRecord(c->ev[2 * c->prof_n], s);
-    // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 1 = exact-f32 32x32x2 kernel, 2 = split-f16 kernel
-    // (iqn_act_split.h), 3 = split-f16 on 32x32x16 tiles (iqn_act_split32.h)
-    // quantile capture (act_eval): the split-f16 kernel's QUANT form for variants 2 and 3, the exact 16x16x4 kernel's for 0 and 1
-    const bool use_sp = c->variant == 2 || (quantiles_dev && c->variant == 3), use_sp32 = !quantiles_dev && c->variant == 3;
-    const bool use32 = !quantiles_dev && c->variant == 1;
+    // variants (mn_iqn_set_variant): 0 = exact-f32 16x16x4 kernel, 2 = split-f16 kernel (iqn_act_split.h); each has a quantile-capture form (act_eval)
+    const bool use_sp = c->variant == 2;
     if (c->tau_mode != 0) {
         // Launch-shared taus: ONE set of 32 quantile fractions for every environment of the launch (iqn_act_split.h, stage_sh).  Only the
         // split-f16 kernel has this form; per-row CVaR (adaptive policies) needs per-environment taus.
@@ -1086,32 +753,24 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
-    if (use_sp || use_sp32) {
-        bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
-        uint32_t *image = use_sp32 ? c->packed_sp32 : c->packed_sp;
-        const int pack_blocks = dirty_s ? (use_sp32 ? sp32::PACK_BLOCKS : sp::PACK_BLOCKS) : 0;
+    if (use_sp) {
+        bool &dirty_s = c->dirty_sp;
+        uint32_t *image = c->packed_sp;
+        const int pack_blocks = dirty_s ? sp::PACK_BLOCKS : 0;
         if (pack_blocks) hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
         if (rng_state_dev) {
             long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
             int rng_blocks = (int)((groups + 255) / 256);
             if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
-            if (use_sp32)
-                hipLaunchKernelGGL(sp32::iqn_split32_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
-                                   image, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
-            else
-                hipLaunchKernelGGL(sp::iqn_split_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
-                                   image, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
+            hipLaunchKernelGGL(sp::iqn_split_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, (const float *)c->consts_sp,
+                               image, (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
             taus_dev = draws_dev;
             explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
         } else if (pack_blocks) {
-            if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
-            else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
+            hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, image);
         }
         dirty_s = false;
-        if (use_sp32)
-            hipLaunchKernelGGL(sp32::iqn_qvals_split32_kernel, dim3(blocks), dim3(512), sp32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                               (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
-        else if (quantiles_dev)
+        if (quantiles_dev)
             hipLaunchKernelGGL(sp::iqn_qvals_split_kernel<true>, dim3(blocks), dim3(512), sp::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                                (const uint32_t *)image, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev, (const float *)nullptr);
         else if (late.mask)
@@ -1123,32 +782,24 @@ static int launch_act(mn_iqn_ctx *c, const float *obs_dev, const float *taus_dev
         if (prof) { (void)hipEventRecord(c->ev[2 * c->prof_n + 1], s); ++c->prof_n; }
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
-    bool &dirty = use32 ? c->dirty32 : c->dirty;
-    float *packed = use32 ? c->packed32 : c->packed;
-    const int pack_blocks = dirty ? (use32 ? v32::PACK_BLOCKS : PACK_BLOCKS) : 0;
+    bool &dirty = c->dirty;
+    float *packed = c->packed;
+    const int pack_blocks = dirty ? PACK_BLOCKS : 0;
     if (rng_state_dev) {
         long groups = ((long)n * (K_TAUS + 1) + 3) / 4;
         int rng_blocks = (int)((groups + 255) / 256);
         if (rng_blocks > 8 * c->n_cu) rng_blocks = 8 * c->n_cu;
-        if (use32)
-            hipLaunchKernelGGL(v32::iqn_prep32_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, packed,
-                               (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
-        else
-            hipLaunchKernelGGL(iqn_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, packed,
-                               (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
+        hipLaunchKernelGGL(iqn_prep_kernel, dim3(pack_blocks + rng_blocks), dim3(256), 0, s, w, packed,
+                           (const uint64_t *)rng_state_dev, draws_dev, n, cvar_row_dev, cvar, pack_blocks);
         taus_dev = draws_dev;
         explore_u_dev = eps > 0.f ? draws_dev + (size_t)n * K_TAUS : nullptr;
     } else if (pack_blocks) {
-        if (use32) hipLaunchKernelGGL(v32::iqn_pack32_kernel, dim3(v32::PACK_BLOCKS), dim3(256), 0, s, w, packed);
-        else hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, packed);
+        hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, packed);
     }
     dirty = false;
     if (quantiles_dev)
         hipLaunchKernelGGL(iqn_qvals_kernel<true>, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                            packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, quantiles_dev);
-    else if (use32)
-        hipLaunchKernelGGL(v32::iqn_qvals32_kernel, dim3(blocks), dim3(512), v32::LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
-                           packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev);
     else
         hipLaunchKernelGGL(iqn_qvals_kernel<false>, dim3(blocks), dim3(512), LDS_FLOATS * sizeof(float), s, obs_dev, taus_dev,
                            packed, qvals_dev, explore_u_dev, eps, actions_dev, n, rng_state_dev, nullptr);
@@ -1164,23 +815,15 @@ extern "C" int mn_iqn_refresh(mn_iqn_ctx *c, const float *const *weights, void *
     const IqnWeights w = {weights[0], weights[1], weights[2], weights[3], weights[4], weights[5], weights[6],
                           weights[7], weights[8], weights[9], weights[10], weights[11], weights[12], weights[13]};
     hipStream_t s = (hipStream_t)stream;
-    if (c->variant == 2 || c->variant == 3) {
-        const bool use_sp32 = c->variant == 3;
-        bool &dirty_s = use_sp32 ? c->dirty_sp32 : c->dirty_sp;
-        if (dirty_s) {
+    if (c->variant == 2) {
+        if (c->dirty_sp) {
             hipLaunchKernelGGL(sp::iqn_split_consts_kernel, dim3(sp::CONST_BLOCKS), dim3(256), 0, s, w, c->consts_sp);
-            if (use_sp32) hipLaunchKernelGGL(sp32::iqn_split32_pack_kernel, dim3(sp32::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp32);
-            else hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
-            dirty_s = false;
+            hipLaunchKernelGGL(sp::iqn_split_pack_kernel, dim3(sp::PACK_BLOCKS), dim3(256), 0, s, w, (const float *)c->consts_sp, c->packed_sp);
+            c->dirty_sp = false;
         }
-    } else {
-        const bool use32 = c->variant == 1;
-        bool &dirty = use32 ? c->dirty32 : c->dirty;
-        if (dirty) {
-            if (use32) hipLaunchKernelGGL(v32::iqn_pack32_kernel, dim3(v32::PACK_BLOCKS), dim3(256), 0, s, w, c->packed32);
-            else hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, c->packed);
-            dirty = false;
-        }
+    } else if (c->dirty) {
+        hipLaunchKernelGGL(iqn_pack_kernel, dim3(PACK_BLOCKS), dim3(256), 0, s, w, c->packed);
+        c->dirty = false;
     }
     return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
 }

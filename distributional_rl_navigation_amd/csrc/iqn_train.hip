@@ -113,11 +113,7 @@ __device__ unsigned long long g_phase3[3][8];         // reduction + Adam blocks
 #define PH2(kern, k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) g_phase2[kern][blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
 #define PH3(k) do { if (threadIdx.x == 0 && (vb == 0 || vb == nvb / 2 || vb == nvb - 1)) g_phase3[vb == 0 ? 0 : (vb == nvb - 1 ? 2 : 1)][k] = wall_clock64(); } while (0)
 #define PH(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_phase[blockIdx.x == 0 ? 0 : 1][k] = wall_clock64(); } while (0)
-// multi-step launch: stamps of target workgroup 0 / the first local workgroup per step (mod 4): [role][step & 3][stamp]
-__device__ unsigned long long g_stepph[2][4][16];
-#define PHK(kk, i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == ph_local)) g_stepph[blockIdx.x == 0 ? 0 : 1][(kk) & 3][i] = wall_clock64(); } while (0)
 #else
-#define PHK(kk, i) do { } while (0)
 #define PH(k) do { } while (0)
 #define PH2(kern, k) do { } while (0)
 #define PH3(k) do { } while (0)
@@ -133,40 +129,20 @@ __device__ __forceinline__ int tid_now() {
 }
 
 // ---- parameter loads ------------------------------------------------------------------------------------------------------
-// A flat parameter vector as the forward / backward kernel reads it (element index -> value).  COH = false: ordinary loads.  COH = true (the fused, possibly
-// multi-step launch): the local network's parameters are REWRITTEN by other workgroups of the same launch between two of its steps (Adam of step k -> forward
-// of step k + 1); the writer stores them through (sc1), this side reads with agent-scope (sc1) loads, which are not served by this CU's vector cache (whose
-// lines nobody refreshes) -- MI355X_MICROARCH: 16-B sc1 stores AND sc1 loads, behind a drained flag.
-template <bool COH>
+// A flat parameter vector as the forward / backward kernel reads it (element index -> value).
 struct ParamView {
     const float *p;
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ explicit ParamView(const float *P) : p(P), r(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P), 0, P_TOTAL * 4, 0x00020000)) {}
-    __device__ __forceinline__ float f1(int i) const {
-        if constexpr (COH) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, i * 4, 0, 16));
-        else return p[i];
-    }
-    __device__ __forceinline__ float2 f2(int i) const {      // i even
-        if constexpr (COH) {
-            typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-            const u32x2s v = __builtin_amdgcn_raw_buffer_load_b64(r, i * 4, 0, 16);
-            return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
-        } else return *reinterpret_cast<const float2 *>(p + i);
-    }
-    __device__ __forceinline__ float4 f4(int i) const {      // i a multiple of 4
-        if constexpr (COH) {
-            typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
-            const u32x4p v = __builtin_amdgcn_raw_buffer_load_b128(r, i * 4, 0, 16);
-            return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-        } else return *reinterpret_cast<const float4 *>(p + i);
-    }
+    __device__ __forceinline__ explicit ParamView(const float *P) : p(P) {}
+    __device__ __forceinline__ float f1(int i) const { return p[i]; }
+    __device__ __forceinline__ float2 f2(int i) const { return *reinterpret_cast<const float2 *>(p + i); }      // i even
+    __device__ __forceinline__ float4 f4(int i) const { return *reinterpret_cast<const float4 *>(p + i); }      // i a multiple of 4
 };
 
 // ---- MFMA tile primitives --------------------------------------------------------------------------------------------
 // B operand of a 16x16 tile over K = 16 * NB, element (k, n), requested into registers (the loads are issued here; nothing waits).  W = parameter offset `off`.
 //   k-contiguous (nn.Linear weight used as W^T in the forward: element (k, n) at W[n * ldb + k]): one 16-byte load per block.
-template <int NB, bool COH>
-__device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb, int row = -1) {
+template <int NB>
+__device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const ParamView &P, int off, int ldb, int row = -1) {
     const int lane = tid_now() & 63, i = row < 0 ? lane & 15 : row, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
@@ -175,8 +151,8 @@ __device__ __forceinline__ void load_b_kcontig(float (&b)[NB][4], const ParamVie
     }
 }
 //   the same, or -- when `real` is false -- NB requests of the one 16-byte word at the head of the vector (a wave that has no such tile)
-template <int NB, bool COH>
-__device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb, bool real) {
+template <int NB>
+__device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const ParamView &P, int off, int ldb, bool real) {
     const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk) {
@@ -185,8 +161,8 @@ __device__ __forceinline__ void load_b_kcontig_if(float (&b)[NB][4], const Param
     }
 }
 //   k-strided (the same weight used untransposed in the backward: element (k, n) at W[k * ldb + n]): four scalar loads per block.
-template <int NB, bool COH>
-__device__ __forceinline__ void load_b_kstrided(float (&b)[NB][4], const ParamView<COH> &P, int off, int ldb) {
+template <int NB>
+__device__ __forceinline__ void load_b_kstrided(float (&b)[NB][4], const ParamView &P, int off, int ldb) {
     const int lane = tid_now() & 63, i = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < NB; ++kk)
@@ -384,8 +360,7 @@ struct FwdWeights {
 
 // All loads are unconditional and in one straight line (clamped indices instead of branches): a divergent branch around a load
 // makes hipcc wait for every outstanding load at the join, which would turn the prefetch into a chain of round trips.
-template <bool COH>
-__device__ __forceinline__ void prefetch_forward(FwdWeights &w, const ParamView<COH> &P) {
+__device__ __forceinline__ void prefetch_forward(FwdWeights &w, const ParamView &P) {
     const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
     {   // encoders: thread t < 416 computes feature o = t % 208 of batch element t / 208 (model.py:170-173); a velocity / goal
         // feature uses the first two of the 22 values it loads (they stay inside the flat parameter vector)
@@ -413,8 +388,7 @@ __device__ __forceinline__ void prefetch_forward(FwdWeights &w, const ParamView<
 // ... and the operands of layers 2-4 (60 % of the bytes), requested right AFTER the first barrier: a wave cannot write its
 // transitions to LDS before it has ISSUED every request in front of that write, and issuing 170 KB per CU takes 2.7 us of the load
 // path's time (37.0 -> 36.55 us per step).
-template <bool COH>
-__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const ParamView<COH> &P) {
+__device__ __forceinline__ void prefetch_forward_late(FwdWeights &w, const ParamView &P) {
     const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15;
     const int t23 = wave & 3;
     const bool l3 = wave < 4;
@@ -432,8 +406,7 @@ struct BwdWeights {
     float w3t[4][4];              // hidden_layer_2 columns of dh2 tile wave & 3 (waves 0-3 use it)
     float w2ta[4][4], w2tb[4][4]; // hidden_layer columns of dx tiles wave, wave + 8
 };
-template <bool COH>
-__device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const ParamView<COH> &PL) {
+__device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const ParamView &PL) {
     const int wave = __builtin_amdgcn_readfirstlane(tid_now() >> 6);
     load_b_kstrided<4>(bw.w3t, PL, O_W3 + (wave & 3) * 16, H);
     load_b_kstrided<4>(bw.w2ta, PL, O_W2 + wave * 16, F);
@@ -442,9 +415,9 @@ __device__ __forceinline__ void prefetch_backward(BwdWeights &bw, const ParamVie
 
 // model.py:160-186 for the 16 rows of this workgroup on all eight waves: `obs` [2][28], `tau` [16] in LDS (visible: the caller
 // placed a barrier after writing them).  Leaves cos, (h1,) x, h2, h3, features and q in LDS; ends with a barrier.
-template <bool BWD_PREFETCH, bool COH>
+template <bool BWD_PREFETCH>
 __device__ __forceinline__ void forward_pass(const PassBufs &Bf, const FwdWeights &w, const float *obs, const float *tau,
-                                             BwdWeights *bw, const ParamView<COH> &PL, int ph_local = -1) {
+                                             BwdWeights *bw, const ParamView &PL, int ph_local = -1) {
     const int tid = tid_now(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     {   // encoders: three linear maps, no activation (model.py:170-173).  Branch-free (a branch here would make hipcc wait for
         // every outstanding weight request): threads >= 416 compute a copy of batch element 1's feature into a dead LDS slot
@@ -499,7 +472,7 @@ __device__ __forceinline__ void forward_pass(const PassBufs &Bf, const FwdWeight
 #pragma unroll
         for (int r = 0; r < 4; ++r) Bf.h2[(4 * g + r) * LDC + o] = fmaxf(acc[r] + w.b2, 0.f);
     }
-    if constexpr (BWD_PREFETCH) prefetch_backward<COH>(*bw, PL);
+    if constexpr (BWD_PREFETCH) prefetch_backward(*bw, PL);
     __syncthreads();
     PH(4);   /* layer 2 */
     if (wave < 4) {   // h3 = relu(h2 W3^T + b3)
@@ -560,8 +533,7 @@ __host__ __device__ constexpr int64_t pad4(int64_t x) { return (x + 3) / 4 * 4; 
 __host__ __device__ constexpr int64_t ws_loss(int n_part) { return (int64_t)n_part * P_PAD; }
 __host__ __device__ constexpr int64_t ws_sq(int n_part) { return ws_loss(n_part) + pad4(n_part); }
 __host__ __device__ constexpr int64_t ws_tdq(int n_part) { return ws_sq(n_part) + pad4(N_RED); }      // (NOT rounded up to a cache line: shifting everything behind it by 32 bytes cost the stand-alone reduction 6 us -- measured, round 5)
-constexpr int MN_TD_SLOTS = 2;      // sets of TD-target granules, by step parity
-__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * MN_TD_SLOTS * (int64_t)n_part * ROWS; }      // (two sets of TD-target granules, by step parity)
+__host__ __device__ constexpr int64_t ws_epoch(int n_part) { return ws_tdq(n_part) + 2 * (int64_t)n_part * ROWS; }
 // epoch block: [0..1] epoch (u64), [2] Adam ticket (u32), [3] reduce ticket (u32), [4..7] staging tag {call counter, ring rows} (2 x u64),
 // [8] WS_MAGIC (written by mn_iqn_train_workspace_init: the reduction and Adam kernels refuse a workspace without it), [9] count of local workgroups of
 // XCD-grouped one-launch steps that did not run on the XCD of their group's first workgroup (u32, diagnostic: their rows took the slow way through memory),
@@ -586,9 +558,7 @@ __host__ __device__ constexpr int64_t ws_lflag(int n_part) { return ws_gdone(n_p
 __host__ __device__ constexpr int64_t ws_lossq(int n_part) { return ws_lflag(n_part) + 8 * 64; }
 __host__ __device__ constexpr int64_t ws_xcc(int n_part) { return ws_lossq(n_part) + pad4(2 * n_part); }
 __host__ __device__ constexpr int64_t ws_grp(int n_part) { return ws_xcc(n_part) + pad4(2 * n_part); }
-//   ws_pflag  256 u64 {step tag}: "the parameters this reduction + Adam block updates in step k are written" (multi-step launch: what the local workgroups of step k + 1 wait for)
-__host__ __device__ constexpr int64_t ws_pflag(int n_part) { return ws_grp(n_part) + 2 * (int64_t)RED_SEG * P_PAD; }
-__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_pflag(n_part) + 2 * 256; }
+__host__ __device__ constexpr int64_t ws_stage(int n_part) { return ws_grp(n_part) + 2 * (int64_t)RED_SEG * P_PAD; }
 constexpr uint32_t WS_MAGIC = 0x4D4E5753u;      // "MNWS"
 constexpr int STG = 72;   // floats per staged batch slot: state[26] | next_state[26] | action | reward | done | pad | taus_target[8] | taus_local[8]
 __host__ __device__ constexpr int64_t ws_total(int n_part) { return ws_stage(n_part) + (int64_t)n_part * BE * STG; }
@@ -673,9 +643,7 @@ static_assert(RA_COLS == 2 * RED_COLS && N_RED == 2 * ((P_TOTAL + 255) / 256), "
 // (defined with group_reduce below) wavefront 0 waits for the "row complete" news of the rows w = x (mod 8); returns the mask of rows that were written
 // through to memory instead of into this XCD's L2, *late = a bounded wait ran out
 __device__ __forceinline__ unsigned long long group_rows_wait(float *__restrict__ ws, int n_part, int x, uint32_t tag, int tid, bool *late);
-// cache policy of the loads that read a group's partial rows back through the XCD's L2.  1 = sc0, 16 = sc1.  Round 4 used sc0 (every row address was read once per
-// launch, so the CU's vector cache could not hold an older copy); in a multi-step launch it can -- the same addresses carry a new row every step and an sc0 load
-// may be served by the vector cache (MI355X_MICROARCH: "sc0 loads hit L1 like plain") -- so: sc1, which bypasses it and is still served by the L2.
+// cache policy of the loads that read a group's partial rows back through the XCD's L2.  1 = sc0, 16 = sc1 (bypasses this CU's vector cache, still served by the L2).
 #ifndef MN_ROW_AUX
 #define MN_ROW_AUX 16
 #endif
@@ -690,7 +658,6 @@ struct StepCtx {
     uint64_t rs0, ctr;   // generator: seed, call counter of THIS step's batch (unused without rng_state)
     bool last;           // the launch's last step: tickets are taken, the counters in memory advance to behind this step, the next batch is staged
     bool fused;          // role of the forward / backward launch: the eight XCD group rows arrive as self-tagged granules (group_reduce)
-    bool multi;          // ... of a launch with more steps to come: parameters are written through (other workgroups of this launch read them), no tail nap
 };
 
 // Physical block `pb` of `n_phys` runs the virtual blocks vb = pb, pb + n_phys, ... < nvb (at most VPB of them; VPB = 1 and n_phys = nvb everywhere but in the
@@ -806,7 +773,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
                         const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(ws, 0, n_part * P_PAD * 4, 0x00020000);
                         const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)bx * P_PAD, 0, P_PAD * 8, 0x00020000);
                         float4 t[16];
-                        // (sc1: past this CU's vector cache -- in a multi-step launch it may hold the previous step's row -- and served by the XCD's L2, which has the line)
+                        // (sc1: past this CU's vector cache, served by the XCD's L2, which has the line)
 #pragma unroll
                         for (int u = 0; u < 16; ++u) t[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rows, ((bx + 8 * u) * N_COLS + c) * 16, 0, ROW_AUX));
                         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -839,8 +806,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             // Nothing can arrive for a while: these blocks start when the target workgroups end, i.e. when the TD targets are out, and the backward pass behind
             // those takes >= 9 us.  65 000 threads polling 2.3 MB of granules through that time is memory traffic next to the backward pass (on this chip it
             // costs the step nothing measurable -- 33.4-33.6 us with naps of 0 / 5 / 7 / 9 us -- but it is traffic other streams' kernels would see).
-            if (!sc.multi)
-                while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)MN_TAIL_NAP) __builtin_amdgcn_s_sleep(32);
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)MN_TAIL_NAP) __builtin_amdgcn_s_sleep(32);
             bool want[VPB];
             uint64_t x[VPB][4];
             const __amdgpu_buffer_rsrc_t grp = __builtin_amdgcn_make_buffer_rsrc(ws + ws_grp(n_part) + 2 * (size_t)seg * P_PAD, 0, P_PAD * 8, 0x00020000);
@@ -947,7 +913,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
             // ... and by the index itself: `on[j]` alone is NOT safe here.  hipcc keeps it as a lane mask, re-forms its negation inside the divergent granule poll above (under
             // that loop's EXEC: v_cmp_ne of a v_cndmask of the mask) and uses THAT register for this test -- lanes 0 / 32 that left the poll before its last iteration
             // read 0 = "on" (ROCm 7.2; found in round 5 with a sentinel region: the store then zeroed the TD-target granules that follow the norm partials in the
-            // workspace, which only a multi-step launch ever reads again).  A scalar compare of the index cannot be merged with that mask.
+            // workspace).  A scalar compare of the index cannot be merged with that mask.
             if (2 * vbs[j] + 1 >= N_RED) continue;
             float t = 0.f;
             for (int k = 0; k < RED_COLS; ++k) t += sq[j][tid + k];
@@ -1021,8 +987,7 @@ __device__ __forceinline__ void reduce_adam_body(const int pb, const int n_phys,
         adam_update(gq, mm, vv, pn, wm, b2f, wv, step_size, bc2_sqrt, eps);
         m[p[j]] = mm;
         v[p[j]] = vv;
-        if (sc.multi) __hip_atomic_store(params + p[j], pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written through: the next step's forward pass reads it (ParamView<true>)
-        else params[p[j]] = pn;
+        params[p[j]] = pn;
     }
     // the block that took the LAST ticket advances the generator's call counter, the hand-off epoch and the Adam step, and tags the staged batch
     // (every block read all of them before taking its ticket; nothing in this launch reads them after that)
@@ -1050,7 +1015,7 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam(float *__restrict_
                                                               uint64_t *__restrict__ rng_state, BatchArgs ba, int prefetch_next,
                                                               float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                               int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d) {
-    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false, false};
+    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false};
     reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, sc);
 }
 
@@ -1060,7 +1025,7 @@ __global__ __launch_bounds__(RA_BT) void iqn_grad_reduce_adam_xchg(float *__rest
                                                                    float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
                                                                    int32_t *__restrict__ step, double lr, double b1, double b2, double eps_d, double max_norm_d,
                                                                    const XchgArgs *__restrict__ xa, float grad_scale) {
-    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false, false};
+    const StepCtx sc = {*reinterpret_cast<const uint64_t *>(ws + ws_epoch(n_part)), *step, rng_state ? rng_state[0] : 0ull, rng_state ? rng_state[1] : 0ull, true, false};
     reduce_adam_body<1>(blockIdx.x, gridDim.x, gridDim.x, ws, n_part, grad, loss_out, rng_state, ba, prefetch_next, params, m, v, step, lr, b1, b2, eps_d, max_norm_d, sc,
                         xa, grad_scale);
 }
@@ -1212,23 +1177,19 @@ __device__ __forceinline__ void group_reduce(float *__restrict__ ws, int n_part,
     }
 }
 
-// ---- The fused step (round 5): reduction + clip + Adam inside the forward / backward launch, for one OR SEVERAL gradient steps ------------------------------
-// Every TARGET workgroup is also a reduction + Adam block (reduce_adam_body): target workgroup w runs the target network on the next_states of step k + 1 --
-// nothing in it depends on the local network -- and then does the reduction + Adam work of step k on the CU it sits on anyway (round 4 launched those blocks
-// behind the forward / backward workgroups, onto the CUs the target workgroups had vacated).  With n_steps > 1 nobody leaves: the launch is PERSISTENT, step
-// k + 1 starts when the reduction + Adam blocks have written step k's parameters (written through; one "parameters ready" word per block, polled by one
-// wavefront of every local workgroup), and reads its batch straight from the ring (its rows follow from {seed, call counter + k} by arithmetic: no staging, one
-// round trip).  What a multi-step launch removes per step: the launch boundary, the L2 write-back of 18 MB of partial rows at it (they are overwritten in the L2
-// by the next step), the generator-state -> batch -> weights chain at the head of a launch, and the target forward pass from the local workgroups' critical path.
-// TD targets of consecutive steps use two sets of granules (step parity): target workgroup w may publish step k + 1's before local workgroup w has read step k's.
-// Always XCD-grouped (the rows of an XCD's workgroups are summed inside its L2); batches whose half is not a multiple of 8 take two launches.
+// ---- The fused step (round 5): reduction + clip + Adam inside the forward / backward launch ---------------------------------------------------------------------
+// Every TARGET workgroup is also a reduction + Adam block (reduce_adam_body): target workgroup w runs the target network on the next_states of its two batch
+// elements -- nothing in it depends on the local network -- and then does reduction + Adam work on the CU it sits on anyway (round 4 launched those blocks
+// behind the forward / backward workgroups, onto the CUs the target workgroups had vacated).  Always XCD-grouped (the rows of an XCD's workgroups are summed
+// inside its L2); batches whose half is not a multiple of 8 take two launches.
+// (Round 5 also ran G steps in ONE persistent launch of this kernel -- mn_iqn_train_steps, bit-identical, 33.4 us per step against 32.4 for G launches: the hand-off
+// of freshly written parameters to 128 workgroups on other XCDs cost what the launch boundary did.  Removed in round 6; profiles/r05_train_step_launches.txt.)
 struct StepTail {
     int n_virtual;      // != 0: the fused step; the N_ADAM virtual reduction + Adam blocks run on ...
     int n_extra;        // ... the target workgroups + this many workgroups behind the forward / backward ones that do nothing else (small batches: 2 x (n_part + n_extra) >= N_ADAM)
-    int n_steps;        // gradient steps of this launch (>= 1)
     int misplace;       // test hook: pretend these local workgroups did not land on XCD (block index % 8): 1 = every fifth, 2 = all, 3 = all of group 3
-    int prefetch_next;  // the last step stages the batch of the call after this launch
-    float *grad, *loss_out, *params, *m, *v;      // loss_out [n_steps]
+    int prefetch_next;  // the step stages the batch of the call after this launch
+    float *grad, *loss_out, *params, *m, *v;
     int32_t *step;
     uint64_t *rng_state;
     double lr, b1, b2, eps, max_norm;
@@ -1259,17 +1220,15 @@ __device__ __forceinline__ BatchArgs ld_batch_args(TrainArgsK A) {
                      A->ba.idx_out, A->ba.taus_out};
 }
 __device__ __forceinline__ StepTail ld_step_tail(TrainArgsK A) {
-    return StepTail{A->tail.n_virtual, A->tail.n_extra, A->tail.n_steps, A->tail.misplace, A->tail.prefetch_next, A->tail.grad, A->tail.loss_out, A->tail.params, A->tail.m,
+    return StepTail{A->tail.n_virtual, A->tail.n_extra, A->tail.misplace, A->tail.prefetch_next, A->tail.grad, A->tail.loss_out, A->tail.params, A->tail.m,
                     A->tail.v, A->tail.step, A->tail.rng_state, A->tail.lr, A->tail.b1, A->tail.b2, A->tail.eps, A->tail.max_norm, A->tail.xa, A->tail.xa_scale};
 }
 
-template <bool XCHG, bool FUSED, bool MULTI>
+template <bool XCHG, bool FUSED>
 __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args) {
-    static_assert(FUSED || !MULTI, "several steps per launch: the fused step only");
     extern __shared__ __align__(16) float S[];
     __shared__ int s_act[BE];
     __shared__ int s_got;
-    const int G = MULTI ? args.tail.n_steps : 1;      // (MULTI = false: one step, compiled as a single pass -- no loop-carried state, ordinary parameter loads)
     // ---- the counters this launch starts from; nothing in memory moves before its last step's reduction + Adam blocks have all taken their ticket
     uint64_t epoch0, rs0 = 0, rs1 = 0, tg0 = 0, tg1 = 0;      // scalar state first (generator state, staging tag): issued before the weight requests flood the memory pipeline
     int32_t step0 = 0;
@@ -1287,8 +1246,8 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     if (tid_now() == 0) g_wgt[blockIdx.x][0] = wall_clock64();
 #endif
 
-    // Iteration k: target workgroups run the target forward pass of step k, then the reduction + Adam work of step k - 1; local workgroups run step k.
-    for (int k = 0; k <= (MULTI ? G : (FUSED ? 1 : 0)); ++k) {
+    // Iteration 0: the forward / backward pass (target workgroups: the target forward pass); iteration 1 (fused step): target and extra workgroups run the reduction + Adam role.
+    for (int k = 0; k <= (FUSED ? 1 : 0); ++k) {
     // (One step's scalar and address arithmetic must not be hoisted out of the loop -- hundreds of values would then live across the whole body: the thread index is
     // opaque at every use (tid_now), the block index and the kernel arguments -- re-read from the kernarg segment -- are made opaque per iteration, and everything
     // derived from them, the workgroup's role included, is derived again.)
@@ -1318,15 +1277,15 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     const float gamma = FUSED ? A->gamma : args.gamma;
     const int use_staged = FUSED ? A->use_staged : args.use_staged;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
-    const ParamView<MULTI> VL(PL);
+    const ParamView VL(PL);
     const float *stage = ws + ws_stage(n_part);
     const int st_slot = min(tid / STG, BE - 1), st_e = tid % STG;
     float *out = ws + (size_t)part * P_PAD;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, P_PAD * 4, 0x00020000);
-    if (k < G && !is_extra) {
+    if (k < 1 && !is_extra) {
     // hand-off tag of this step: never 0 (the workspace starts zero-filled), different from the neighbouring steps' and launches' tags
     const uint32_t tag = (uint32_t)((epoch0 + (uint64_t)k) % 0xFFFFFFFFull) + 1u;
-    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + ((size_t)(k % MN_TD_SLOTS) * n_part + part) * ROWS;
+    gu64 *granules = (gu64 *)(ws + ws_tdq(n_part)) + (size_t)part * ROWS;
     if (FUSED && !is_target && tid == 0) {      // where this local workgroup runs (see "local workgroup" below)
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1336,33 +1295,13 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     // ---- The first requests of a step: (a) -- first step of a launch -- this workgroup's two batch slots as the previous launch's reduction blocks STAGED them
     // (transitions and taus, 72 floats per slot, at an address that depends on nothing but the kernel arguments), (b) every weight
     // operand of the forward pass.  One round trip instead of three dependent ones (generator state -> ring rows -> transitions).
-    if (MULTI && !is_target && k > 0) {
-        // ---- multi-step launch: the parameters of step k - 1, from every reduction + Adam block (their stores are written through and acknowledged before the
-        // word is): ONE wavefront polls the n_phys words, everything this workgroup reads of the local network from here on is read past its vector cache
-        const uint32_t ptag = (uint32_t)((epoch0 + (uint64_t)k - 1) % 0xFFFFFFFFull) + 1u;
-        bool plate = false;
-        if (wave == 0) {
-            const gu64 *pf = (const gu64 *)(ws + ws_pflag(n_part));
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                bool ok = true;
-                for (int q = lane; q < n_phys; q += 64) ok = ok && (uint32_t)(__hip_atomic_load(pf + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == ptag;
-                if (__all(ok)) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { plate = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (plate && lane == 0) atomicAdd(reinterpret_cast<unsigned *>(ws + ws_epoch(n_part) + 12), 1u);      // (status word: this step runs on stale parameters)
-        }
-        __syncthreads();
-    }
-    PHK(k, 0);   /* step k begins (parameters of step k - 1 seen) */
     // (Measured and dropped: gathering the batch in FRONT of that wait -- 1.6 us earlier requests, but two sites that define the 140 weight registers cost 48 bytes of
     // scratch per lane and the step got 1 us longer.)
     const bool try_staged = use_staged && k == 0;
     float st_v = 0.f;
     if (try_staged) st_v = stage[(b0 + st_slot) * STG + st_e];      // kernel argument: a scalar branch
     FwdWeights w;
-    const ParamView<MULTI> V(is_target ? PT : PL);
+    const ParamView V(is_target ? PT : PL);
     prefetch_forward(w, V);
     PH(14);  /* all requests issued */
     // the staged batch is this step's batch iff it was drawn for this call counter from a ring of this many rows
@@ -1428,7 +1367,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     __syncthreads();
     prefetch_forward_late(w, V);
     PH(1);   /* draw + gather + weight requests */
-    PHK(k, 1);
 
     // output-layer row of the action taken, for dh3 (element tid + 512 e of the [16][64] tile: row 8 e + (tid >> 6), column tid & 63,
     // i.e. batch element e): two more early requests
@@ -1450,12 +1388,10 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
             __hip_atomic_store(granules + tid, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PH(7);   /* granules published */
-        PHK(k, 2);
-        if (bid == 0 && k == G - 1) write_batch_copies(ba, base, batch);
+        if (bid == 0) write_batch_copies(ba, base, batch);
 #ifdef MN_TRAIN_PHASES
         if (tid_now() == 0) g_wgt[blockIdx.x][1] = wall_clock64();
 #endif
-        if (MULTI) __syncthreads();      // (the next forward pass of this workgroup overwrites the rewards / done flags wave 0 has just read)
     } else {
 
     // ---- local workgroup
@@ -1471,7 +1407,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         if (tid == 0 && (part >> 3) != 0) lead_word = __hip_atomic_load((const gu64 *)(ws + ws_xcc(n_part)) + (part & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- TD targets: from the target workgroup of the same two batch elements (ready by now -- it ran the same forward at the same
-    // time on another CU; in a multi-step launch one step ahead), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
+    // time on another CU), or computed here (mode 1; or the granules did not arrive within the bound, which in-order workgroup
     // dispatch makes impossible -- kept so that a wait can never hang the device)
     if (two_roles) {
         if (wave == 0) {
@@ -1510,7 +1446,7 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
             __syncthreads();
         }
         FwdWeights wt;
-        const ParamView<MULTI> VT(PT);
+        const ParamView VT(PT);
         prefetch_forward(wt, VT);
         prefetch_forward_late(wt, VT);
         const PassBufs Bt = {S + T_C, nullptr, S + T_X, S + T_H2, S + T_H3, S + T_FEAT, S + T_Q};
@@ -1523,7 +1459,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     }
 
     PH(8);   /* TD targets in LDS (hand-off wait, or own target forward) */
-    PHK(k, 3);
     // ---- quantile-Huber loss and dL/dQ_expected (agent.py:289-295, 401-407); every thread evaluates the (cheap) gradient of
     // the row its dh3 elements belong to, so the loss phase and the output-layer backward share one barrier interval
     // Fused step: the row is read by the workgroups of its group (block index % 8), which share an XCD, through that XCD's L2: ordinary stores.  A workgroup
@@ -1705,7 +1640,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     }
     if (tid < P_PAD - P_TOTAL) pstore1(out + P_TOTAL + tid, 0.f, wt);   // row padding: read (as zeros) by the reduction's 16-byte loads
     PH(13);  /* dW1, encoder gradients issued */
-    PHK(k, 4);
     if (!two_roles && bid == 0) write_batch_copies(ba, base, batch);
     if (FUSED) {      // this workgroup's row (and loss partial) is final
         // Its stores are acknowledged -- by memory if they were write-through ones, by this XCD's L2 otherwise -- once vmcnt is 0; nothing of a
@@ -1713,7 +1647,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         PH(17);
-        PHK(k, 5);
 #ifdef MN_TRAIN_PHASES
         if (tid_now() == 0) g_wgt[blockIdx.x][2] = wall_clock64();
 #endif
@@ -1723,7 +1656,6 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
         }
         group_reduce(ws, n_part, part, tag, tid);      // ... and this workgroup's share of its XCD group's row sum (self-tagged: nothing to wait for behind it)
         PH(18);
-        PHK(k, 6);
     }
 #ifdef MN_TRAIN_PHASES
     __builtin_amdgcn_s_waitcnt(0);
@@ -1735,19 +1667,9 @@ __global__ __launch_bounds__(THREADS) void iqn_train_fwdbwd(const TrainArgs args
     if ((is_target || is_extra) && k >= 1) {
         // ---- reduction + clip + Adam of step k - 1
         const int s = k - 1;
-        const StepCtx sc = {epoch0 + (uint64_t)s, step0 + s, rs0, rs1 + (uint64_t)s, s == G - 1, true, MULTI};
-        PHK(s, 8);   /* reduction + Adam of step s begins */
+        const StepCtx sc = {epoch0 + (uint64_t)s, step0 + s, rs0, rs1 + (uint64_t)s, true, true};
         reduce_adam_body<2>(pb, n_phys, tail.n_virtual, ws, n_part, tail.grad, tail.loss_out + s, tail.rng_state, ba, tail.prefetch_next, tail.params, tail.m, tail.v,
                             tail.step, tail.lr, tail.b1, tail.b2, tail.eps, tail.max_norm, sc, XCHG ? tail.xa : nullptr, XCHG ? tail.xa_scale : 1.0f);
-        if (s < G - 1) {      // more steps to come: this block's parameters are out (write-through stores, acknowledged) -- say so
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (tid == 0) {
-                const uint32_t stag = (uint32_t)((epoch0 + (uint64_t)s) % 0xFFFFFFFFull) + 1u;
-                __hip_atomic_store((gu64 *)(ws + ws_pflag(n_part)) + pb, (uint64_t)stag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        PHK(s, 12);   /* parameters out */
     }
     }      // k
 }
@@ -2063,9 +1985,6 @@ extern "C" int mn_iqn_train_debug_wgt(unsigned long long *out_host) {   // [1024
 extern "C" int mn_iqn_train_debug_phases3(unsigned long long *out_host) {   // [first, middle, last reduction + Adam block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase3), sizeof(unsigned long long) * 24) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
-extern "C" int mn_iqn_train_debug_stepph(unsigned long long *out_host) {   // [target workgroup 0, first local workgroup][step & 3][16]
-    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stepph), sizeof(unsigned long long) * 128) == hipSuccess ? MN_OK : MN_ERR_HIP;
-}
 extern "C" int mn_iqn_train_debug_phases2(unsigned long long *out_host) {   // [reduce, adam][block 0, middle block][8]
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase2), sizeof(unsigned long long) * 32) == hipSuccess ? MN_OK : MN_ERR_HIP;
 }
@@ -2154,9 +2073,8 @@ static int dev_info(DevInfo *out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MN_ERR_HIP;
         // the forward / backward kernel's dynamic LDS (97 KB) is above the default limit: raised once per device
-        const void *kernels[] = {reinterpret_cast<const void *>(iqn_train_fwdbwd<false, false, false>), reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true, false>),
-                                 reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true, false>), reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true, true>),
-                                 reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true, true>)};
+        const void *kernels[] = {reinterpret_cast<const void *>(iqn_train_fwdbwd<false, false>), reinterpret_cast<const void *>(iqn_train_fwdbwd<false, true>),
+                                 reinterpret_cast<const void *>(iqn_train_fwdbwd<true, true>)};
         for (const void *kf : kernels)
             if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return MN_ERR_HIP;
         int a = 0, b = 0;
@@ -2176,7 +2094,7 @@ static int dev_info(DevInfo *out) {
 struct LaunchPlan {
     int mode;        // MODE_TWO_ROLES / MODE_LOCAL_ONLY
     int n_fwd;       // forward / backward workgroups
-    int launches;    // per gradient step -- 1: the fused step (reduction + Adam ride in the forward / backward launch; a multi-step call is ONE launch altogether);
+    int launches;    // per gradient step -- 1: the fused step (reduction + Adam ride in the forward / backward launch);
                      // 2: + iqn_grad_reduce_adam[_xchg]; 3: + iqn_grad_reduce + iqn_adam; 4: + iqn_grad_reduce, iqn_grad_gather, iqn_adam (shared learner on a device
                      // too small for the fused launches)
     int n_extra;     // fused: workgroups behind the forward / backward ones that only run reduction + Adam blocks
@@ -2191,8 +2109,8 @@ static LaunchPlan plan_launch(const DevInfo &d, int batch, int flags, bool adam,
     if (!adam) { p.launches = 2; return p; }      // (mn_iqn_train_grad*: forward / backward + iqn_grad_reduce; Adam is the caller's next call)
     if ((flags & MN_TRAIN_ONE_LAUNCH) && p.mode == MODE_TWO_ROLES && n_part % 8 == 0) {
         // The fused step: the target workgroups are the reduction + Adam blocks (two virtual blocks each; small batches add blocks that do nothing else).  Its
-        // workgroups wait for each other -- local ones for their XCD group's rows, reduction + Adam blocks for each other's norm partials, in a multi-step
-        // launch everybody for everybody -- so ALL of them must be resident together: one CU each (97 KB of LDS, 226 registers).
+        // workgroups wait for each other -- local ones for their XCD group's rows, reduction + Adam blocks for each other's norm partials
+        // -- so ALL of them must be resident together: one CU each (97 KB of LDS, 226 registers).
         p.n_extra = std::max(0, (N_ADAM + 1) / 2 - n_part);
         if (p.n_fwd + p.n_extra <= d.n_cu) { p.launches = 1; return p; }
     }
@@ -2236,11 +2154,10 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
                        const float *ring_rewards, const float *ring_dones, const int64_t *idx_dev, const float *taus_target_dev,
                        const float *taus_local_dev, const float *params_local, const float *params_target, float *workspace,
                        float *grad_out, float *loss_out, int32_t batch, int32_t num_taus, float gamma, uint64_t *rng_state_dev,
-                       int64_t ring_size, int64_t *idx_out, float *taus_out, int32_t flags, void *stream, const AdamArgs *adam = nullptr, int n_steps = 1) {
+                       int64_t ring_size, int64_t *idx_out, float *taus_out, int32_t flags, void *stream, const AdamArgs *adam = nullptr) {
     if (!ring_states || !ring_next_states || !ring_actions || !ring_rewards || !ring_dones || !params_local || !params_target ||
         !workspace || !grad_out || !loss_out)
         return MN_ERR_INVALID;
-    if (n_steps < 1 || (n_steps > 1 && (!adam || !rng_state_dev))) return MN_ERR_INVALID;      // several steps: whole steps, batches drawn in the launch
     if (rng_state_dev ? (ring_size < batch || ring_size > 0x7fffffff) : (!idx_dev || !taus_target_dev || !taus_local_dev))
         return MN_ERR_INVALID;
     if (batch <= 0 || batch > MAX_BATCH || batch % BE || num_taus != NQ) return MN_ERR_INVALID;
@@ -2257,28 +2174,17 @@ static int launch_grad(const float *ring_states, const float *ring_next_states, 
     hipStream_t s = (hipStream_t)stream;
     const int use_staged = rng_state_dev && (flags & MN_TRAIN_USE_STAGED) ? 1 : 0;
     const int prefetch_next = rng_state_dev && (flags & MN_TRAIN_STAGE_NEXT) ? 1 : 0;
-    if (plan.launches == 1) {      // the fused step: ONE launch for all n_steps
-        const StepTail tail = {N_ADAM, plan.n_extra, n_steps, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
+    if (plan.launches == 1) {      // the fused step
+        const StepTail tail = {N_ADAM, plan.n_extra, (flags >> 4) & 3, prefetch_next, grad_out, loss_out, adam->params, adam->exp_avg, adam->exp_avg_sq, adam->step_dev,
                                rng_state_dev, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->max_norm, x ? x->dev_args : nullptr, adam->grad_scale};
         const TrainArgs ta = {ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, tail};
         const dim3 grid(plan.n_fwd + plan.n_extra);
-        if (x && n_steps > 1) hipLaunchKernelGGL((iqn_train_fwdbwd<true, true, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
-        else if (x) hipLaunchKernelGGL((iqn_train_fwdbwd<true, true, false>), grid, dim3(THREADS), LDS_BYTES, s, ta);
-        else if (n_steps > 1) hipLaunchKernelGGL((iqn_train_fwdbwd<false, true, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
-        else hipLaunchKernelGGL((iqn_train_fwdbwd<false, true, false>), grid, dim3(THREADS), LDS_BYTES, s, ta);
+        if (x) hipLaunchKernelGGL((iqn_train_fwdbwd<true, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
+        else hipLaunchKernelGGL((iqn_train_fwdbwd<false, true>), grid, dim3(THREADS), LDS_BYTES, s, ta);
         return hipGetLastError() == hipSuccess ? MN_OK : MN_ERR_HIP;
     }
-    if (n_steps > 1) {      // no fused form for this batch / device: the steps one after the other (every later one starts from the batch its predecessor staged)
-        for (int k = 0; k < n_steps; ++k) {
-            const int f = k == 0 ? flags : ((flags | MN_TRAIN_USE_STAGED) & (prefetch_next ? ~0 : ~MN_TRAIN_USE_STAGED));
-            if (int rc = launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, idx_dev, taus_target_dev, taus_local_dev, params_local, params_target,
-                                     workspace, grad_out, loss_out + k, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, f, stream, adam, 1))
-                return rc;
-        }
-        return MN_OK;
-    }
     const StepTail no_tail = {};
-    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s,
+    hipLaunchKernelGGL((iqn_train_fwdbwd<false, false>), dim3(plan.n_fwd), dim3(THREADS), LDS_BYTES, s,
                        TrainArgs{ba, params_local, params_target, workspace, batch, gamma, plan.mode, use_staged, no_tail});
     if (plan.launches == 2 && x)
         hipLaunchKernelGGL(iqn_grad_reduce_adam_xchg, dim3(N_ADAM), dim3(RA_BT), 0, s, workspace, n_part, grad_out, loss_out, rng_state_dev, ba, prefetch_next,
@@ -2330,32 +2236,6 @@ extern "C" int mn_iqn_train_step(const float *ring_states, const float *ring_nex
     return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, rng_state_dev ? nullptr : idx_dev,
                        rng_state_dev ? nullptr : taus_target_dev, rng_state_dev ? nullptr : taus_local_dev, params_local, params_target, workspace,
                        grad_out, loss_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags, stream, &adam);
-}
-
-// n_steps gradient steps of a single learner, batches drawn in the launch -- ONE launch where the fused step exists (batch a multiple of 16, every workgroup a CU of
-// its own: batch <= 256 on an MI355X), else n_steps x mn_iqn_train_step.  Step k's loss -> losses_out[k].  Bit-identical to n_steps calls of mn_iqn_train_step
-// (with MN_TRAIN_STAGE_NEXT / MN_TRAIN_USE_STAGED as the caller would pass them: `flags` describe the FIRST step; later ones need no staging).
-extern "C" int mn_iqn_train_steps(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
-                                  const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
-                                  const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
-                                  int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1, double beta2,
-                                  double eps, double max_norm, void *stream) {
-    if (!rng_state_dev || !params_local || !exp_avg || !exp_avg_sq || !step_dev || n_steps < 1) return MN_ERR_INVALID;
-    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, nullptr, 1.0f};
-    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local, params_target, workspace,
-                       grad_out, losses_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags | MN_TRAIN_ONE_LAUNCH, stream, &adam, n_steps);
-}
-
-// ... and of a SHARED learner (the exchange inside every step's reduction + Adam role; all ranks call with the same n_steps)
-extern "C" int mn_iqn_train_steps_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
-                                       const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
-                                       const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
-                                       int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1,
-                                       double beta2, double eps, double max_norm, float grad_scale, void *stream) {
-    if (!x || !rng_state_dev || !params_local || !exp_avg || !exp_avg_sq || !step_dev || n_steps < 1 || !(grad_scale > 0.f)) return MN_ERR_INVALID;
-    const AdamArgs adam = {params_local, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, max_norm, x, grad_scale};
-    return launch_grad(ring_states, ring_next_states, ring_actions, ring_rewards, ring_dones, nullptr, nullptr, nullptr, params_local, params_target, workspace,
-                       grad_out, losses_out, batch, num_taus, gamma, rng_state_dev, ring_size, idx_out, taus_out, flags | MN_TRAIN_ONE_LAUNCH, stream, &adam, n_steps);
 }
 
 extern "C" int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,

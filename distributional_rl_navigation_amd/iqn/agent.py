@@ -116,9 +116,6 @@ class IQNAgent(ReferenceLoopMixin):
         self.use_library_rng = True                  # False: taus / exploration uniforms from torch.rand on self.gen
         self.shared_taus = False                     # opt-in: one set of 32 taus per act LAUNCH instead of per row (fused_act(shared_taus=True))
         self.use_fused_graph = False                 # opt-in: the fused gradient steps of one training event as one captured hipGraph (train_steps_from_memory)
-        self.use_multi_step = False                  # opt-in: the gradient steps of one training event as ONE persistent launch (mn_iqn_train_steps; bit-identical to the
-                                                     # single steps).  One launch instead of G for the host; on the GPU 33.4 us per step against 32.4 for single fused steps
-                                                     # (round 5: the parameter hand-off between steps costs what the launch boundary did) -- so not the default
         self.reset_under_act = False                 # vec_step: the episode resets of a vector step run on the env's own stream UNDER the next step's act kernel (which takes
                                                      # the finished envs' rows last) instead of in front of it: same results, ~28 us off every vector step's critical path.  The
                                                      # `obs` vec_step returns then has rows still being written: hand it back to vec_step, or call `train_env.join_reset()` before
@@ -325,14 +322,6 @@ class IQNAgent(ReferenceLoopMixin):
             loss = ft.graphed_steps((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, n_steps)
             self.grad_steps += n_steps
             return loss
-        if (self.use_multi_step and self.use_fused_train and self.device.type == "cuda" and n_steps > 1 and len(self.memory) >= self.BATCH_SIZE):
-            ft = self._fused_trainer()
-            if ft._two_launches():      # (an RCCL shared learner has its collective between the gradient and Adam: single steps)
-                m = self.memory
-                self._enter_train_path("hip")
-                loss = ft.steps_sampled((m.states, m.actions, m.rewards, m.next_states, m.dones), m.size, self.BATCH_SIZE, n_steps, m.version)
-                self.grad_steps += n_steps
-                return loss
         loss = None
         for _ in range(n_steps):
             loss = self.train_from_memory()

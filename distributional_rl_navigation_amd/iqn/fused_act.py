@@ -66,7 +66,7 @@ class ActContext:
 
     def set_variant(self, variant):
         """2 = the split-f16 kernel (default: three f16 MFMA products per float32 product, float32-class accuracy, ~3x faster),
-        0 = the exact-f32 16x16x4 MFMA kernel, 1 = its 32x32x2 re-layout, 3 = the split-f16 kernel on 32x32x16 tiles (A / B measurements, tests)."""
+        0 = the exact-f32 16x16x4 MFMA kernel (A / B measurements, tests)."""
         rc = _capi.lib().mn_iqn_set_variant(self.h, int(variant))
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_set_variant failed ({rc})")

@@ -56,7 +56,6 @@ class FusedTrainer:
         self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)      # per-step losses of a multi-step launch (steps_sampled)
         self._ws, self._ws_batch, self._ws_by_batch = None, 0, {}
         self._mailbox = None         # iqn/mailbox.py: MailboxExchange of a shared learner with agent.exchange == "mailbox"
         self._staged_key = None      # (ring, its version, rows, batch, workspace) the workspace holds a staged next batch for
@@ -266,42 +265,6 @@ class FusedTrainer:
                 mb = self._mailbox = MailboxExchange(self.device)
             return L.mn_iqn_train_step_xchg(mb.h, *common, C.c_float(1.0 / mb.world), stream)
         return L.mn_iqn_train_step(*common, stream)
-
-    def steps_sampled(self, ring, ring_size, batch, n_steps, ring_version=None):
-        """`n_steps` x step_sampled as ONE call into the library (mn_iqn_train_steps[_xchg]): where the fused step exists ONE persistent launch -- step k + 1 starts
-        when the reduction + Adam blocks have written step k's parameters, reads its batch straight from the ring and finds its TD targets waiting -- else the
-        steps one after the other.  Bit-identical to the eager sequence (tests).  Returns the last step's loss; `self.losses[:n_steps]` holds all of them."""
-        ag = self.agent
-        assert self._two_launches(), "multi-step launches need the whole step in the library: a single learner, or the mailbox exchange"
-        states, actions, rewards, next_states, dones = ring
-        for t in ring:
-            assert t.is_cuda and t.is_contiguous()
-        if batch not in self._idx:
-            self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
-            self._taus[batch] = torch.empty(2, batch, ag.N, dtype=torch.float32, device=self.device)
-        if self.losses.numel() < n_steps:
-            self.losses = torch.zeros(n_steps, dtype=torch.float32, device=self.device)
-        L = _capi.lib()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        ws = self._workspace(batch)
-        flags = 0
-        if ring_version is not None:      # the first step may start from the batch the previous call staged; the last one stages for the next call
-            key = (states.data_ptr(), int(ring_version), int(ring_size), batch, ws.data_ptr())
-            flags = 2 | (1 if key == self._staged_key else 0)
-        flags |= self._one_launch_flags(batch) & ~4      # (the test hook; MN_TRAIN_ONE_LAUNCH is implied)
-        args = (_p(states), _p(next_states), _p(actions), _p(rewards), _p(dones), int(ring_size), _p(self.rng_state), _p(self._idx[batch]), _p(self._taus[batch]),
-                _p(self.local), _p(self.target), _p(ws), _p(self.grad), _p(self.losses), _p(self.exp_avg), _p(self.exp_avg_sq), _p(self.step_dev), batch, ag.N,
-                C.c_float(ag.GAMMA ** ag.n_step), flags, int(n_steps), C.c_double(ag.LR), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-8), C.c_double(0.5))
-        if ag.distributed:
-            mb = self._mailbox
-            rc = L.mn_iqn_train_steps_xchg(mb.h, *args, C.c_float(1.0 / mb.world), stream)
-        else:
-            rc = L.mn_iqn_train_steps(*args, stream)
-        self._staged_key = (states.data_ptr(), int(ring_version), int(ring_size), batch, ws.data_ptr()) if ring_version is not None else None
-        if rc:
-            raise _capi.MarineNavHipError(f"mn_iqn_train_steps failed ({rc}): need batch <= 1024 and ring_size >= batch")
-        weights_changed(ag.qnetwork_local)
-        return self.losses[n_steps - 1]
 
     def graphed_steps(self, ring, ring_size, batch, n_steps):
         """`n_steps` x step_sampled as ONE hipGraph launch (captured on first use, re-captured when the ring's tensors / size, the

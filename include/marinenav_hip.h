@@ -289,11 +289,9 @@ int mn_iqn_weights_changed(mn_iqn_ctx *c);
  *      and a product is accumulated as lo.hi + hi.lo + hi.hi on v_mfma_f32_16x16x32_f16 with power-of-two range scaling chosen
  *      from a guaranteed bound, so the result has the error class of float32 arithmetic (measured against a float64
  *      evaluation it is as close as the exact kernel and as eager PyTorch float32) at ~1/3 of the time;
- *   0: the exact-f32 v_mfma_f32_16x16x4_f32 kernel;
- *   1: the exact-f32 v_mfma_f32_32x32x2_f32 re-layout (measured 2.6 % slower than 0 on MI355X, kept for comparison);
- *   3: the split-f16 kernel on v_mfma_f32_32x32x16_f16 tiles, output layer on the matrix pipe too (half the MFMA instructions
- *      of 2; measured 4 % slower on MI355X, kept for comparison; quantile output is served by kernel 2).
- * Same network in all four; they differ by float32 rounding only. */
+ *   0: the exact-f32 v_mfma_f32_16x16x4_f32 kernel.
+ * Same network in both; they differ by float32 rounding only.  Anything else is MN_ERR_INVALID (1 and 3 were the 32x32 re-layouts of the two kernels,
+ * measured 2.6 % / 4 % slower on MI355X in rounds 2 / 4 and removed in round 6). */
 int mn_iqn_set_variant(mn_iqn_ctx *c, int32_t variant);
 /* How an act launch's quantile fractions are drawn (round 4).
  *   0 (default): every observation row gets its own 32 taus -- what a batch of independent calls of the reference's batch-1
@@ -315,7 +313,7 @@ int mn_iqn_set_tau_mode(mn_iqn_ctx *c, int32_t mode);
  * stream is still writing, flags_dev [n] / tick say when a row is final (flags_dev[e] == tick; the row itself written through at agent
  * scope before the word).  The launch takes those rows last and reads them past the caches; results equal those of a launch behind the
  * reset.  Returns MN_OK if the next launch of n rows will honour it (launch it next on this context), 1 if the context's current form
- * cannot (exact / 32x32 variants, launch-shared taus, quantile capture, more than 64 rows per wavefront): the caller joins the reset
+ * cannot (the exact-f32 variant, launch-shared taus, quantile capture, more than 64 rows per wavefront): the caller joins the reset
  * (mn_reset_join) instead.  NULL, NULL clears.  mn_iqn_late_timeouts: waits that ran out (0.5 s bound; mn_iqn_set_late_bound_ms, in (0, 60 000] ms,
  * for launches armed afterwards) since the context was made -- anything but 0 means an action was computed on an unfinished row, i.e. the reset
  * launch did not run beside the act kernel on this box: the caller goes back to mn_reset_done (synchronises `stream`).  mn_iqn_late_timeouts_peek:
@@ -417,9 +415,7 @@ int mn_replay_append(const float *obs_dev, const int32_t *actions_dev, const flo
  * step; batch a multiple of 16 and every workgroup a CU of its own: batch <= 256 on an MI355X; else two launches): the target workgroups of the forward /
  * backward launch are also its reduction + Adam blocks.  XCD-grouped: the partial-gradient rows of the workgroups that share an XCD (block index mod 8: the
  * dispatcher deals workgroups out round-robin) are summed inside that XCD's L2 and only the eight group rows cross to the other XCDs, as self-tagged granules the
- * reduction blocks poll.  mn_iqn_train_steps: n_steps such steps in ONE persistent launch (round 5) -- step k + 1 starts when the reduction + Adam blocks have
- * written step k's parameters; losses_out [n_steps].  All forms
- * are bit-identical.  rng_state_dev != NULL: the batch is drawn in the
+ * reduction blocks poll.  All forms are bit-identical.  rng_state_dev != NULL: the batch is drawn in the
  * launch (arguments as mn_iqn_train_grad_sampled; idx_dev / taus_*_dev ignored); NULL: the given batch (as mn_iqn_train_grad).  params_local is
  * updated in place, grad_out receives the clipped gradient.  Bit-identical to mn_iqn_train_grad* + mn_iqn_train_adam(grad_scale = 1): those stay
  * for callers that put something between the two (the shared learner's all-reduce / exchange). */
@@ -428,11 +424,6 @@ int mn_iqn_train_step(const float *ring_states, const float *ring_next_states, c
                       const float *taus_local_dev, int64_t *idx_out, float *taus_out, float *params_local, const float *params_target,
                       float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq, int32_t *step_dev, int32_t batch,
                       int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2, double eps, double max_norm, void *stream);
-int mn_iqn_train_steps(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
-                       const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
-                       const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
-                       int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1, double beta2,
-                       double eps, double max_norm, void *stream);
 int64_t mn_iqn_train_workspace_floats(int32_t batch);
 /* Diagnostic: float index inside the workspace of a u32 counter -- local workgroups of one-launch steps that did not run on the XCD of the first
  * workgroup of their group (block index % 8) since mn_iqn_train_workspace_init (their partial-gradient rows go through memory instead of staying in the
@@ -503,12 +494,6 @@ int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ri
                            const float *params_target, float *workspace, float *grad_out, float *loss_out, float *exp_avg, float *exp_avg_sq,
                            int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                            double eps, double max_norm, float grad_scale, void *stream);
-/* ... n_steps of them in one persistent launch (all ranks call with the same n_steps); arguments as mn_iqn_train_steps */
-int mn_iqn_train_steps_xchg(mn_xchg *x, const float *ring_states, const float *ring_next_states, const int64_t *ring_actions, const float *ring_rewards,
-                            const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev, int64_t *idx_out, float *taus_out, float *params_local,
-                            const float *params_target, float *workspace, float *grad_out, float *losses_out, float *exp_avg, float *exp_avg_sq,
-                            int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, int32_t n_steps, double lr, double beta1,
-                            double beta2, double eps, double max_norm, float grad_scale, void *stream);
 int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
 int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
@@ -536,7 +521,7 @@ int mn_iqn_train_grad(const float *ring_states, const float *ring_next_states, c
  * if the ring was not written since the staging call (then the step is bit-identical to the unstaged one). */
 #define MN_TRAIN_USE_STAGED 1
 #define MN_TRAIN_STAGE_NEXT 2
-#define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step[_xchg]: the fused step -- reduction + clip + Adam inside the forward / backward launch (mn_iqn_train_steps* imply it) */
+#define MN_TRAIN_ONE_LAUNCH 4      /* mn_iqn_train_step[_xchg]: the fused step -- reduction + clip + Adam inside the forward / backward launch */
 #define MN_TRAIN_TEST_MISPLACE(k) ((k) << 4)   /* test hook, k = 1..3, with MN_TRAIN_ONE_LAUNCH: treat some workgroups as if they had landed on another XCD */
 int mn_iqn_train_grad_sampled(const float *ring_states, const float *ring_next_states, const int64_t *ring_actions,
                               const float *ring_rewards, const float *ring_dones, int64_t ring_size, uint64_t *rng_state_dev,

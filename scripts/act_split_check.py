@@ -1,5 +1,5 @@
 """Accuracy and speed of the acting-kernel variants against a float64 evaluation of the same network (MI355X).
-variant 0 = exact-f32 MFMA 16x16x4, 1 = exact-f32 32x32x2, 2 = split-f16 (three f16 MFMA products per f32 product)."""
+variant 0 = exact-f32 MFMA 16x16x4, 2 = split-f16 (three f16 MFMA products per f32 product)."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

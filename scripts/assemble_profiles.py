@@ -61,22 +61,13 @@ open(P + 'experiment_sweep.txt', 'w').write(("# %s: scripts/experiment_sweep.py 
 out = ("# %s: the gradient step by launch form (learner alone, batch 256 drawn in the launch, replay 100 000; MI355X, one box, one session).\n"
        "# (1) scripts/learner_bench.py 3000: wall clock over 3 000 back-to-back steps.  'mode 1' = every local workgroup computes its own target forward (the fallback of the in-launch TD hand-off).\n"
        "#     1 launch = iqn_train_fwdbwd<., FUSED> with the reduction + clip + Adam workgroups as its tail role; 2 = iqn_train_fwdbwd + iqn_grad_reduce_adam; 3 = + iqn_grad_reduce, iqn_adam (the RCCL form);\n"
-       "#     persistent = mn_iqn_train_steps: G steps per launch (iqn_train_fwdbwd<., true, MULTI>), bit-identical to G single steps (tests/test_iqn_gpu.py).\n") % RT
+       ) % RT
 out += body('learner_bench.txt').rstrip() + '\n\n'
 out += "# (2) rocprofv3 --kernel-trace --stats of scripts/learner_prof.py <form> (600 steps each; durations start to start)\n"
-for form, name in ((1, 'one launch per step'), (2, 'two launches per step'), (3, 'three launches per step'), (16, 'persistent 16-step launches')):
+for form, name in ((1, 'one launch per step'), (2, 'two launches per step'), (3, 'three launches per step')):
     rows = [l for l in body('prof_learner_%d_summary.txt' % form).split('\n') if 'iqn_' in l]
     out += '# -- %s\n' % name + '\n'.join(rows) + '\n'
-out += ("\n# (3) scripts/train_multi_phase_timing.py 16 100: 100 MHz stamps of the first local workgroup and target workgroup 0 over the last steps of a 16-step persistent launch (profiling build)\n")
-out += body('train_multi_phase_timing.txt').rstrip() + '\n'
-out += ("#\n# Reading (VERDICT r4 item 3: 'persistent multi-step launch, >= 35 k grad-steps/s' -- closed with numbers, target NOT met).  A step of the persistent launch costs what a\n"
-        "# single fused launch costs plus ~1 us: the launch boundary it removes (~2 us: compare 1 vs 2 launches) is replaced by the hand-off of the freshly written parameters -- 128 tail\n"
-        "# workgroups on 8 XCDs each publish 'my 256 parameters of step k are out' and 128 local workgroups wait for all of them (begins(k+1) - parameters out(k) = 1.5-1.9 us) -- and every\n"
-        "# step's weights have to be read past the L2 (sc1 loads: 'requests out' 5.2-5.3 us against 4.4 in the single launch).  Per step: inputs 5.3, forward 5.8, backward 9.1, row\n"
-        "# acknowledged 1.2, group share 5.0, tail 5.8 (target wg: tail begins -> parameters out: 23 us, of which it waits ~17 for the group rows).  The data dependence Adam(k) -> forward(k+1)\n"
-        "# leaves only the 5 us of inputs to overlap, and doing so changes either the summation order or the step semantics.  So single launches stay the default\n"
-        "# (IQNAgent.use_multi_step = False); the multi-step form is kept for hosts that cannot enqueue 16 launches per vector step, and is what bench.py reports as\n"
-        "# learner_only.fused_hip_g16 / also.train_cadence_multi_step.\n")
+out += ("#\n# (The persistent multi-step launch of round 5 -- 33.4 us per step against 32.4 for single fused launches, profiles/r05_train_step_launches.txt -- was removed in round 6.)\n")
 open(P + 'train_step_launches.txt', 'w').write(out)
 
 out = ("# %s: scripts/scale.sh on ONE MI355X (no multi-GPU node was available to the build).  c3 = configs[3] (independent learners), c4 = configs[4] (shared learner, CVaR 0.5, RCCL all-reduce),\n"

@@ -12,10 +12,9 @@ n = 100_000
 ag.memory.add_batch(torch.randn(n, 26, device=dev, generator=g), torch.randint(0, 9, (n,), device=dev, generator=g), torch.randn(n, device=dev, generator=g),
                     torch.randn(n, 26, device=dev, generator=g), (torch.rand(n, device=dev, generator=g) < 0.05).float())
 out = []
-for launches in (3, 2, 1, 16):
-    ag.use_multi_step = launches == 16
-    ag.two_launch_step, ag.one_launch_step = launches != 3, launches in (1, 16)
-    G = 16 if launches == 16 else 1
+for launches in (3, 2, 1):
+    ag.two_launch_step, ag.one_launch_step = launches != 3, launches == 1
+    G = 1
     for _ in range(20):
         ag.train_steps_from_memory(G) if G > 1 else ag.train_from_memory()
     torch.cuda.synchronize()

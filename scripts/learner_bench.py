@@ -33,21 +33,6 @@ for mode, launches in ((0, 1), (0, 2), (0, 3), (1, 1), (0, 1), (0, 2), (0, 3)):
     dt = time.perf_counter() - t0
     print(f"mode {mode}, {launches} launch(es) per step: {reps / dt:9.0f} grad-steps/s  ({1e6 * dt / reps:6.2f} us per step), loss {float(ag._fused.loss):.5f}", flush=True)
 _capi.lib().mn_iqn_train_set_mode(0)
-# persistent multi-step launches (mn_iqn_train_steps): G gradient steps per launch
-ag.two_launch_step, ag.one_launch_step, ag.use_multi_step = True, True, True
-for G in (2, 4, 16, 64):
-    ag._fused.losses = torch.zeros(max(G, 16), device=dev)
-    for _ in range(3):
-        ag.train_steps_from_memory(G)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    k = max(1, reps // G)
-    for _ in range(k):
-        ag.train_steps_from_memory(G)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f"persistent launch of {G:3d} steps: {k * G / dt:9.0f} grad-steps/s  ({1e6 * dt / (k * G):6.2f} us per step), timeouts {ag._fused.timeouts()}", flush=True)
-ag.use_multi_step = False
 ag.two_launch_step, ag.one_launch_step = True, False
 # the same gradient steps as captured hipGraphs of G steps each (IQNAgent.use_fused_graph)
 for G in (16, 64):

@@ -1,4 +1,4 @@
-"""For rocprofv3: 600 back-to-back gradient steps in one launch form (argv[1] = 3, 2, 1 launches per step, or 16 = persistent 16-step launches)."""
+"""For rocprofv3: 600 back-to-back gradient steps in one launch form (argv[1] = 3, 2, 1 launches per step)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -10,8 +10,7 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 n = 100_000
 ag.memory.add_batch(torch.randn(n, 26, device=dev, generator=g), torch.randint(0, 9, (n,), device=dev, generator=g), torch.randn(n, device=dev, generator=g),
                     torch.randn(n, 26, device=dev, generator=g), (torch.rand(n, device=dev, generator=g) < 0.05).float())
-ag.use_multi_step = form == 16
-ag.two_launch_step, ag.one_launch_step = form != 3, form in (1, 16)
-for _ in range(600 // (16 if form == 16 else 1)):
-    ag.train_steps_from_memory(16) if form == 16 else ag.train_from_memory()
+ag.two_launch_step, ag.one_launch_step = form != 3, form == 1
+for _ in range(600):
+    ag.train_from_memory()
 torch.cuda.synchronize()

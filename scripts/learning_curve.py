@@ -21,7 +21,6 @@ ap.add_argument("--envs", type=int, default=65536)
 ap.add_argument("--target-mult", type=float, default=1.0)
 ap.add_argument("--eps-floor", type=float, default=0.05)
 ap.add_argument("--shared-taus", action="store_true")
-ap.add_argument("--multi-step", action="store_true")
 ap.add_argument("--replay", type=int, default=100_000, help="replay ring rows (the bench keeps BASELINE's 100 000)")
 ap.add_argument("--grad-steps", type=int, default=None, help="gradient steps per vector step (default: 16 per 65 536 envs)")
 ap.add_argument("--tag", default="", help="label printed in the header line")
@@ -35,13 +34,6 @@ seeds = [int(x) for x in args.seed_list.split(",")] if args.seed_list else list(
 print(f"# {args.tag + ': ' if args.tag else ''}{len(seeds)} seeds {seeds}; {args.envs} envs, replay ring {args.replay} rows, {args.evals} evaluation points, target copy x{args.target_mult}, eps floor {args.eps_floor}, "
       f"acting taus {'shared per launch' if args.shared_taus else 'per env'}", flush=True)
 curves, finals, bests, walls = [], [], [], []
-if args.multi_step:
-    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
-    _init = IQNAgent.__init__
-    def _patched(self, *a, **k):
-        _init(self, *a, **k)
-        self.use_multi_step = True
-    IQNAgent.__init__ = _patched
 for sd in seeds:
     with tempfile.TemporaryDirectory() as tmp:
         params = dict(seed=sd, total_timesteps=3_000_000, eval_freq=10_000, save_dir=tmp, training_time="run")

@@ -1,14 +1,13 @@
 # One round's measurement session (run on the GPU box from the repo root; outputs under gpurun_out/$MEASURE_DIR, summaries copied into profiles/ by
 # scripts/assemble_profiles.py): the bench line; rocprofv3 --kernel-trace --stats of the headline loop (per-env and launch-shared taus) and of the
 # training cadence; PMC passes, one counter per run (HBM traffic of the env / act kernels, MFMA-busy cycles, instruction mix); the learner alone by
-# launch form incl. the persistent multi-step launch and its phase stamps; the reset kernel against the number of resets; configs[3] / configs[4]
+# launch form; the reset kernel against the number of resets; configs[3] / configs[4]
 # lines at N = 1 and with two ranks on the one GPU; the experiment sweep.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${MEASURE_DIR:-m5}; mkdir -p $O; rm -f $O/pmc_summary.txt $O/pmc_shared_summary.txt
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --shared-taus --cpu-steps 0 --no-also --no-learner-only > $O/bench_shared_taus.json 2> $O/bench_shared_taus.err
 python scripts/learner_bench.py 3000 > $O/learner_bench.txt 2>&1
-python scripts/train_multi_phase_timing.py 16 100 > $O/train_multi_phase_timing.txt 2>&1
 python scripts/reset_scaling.py f64 > $O/reset_scaling.txt 2>&1
 python scripts/reset_under_act_ab.py 200 > $O/reset_under_act_ab.txt 2>&1
 python scripts/experiment_sweep.py > $O/experiment_sweep.txt 2>&1
@@ -24,7 +23,7 @@ prof loop --steps 100 --warmup 20
 prof loop_reset_in_front --steps 100 --warmup 20 --reset-in-front
 prof shared --shared-taus --steps 100 --warmup 20
 prof g16 --steps 60 --warmup 10 --update-every 1 --grad-steps 16 --eps 0.05
-for form in 1 2 3 16; do
+for form in 1 2 3; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_learner_$form -- python $R/scripts/learner_prof.py $form > $O/prof_learner_$form.log 2>&1
   python $R/scripts/prof_summary.py $(find $O/prof_learner_$form -name "*kernel_stats.csv" | head -1) 6 > $O/prof_learner_${form}_summary.txt
 done

@@ -34,7 +34,7 @@ grad = torch.zeros(P, device=dev); m = torch.zeros(P, device=dev); v = torch.zer
 step = torch.zeros(1, dtype=torch.int32, device=dev); loss = torch.zeros(1, device=dev)
 rng = torch.tensor([12345, 0], dtype=torch.int64, device=dev)
 p = lambda t: C.c_void_p(t.data_ptr())
-flags = 3 | (4 if launches == 1 else 0) | int(os.environ.get("MN_STEP_FLAGS", "0"))      # 8 = ungrouped rows (MN_TRAIN_UNGROUPED)
+flags = 3 | (4 if launches == 1 else 0) | int(os.environ.get("MN_STEP_FLAGS", "0"))      # (16 / 32 / 48: the XCD-misplacement test hooks)
 acc1 = np.zeros((2, 32)); acc3 = np.zeros((3, 8)); accw = np.zeros((256, 4)); cnt = 0
 for it in range(reps + 20):
     rc = L.mn_iqn_train_step(p(ring[0]), p(ring[1]), p(ring[2]), p(ring[3]), p(ring[4]), C.c_int64(n), p(rng), None, None, None, None, None,

@@ -154,11 +154,10 @@ def test_iqn_ctx_c_abi_errors(torch):
 
 
 @pytest.mark.parametrize("weights", ["seeded", "pretrained"])
-def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
-    """The acting kernel exists in three forms (`mn_iqn_set_variant`: 2 = split-f16 MFMA, the default; 0 = exact-f32 16x16x4;
-    1 = the exact-f32 32x32x2 re-layout; 3 = the split-f16 kernel on 32x32x16 tiles).  Same network, float32-class results in all: each matches eager PyTorch to float32
-    rounding on ragged batch sizes, they match each other, and they pick the same greedy action wherever the top-2 gap is
-    above the rounding noise."""
+def test_both_act_kernels_agree_with_pytorch(torch, weights):
+    """The acting kernel exists in two forms (`mn_iqn_set_variant`: 2 = split-f16 MFMA, the default; 0 = exact-f32 16x16x4).  Same network, float32-class
+    results in both: each matches eager PyTorch to float32 rounding on ragged batch sizes, they match each other, and they pick the same greedy action
+    wherever the top-2 gap is above the rounding noise.  (Variants 1 and 3, the 32x32 re-layouts measured slower in rounds 2 / 4, were removed: refused.)"""
     from distributional_rl_navigation_amd.iqn.fused_act import act_context, fused_act
     from distributional_rl_navigation_amd.iqn.model import ObsEncoder
     dev = "cuda:0"
@@ -172,22 +171,22 @@ def test_both_mfma_shapes_agree_with_pytorch(torch, weights):
         with torch.no_grad():
             ref = net.get_qvals(obs, 1.0, taus=taus)
         out = {}
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 2):
             ctx.set_variant(variant)
             out[variant] = fused_act(net, obs, 0.0, 1.0, taus=taus, want_qvals=True)
         ctx.set_variant(ctx.DEFAULT_VARIANT)
         scale = max(1.0, float(ref.abs().max()))
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 2):
             a, q = out[variant]
             assert float((q - ref).abs().max()) < 3e-5 * scale, (variant, n)
             top2 = ref.topk(2, dim=1).values
             clear = (top2[:, 0] - top2[:, 1]) > 1e-3 * scale
             assert torch.equal(a.long()[clear], ref.argmax(dim=1)[clear])
-        assert float((out[0][1] - out[1][1]).abs().max()) < 3e-5 * scale
         assert float((out[0][1] - out[2][1]).abs().max()) < 3e-5 * scale
-        assert float((out[0][1] - out[3][1]).abs().max()) < 3e-5 * scale
-    # exploration epilogue of the 32x32x2 kernel: same rule as the default kernel (greedy iff u > eps)
-    ctx.set_variant(1)
+    # exploration epilogue of the exact-f32 kernel: same rule as the default kernel (greedy iff u > eps)
+    from distributional_rl_navigation_amd import _capi
+    assert _capi.lib().mn_iqn_set_variant(ctx.h, 1) != 0 and _capi.lib().mn_iqn_set_variant(ctx.h, 3) != 0
+    ctx.set_variant(0)
     n = 20000
     obs = torch.randn(n, 26, device=dev, generator=g) * 4.0; taus = torch.rand(n, 32, device=dev, generator=g)
     g2 = torch.Generator(device=dev); g2.manual_seed(1)

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SPLIT, EXACT, SPLIT32 = 2, 0, 3
+SPLIT, EXACT = 2, 0
 
 
 @pytest.fixture(scope="module")
@@ -102,20 +102,6 @@ def test_range_scaling_is_safe_and_accurate(torch, case):
     row_err = ((e[SPLIT]["q"].double() - ref).abs().max(dim=1).values / row_scale)
     row_err0 = ((e[EXACT]["q"].double() - ref).abs().max(dim=1).values / row_scale)
     assert float(row_err.max()) < 2.0 * float(row_err0.max()) + 1e-6, (case, float(row_err.max()), float(row_err0.max()))
-
-
-def test_split_kernel_on_32x32x16_tiles_is_float32_class_too(torch):
-    """`mn_iqn_set_variant(ctx, 3)`: the same arithmetic on v_mfma_f32_32x32x16_f16 tiles (output layer on the matrix pipe as well);
-    opt-in -- measured 4 % slower than the default -- but held to the same accuracy bar, incl. the range cases' worst one."""
-    for which, scale in (("seeded", 5.0), ("pretrained", 5.0), ("seeded", 5e6)):
-        net = _nets(torch, which)
-        obs, taus = _inputs(torch, 8192 + 7, scale)
-        ref, e = _errors(torch, net, obs, taus, variants=(EXACT, SPLIT32))
-        assert bool(torch.isfinite(e[SPLIT32]["q"]).all())
-        assert e[SPLIT32]["rms"] < 1.25 * e[EXACT]["rms"] + 2e-8 and e[SPLIT32]["max"] < 1.5 * e[EXACT]["max"] + 1e-7, (which, scale, e)
-        top2 = ref.topk(2, dim=1).values
-        clear = (top2[:, 0] - top2[:, 1]) > 1e-5 * float(ref.abs().max())
-        assert torch.equal(e[SPLIT32]["a"].long()[clear], ref.argmax(dim=1)[clear])
 
 
 def test_results_do_not_depend_on_batch_position_or_size(torch):

@@ -291,11 +291,11 @@ def test_iqn_c_abi_argument_checks(torch):
     import ctypes as C
     from distributional_rl_navigation_amd import _capi
     L = _capi.lib()
-    # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + two sets (step parity) of 128 x 16 8-byte hand-off granules + epoch / tickets /
+    # 128 partial rows of 35 788 floats + 128 loss partials + 280 norm partials + 128 x 16 8-byte hand-off granules + epoch / tickets /
     # staging tag / magic word / status word (16 words) + the 280 tagged norm partials of the fused reduction + Adam launch; in brackets the fused step's 128 8-byte
-    # row-complete words, the 128 buddy words, 8 x 64 XCD-local row-complete words, 128 tagged loss partials, 128 "which XCD" words, the eight XCD group rows as 8-byte
-    # granules and the 256 "parameters ready" words of a multi-step launch; + the staged next batch (256 slots of 72 floats)
-    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * (2 * 128 * 16) + 16 + 2 * 280 + (2 * 128 + 128 + 512 + 2 * 128 + 2 * 128 + 16 * 35788 + 2 * 256) + 256 * 72
+    # row-complete words, the 128 buddy words, 8 x 64 XCD-local row-complete words, 128 tagged loss partials, 128 "which XCD" words and the eight XCD group rows as 8-byte
+    # granules; + the staged next batch (256 slots of 72 floats)
+    assert L.mn_iqn_train_workspace_floats(256) == 128 * 35788 + 128 + 280 + 2 * 128 * 16 + 16 + 2 * 280 + (2 * 128 + 128 + 512 + 2 * 128 + 2 * 128 + 16 * 35788) + 256 * 72
     assert L.mn_iqn_train_workspace_floats(255) == -1 and L.mn_iqn_train_workspace_floats(0) == -1
     dev = "cuda:0"
     st = torch.zeros(2, dtype=torch.int64, device=dev); idx = torch.zeros(2048, dtype=torch.int64, device=dev)
@@ -598,7 +598,6 @@ def test_one_and_two_launch_steps_equal_the_three_launch_step_bitwise(torch):
     for two, one, misplace, mode in cases:
         ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=2048, device=dev, seed=11)
         ag.two_launch_step, ag.one_launch_step, ag._test_misplace = two, one, misplace
-        ag.use_multi_step = False      # (this test: single steps; multi-step launches have their own)
         _capi.lib().mn_iqn_train_set_mode(mode)      # 1: every workgroup computes its own TD targets, no target role in the launch
         g = torch.Generator(device=dev); g.manual_seed(5)
         ag.memory.add_batch(*_random_batch(torch, 2048, g))
@@ -657,45 +656,33 @@ def test_launch_plan_follows_the_device_size_and_small_devices_fall_back_bitwise
             assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("batch,misplace", [(256, 0), (256, 1), (256, 3), (32, 0), (64, 2), (128, 0), (100, 0), (512, 0)])
-def test_multi_step_launch_equals_single_steps_bitwise(torch, batch, misplace):
-    """`mn_iqn_train_steps` (round 5): the G gradient steps of a training event as ONE persistent launch -- target workgroups that are also the reduction + Adam
-    blocks, step k + 1 starting when step k's parameters are written (through, behind a drained flag) and reading its batch straight from the ring, TD targets one
-    step ahead in two sets of granules -- against G single fused steps and against the three-launch path: every step's loss, the parameters, both moments, the
-    last clipped gradient, the Adam step and the generator state bit-identical, over events of 16 / 5 / 1 / 16 steps with ring writes in between (so that staged
-    first batches are used and refused), at batch 256 (also with workgroups pretending to sit on another XCD), 32 / 64 / 128 (extra reduction + Adam workgroups)
-    and 100 / 512 (no fused form: the library runs the steps one after the other).  No bounded wait ran out."""
+@pytest.mark.parametrize("batch,misplace", [(256, 0), (256, 1), (64, 2), (100, 0)])
+def test_training_events_fused_equals_three_launches_bitwise(torch, batch, misplace):
+    """Training events as the batched loop runs them (`train_steps_from_memory`: G gradient steps back to back, the first from the batch the previous event's last
+    step staged -- used while the ring has not moved, refused after ring writes): the fused one-launch step against the three-launch path over events of
+    16 / 16 / 5 / 1 / 16 / 3 steps with ring writes in between -- every event's last loss, the parameters, both moments, the last clipped gradient, the Adam step
+    and the generator state bit-identical, also with workgroups pretending to sit on another XCD and at batch 100 (no fused form: two launches).  No bounded wait ran out."""
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
     dev = "cuda:0"
     runs = []
-    for form in ("multi", "single", "three"):
+    for form in ("single", "three"):
         ag = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=2048, device=dev, seed=11)
-        ag.use_multi_step, ag.two_launch_step, ag.one_launch_step, ag._test_misplace = form == "multi", form != "three", True, misplace
+        ag.two_launch_step, ag.one_launch_step, ag._test_misplace = form != "three", True, misplace
         g = torch.Generator(device=dev); g.manual_seed(5)
         ag.memory.add_batch(*_random_batch(torch, 2048, g))
         losses = []
         for ev, G in enumerate((16, 16, 5, 1, 16, 3)):
             if ev in (2, 4):
                 ag.memory.add_batch(*_random_batch(torch, 300, g))      # the ring moves: the batch the previous event staged must not be used
-            last = float(ag.train_steps_from_memory(G))
-            ft = ag._fused
-            if form == "multi" and G > 1:
-                ls = [float(x) for x in ft.losses[:G]]
-                assert ls[-1] == last
-                losses += ls
-            else:
-                losses.append(last)
-        assert ft.timeouts() == 0 and ft.xcd_misplaced(batch) == (0 if misplace == 0 or form == "three" else ft.xcd_misplaced(batch))
+            losses.append(float(ag.train_steps_from_memory(G)))
+        ft = ag._fused
+        assert ft.timeouts() == 0
         runs.append((losses, ft.local.clone(), ft.grad.clone(), ft.exp_avg.clone(), ft.exp_avg_sq.clone(), int(ft.step_dev), ft.rng_state.clone(), ag.grad_steps))
-    multi, single, three = runs
-    assert all(np.isfinite(multi[0])) and len(multi[0]) == 16 + 16 + 5 + 1 + 16 + 3
-    # the single-step runs report the last loss of every event: the events' ends within the multi-step run's list
-    ends = np.cumsum([16, 16, 5, 1, 16, 3]) - 1
-    assert [multi[0][e] for e in ends] == single[0] == three[0]
-    for r in (single, three):
-        for x, y in zip(multi[1:5], r[1:5]):
-            assert torch.equal(x, y)
-        assert multi[5] == r[5] == 57 and torch.equal(multi[6], r[6]) and multi[7] == r[7] == 57
+    single, three = runs
+    assert all(np.isfinite(single[0])) and single[0] == three[0]
+    for x, y in zip(single[1:5], three[1:5]):
+        assert torch.equal(x, y)
+    assert single[5] == three[5] == 57 and torch.equal(single[6], three[6]) and single[7] == three[7] == 57
 
 
 @pytest.mark.parametrize("batch", [16, 48, 100, 128, 384, 512, 1024])

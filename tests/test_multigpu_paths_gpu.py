@@ -231,10 +231,10 @@ from distributional_rl_navigation_amd import _capi
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 rank, port, out, mode = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[5]
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
-_capi.lib().mn_iqn_train_set_cu_limit(120)      # two ranks share this GPU: each plans its (persistent) launches for half of it
+_capi.lib().mn_iqn_train_set_cu_limit(120)      # two ranks share this GPU: each plans its fused launches for half of it
 agent = IQNAgent(26, 9, BATCH_SIZE=32, BUFFER_SIZE=512, device="cuda:0", seed=3, distributed=True, rank=rank)
 agent.exchange = "collective" if mode == "collective" else "mailbox"
-agent.one_launch_step, agent.use_multi_step = True, mode == "multi"
+agent.one_launch_step = True
 agent.memory.add_batch(*_batch(torch, 100 + rank, 512, "cuda:0"))      # every rank its own replay ring (and its own sampling stream: IQNAgent(rank=...))
 losses = []
 for ev, G in enumerate((8, 8, 3, 1, 8)):
@@ -253,13 +253,12 @@ dist.destroy_process_group()
 """
 
 
-def test_multi_step_launch_with_the_mailbox_exchange_two_ranks_bitwise(torch, tmp_path):
-    """A shared learner's training events as persistent multi-step launches (`mn_iqn_train_steps_xchg`): two ranks (two processes on this GPU), each sampling its own
+def test_training_events_with_the_mailbox_exchange_two_ranks_bitwise(torch, tmp_path):
+    """A shared learner's training events with the exchange inside every fused step (`mn_iqn_train_step_xchg`): two ranks (two processes on this GPU), each sampling its own
     replay ring, 28 gradient steps in events of 8 / 8 / 3 / 1 / 8 -- every step's reduction + Adam blocks publish into and gather from the two ranks' mailboxes inside
-    the launch.  Against the same events as single fused steps with the exchange inside each, and against the all-reduce path (bucket over gloo): parameters and
-    event losses bit-identical, ranks bit-identical to each other, no bounded wait ran out."""
+    the launch.  Against the all-reduce path (bucket over gloo): parameters and event losses bit-identical, ranks bit-identical to each other, no bounded wait ran out."""
     res = {}
-    for mode in ("collective", "single", "multi"):
+    for mode in ("collective", "single"):
         out = str(tmp_path / f"{mode}.pt"); port = str(_free_port())
         script = str(tmp_path / "ring_worker.py")
         with open(script, "w") as f:
@@ -272,8 +271,8 @@ def test_multi_step_launch_with_the_mailbox_exchange_two_ranks_bitwise(torch, tm
     for mode, r in res.items():
         assert r["same"] and r["timeouts"] == 0 and r["steps"] == 28, (mode, r["same"], r["timeouts"], r["steps"])
         assert all(np.isfinite(r["losses"]))
-    assert res["single"]["launches"] == 1 and res["multi"]["launches"] == 1 and res["collective"]["launches"] == 3
-    for mode in ("single", "multi"):
+    assert res["single"]["launches"] == 1 and res["collective"]["launches"] == 3
+    for mode in ("single",):
         assert res[mode]["losses"] == res["collective"]["losses"]
         assert torch.equal(res[mode]["params"], res["collective"]["params"])
 
@@ -285,13 +284,12 @@ def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graph
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         runs = []
-        for distributed, graphed, one, two, multi in ((False, False, False, True, False), (True, False, False, True, False), (True, True, False, True, False),
-                                                      (True, False, True, True, False), (True, True, True, True, False), (True, False, False, False, False),
-                                                      (True, True, False, False, False), (True, False, True, True, True), (False, False, True, True, True)):
+        for distributed, graphed, one, two in ((False, False, False, True), (True, False, False, True), (True, True, False, True),
+                                               (True, False, True, True), (True, True, True, True), (True, False, False, False), (True, True, False, False)):
             ag = IQNAgent(26, 9, BATCH_SIZE=64, BUFFER_SIZE=256, device=dev, seed=5, distributed=distributed)
             ag.exchange = "mailbox"
             ag.one_launch_step, ag.two_launch_step = one, two      # the exchange inside ONE launch / inside the reduction + Adam launch / as its own launch
-            ag.use_fused_graph, ag.use_multi_step = graphed, multi      # multi: the 8 steps of an event as ONE persistent launch, the exchange inside every step of it
+            ag.use_fused_graph = graphed
             ag.memory.add_batch(*_batch(torch, 7, 300, dev))
             losses = [float(ag.train_steps_from_memory(8)) for _ in range(3)]
             runs.append((losses, ag._fused.local.clone(), ag._fused.exp_avg_sq.clone(), int(ag._fused.step_dev)))
