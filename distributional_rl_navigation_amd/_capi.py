@@ -114,6 +114,7 @@ SIGNATURES = [
     ("mn_iqn_train_step_xchg", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float,
                                          _i32, _dbl, _dbl, _dbl, _dbl, _dbl, C.c_float, _vp]),
     ("mn_xchg_status", C.c_int, [_vp, _pi32]),
+    ("mn_xchg_last_error", C.c_char_p, [_vp]),
     ("mn_xchg_destroy", C.c_int, [_vp]),
     ("mn_probe_mfma_clock", C.c_int, [C.c_double, _pd, _vp]),
     ("mn_iqn_refresh", C.c_int, [_vp, C.POINTER(C.c_void_p), _vp]),

@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -2044,6 +2045,7 @@ struct mn_xchg {
     int kind = 0;                              // how `own` was allocated: 2 = uncached, 1 = fine-grained, 0 = plain hipMalloc (see mn_xchg_create)
     uint64_t bound = 200000000ull;             // ticks of the 100 MHz counter a gather waits for a peer's granules (mn_xchg_set_timeout_ms)
     XchgArgs *dev_args = nullptr;              // the record above in device memory, as the fused kernels read it (xchg_sync)
+    char err[384] = "";                        // mn_xchg_last_error
 };
 
 struct AdamArgs {      // non-null: the step also performs clip + Adam (mn_iqn_train_step*)
@@ -2302,6 +2304,7 @@ extern "C" int mn_xchg_create(int32_t rank, int32_t world, mn_xchg **out) {
 }
 
 extern "C" int mn_xchg_memory_kind(mn_xchg *x) { return x ? x->kind : -1; }
+extern "C" const char *mn_xchg_last_error(const mn_xchg *x) { return x ? x->err : "mn_xchg: NULL handle"; }
 
 // How long a gather waits for a peer's granules before it gives up (status word raised, the block's update skipped).  Default: 30 s when there are peers, 2 s alone.
 extern "C" int mn_xchg_set_timeout_ms(mn_xchg *x, int64_t ms) {
@@ -2314,7 +2317,11 @@ extern "C" int mn_xchg_export(mn_xchg *x, void *handle_out) {
     if (!x || !handle_out) return MN_ERR_INVALID;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "mn_xchg_export / _import exchange 64-byte handles");
     hipIpcMemHandle_t h;
-    if (hipIpcGetMemHandle(&h, (void *)x->own) != hipSuccess) return MN_ERR_HIP;
+    if (const hipError_t e = hipIpcGetMemHandle(&h, (void *)x->own); e != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(x->err, sizeof(x->err), "hipIpcGetMemHandle of rank %d's mailbox failed: %s (memory kind %d; is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", x->rank, hipGetErrorString(e), x->kind);
+        return MN_ERR_PEER;
+    }
     memcpy(handle_out, &h, sizeof(h));
     return MN_OK;
 }
@@ -2324,7 +2331,12 @@ extern "C" int mn_xchg_import(mn_xchg *x, int32_t peer_rank, const void *handle)
     hipIpcMemHandle_t h;
     memcpy(&h, handle, sizeof(h));
     void *p = nullptr;
-    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MN_ERR_HIP;
+    if (const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess); e != hipSuccess || !p) {
+        (void)hipGetLastError();
+        snprintf(x->err, sizeof(x->err), "hipIpcOpenMemHandle of rank %d's mailbox on device %d failed: %s -- the exchange needs IPC between the ranks' processes and peer "
+                 "access between their devices; use the RCCL exchange (--exchange collective) on this node", peer_rank, x->device, hipGetErrorString(e));
+        return MN_ERR_PEER;
+    }
     x->peer[peer_rank] = (const gu64 *)p;
     x->opened[peer_rank] = true;
     return xchg_sync(x);

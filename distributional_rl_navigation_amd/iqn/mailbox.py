@@ -34,14 +34,14 @@ class MailboxExchange:
             if self.world > 1:
                 rc = L.mn_xchg_export(h, mine)
                 if rc:
-                    raise _capi.MarineNavHipError(f"mn_xchg_export failed ({rc}): hipIpcGetMemHandle (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)")
+                    raise _capi.MarineNavHipError(f"mn_xchg_export failed ({rc}): {L.mn_xchg_last_error(h).decode()}")
                 handles = [None] * self.world
                 dist.all_gather_object(handles, bytes(mine.raw), group=group)
                 for r, hb in enumerate(handles):
                     if r != self.rank:
                         rc = L.mn_xchg_import(h, r, C.create_string_buffer(hb, 64))
                         if rc:
-                            raise _capi.MarineNavHipError(f"mn_xchg_import of rank {r}'s mailbox failed ({rc})")
+                            raise _capi.MarineNavHipError(f"mn_xchg_import of rank {r}'s mailbox failed ({rc}): {L.mn_xchg_last_error(h).decode()}")
         self._attached = set()
         ms = os.environ.get("MN_XCHG_TIMEOUT_MS")      # how long a gather waits for a peer (default: 30 s with peers, 2 s alone)
         if ms:

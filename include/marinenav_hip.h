@@ -45,7 +45,9 @@ typedef enum mn_status {
     MN_ERR_INVALID = -1,   /* bad argument */
     MN_ERR_HIP = -2,       /* a HIP runtime call failed (text in mn_last_error) */
     MN_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
-    MN_ERR_ALLOC = -4
+    MN_ERR_ALLOC = -4,
+    MN_ERR_PEER = -5       /* mn_xchg_export / mn_xchg_import: the runtime refused to export this rank's mailbox or to map a peer's (no IPC between the processes --
+                              HSA_ENABLE_IPC_MODE_LEGACY=0 missing? -- or no peer access between the devices); text in mn_xchg_last_error */
 } mn_status;
 
 /* info codes written by mn_step; strings at marinenav_env.py:243,246,250,254,257 */
@@ -495,6 +497,8 @@ int mn_iqn_train_step_xchg(mn_xchg *x, const float *ring_states, const float *ri
                            int32_t *step_dev, int32_t batch, int32_t num_taus, float gamma, int32_t flags, double lr, double beta1, double beta2,
                            double eps, double max_norm, float grad_scale, void *stream);
 int mn_xchg_status(mn_xchg *x, int32_t *timeouts);
+/* Text of the last failure of an mn_xchg_* call on this exchange ("" if none; valid until the next call on it). */
+const char *mn_xchg_last_error(const mn_xchg *x);
 int mn_xchg_destroy(mn_xchg *x);
 /* ReplayBuffer.sample (replay_buffer.py:42-47, random.sample: `batch` DISTINCT uniform rows of [0, ring_size)) -> idx_out
  * [batch] i64, plus n_taus_total uniform [0,1) floats -> taus_out (the step's tau draws, model.py:149; may be 0).  Slot k reads

@@ -24,11 +24,19 @@ for N in 1 2 4 8; do
     if [ "$N" -eq 1 ]; then python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-steps 0 --no-also --no-learner-only "$@" > "$OUT/${name}_$N.json" 2> "$OUT/${name}_$N.err"
     else python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$N" --ranks-per-gpu "$RPG" --steps 200 --warmup 20 --cpu-steps 0 --no-also --no-learner-only "$@" > "$OUT/${name}_$N.json" 2> "$OUT/${name}_$N.err"; fi
     PORT=$((PORT + 1))
-    python - "$OUT/${name}_$N.json" "$name" <<'PY'
+    python - "$OUT/${name}_$N.json" "$name" "$N" <<'PY'
 import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(f"{sys.argv[2]:4s} N={d['n_gpus']}: {d['value'] / 1e6:8.1f} M env steps/s  {d['ms_per_step']:.4f} ms/step  grad-steps/s {d['grad_steps_per_sec']:9.1f}  "
-      f"all_reduce_ms {d.get('all_reduce_ms')}  timeouts {d.get('timeouts')}  act frac_algorithmic {d['roofline'].get('frac_algorithmic')}  env-step HBM frac {d['roofline_env_step']['frac']:.3f}")
+try:      # (a leg that failed must not take the summary of the others with it)
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(f"{sys.argv[2]:4s} N={d['n_gpus']}: {d['value'] / 1e6:8.1f} M env steps/s  {d['ms_per_step']:.4f} ms/step  grad-steps/s {d['grad_steps_per_sec']:9.1f}  "
+          f"all_reduce_ms {d.get('all_reduce_ms')}  timeouts {d.get('timeouts')}  act launch_ms {d['roofline'].get('launch_ms')}  act frac_algorithmic {d['roofline'].get('frac_algorithmic')}  env-step HBM frac {d['roofline_env_step']['frac']:.3f}")
+except Exception as e:
+    err = sys.argv[1][:-5] + ".err"
+    try:
+        last = [l for l in open(err).read().strip().splitlines() if l.strip()][-1][:200]
+    except Exception:
+        last = "no stderr"
+    print(f"{sys.argv[2]:4s} N={sys.argv[3]}: FAILED ({type(e).__name__}); last line of {err}: {last}")
 PY
   }
   run c3

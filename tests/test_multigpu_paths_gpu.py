@@ -277,6 +277,24 @@ def test_training_events_with_the_mailbox_exchange_two_ranks_bitwise(torch, tmp_
         assert torch.equal(res[mode]["params"], res["collective"]["params"])
 
 
+def test_mailbox_import_that_the_runtime_refuses_is_a_clear_status(torch):
+    """A peer's mailbox that cannot be mapped (here: a handle that is not one) is MN_ERR_PEER with a text that names the remedy -- not a bare HIP error code."""
+    import ctypes as C
+    from distributional_rl_navigation_amd import _capi
+    L = _capi.lib()
+    x = C.c_void_p()
+    assert L.mn_xchg_create(0, 2, C.byref(x)) == 0
+    try:
+        assert L.mn_xchg_last_error(x) == b""
+        rc = L.mn_xchg_import(x, 1, C.create_string_buffer(b"\x00" * 64, 64))
+        assert rc == -5, rc                                                    # MN_ERR_PEER
+        msg = L.mn_xchg_last_error(x).decode()
+        assert "hipIpcOpenMemHandle" in msg and "rank 1" in msg and "--exchange collective" in msg, msg
+        assert L.mn_xchg_import(x, 0, C.create_string_buffer(b"\x00" * 64, 64)) == -1      # own rank: MN_ERR_INVALID as before
+    finally:
+        assert L.mn_xchg_destroy(x) == 0
+
+
 def test_mailbox_exchange_world_size_1_is_bitwise_the_plain_step_eager_and_graphed(torch):
     import torch.distributed as dist
     from distributional_rl_navigation_amd.iqn.agent import IQNAgent
