@@ -61,8 +61,8 @@ ACT_SHARED_MFMA_FLOP = 216 * 16384
 F32_MFMA_PEAK_TFLOPS = 157.3                 # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction; 65 536 envs, 8 cores / 10 obstacles).  Not measured live.
-PMC_TRAFFIC_MB = {"step_append_f64": 63.5, "step_append_mixed": 51.5, "step_mixed": 30.0, "act_split": 24.6, "act_exact": 24.8, "reset_f64": 3.2,
-                  "source": "profiles/r05_full_loop_kernel_stats.txt (float64 / split-f16 rows; the others r02-r04)"}
+PMC_TRAFFIC_MB = {"step_append_f64": 63.5, "act_split": 24.6, "reset_f64": 3.2,
+                  "source": "profiles/r05_full_loop_kernel_stats.txt (scripts/assemble_profiles.py refuses a constant that disagrees with the round's profile)"}
 # mn_reset_kernel, algorithmic bytes per episode start: 4 B x the MT19937 words a reset consumes on average (oracle, 10 000 resets per world size: 294 / 179 / 138
 # words at (8, 10, 40 m) / (8, 5, 25 m) / (4, 6, 30 m)) + what it writes: cores nc x 24 B + obstacles no x 24 B + the fixed-point copy (nc + no) x 12 B + pose / start /
 # goal / initial state 112 B + counters 8 B + first observation 104 B
@@ -695,7 +695,7 @@ def main():
             ghz = sum(clocks) / len(clocks) if clocks else None
             out["roofline"] = {
                 "kernel": kern, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "frac_algorithmic": alg_tf / peak,
-                "traffic": None, "traffic_mb_profiled": PMC_TRAFFIC_MB["act_split" if args.act_variant == 2 else "act_exact"] if n == 65536 else None,
+                "traffic": None, "traffic_mb_profiled": PMC_TRAFFIC_MB.get("act_split") if (args.act_variant == 2 and n == 65536 and not args.shared_taus) else None,
                 "launch_ms": act_ms, "launches_timed": act_launches, "env_steps_per_launch": n,
                 "clock_ghz": ghz, "kilocycles": act_ms * 1e-3 * ghz * 1e6 if ghz else None,
             }

@@ -99,7 +99,7 @@ def plan_cadence(total_timesteps, eval_freq, n_envs_total, batch, ref_batch=32, 
 
 def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, replay=100_000, verbose=True,
               grad_steps=None, torch_train=False, total_grad_steps=None, n_evals=None, cvar=1.0, precision="f64",
-              exchange="collective", shared_taus=False, target_sync_mult=1.0, final_eps=0.05, eval_adaptive=True):
+              exchange="collective", shared_taus=False, target_sync_mult=1.0, final_eps=0.05, eval_adaptive=True, n_step=1):
     """train_IQN_model.py:74-121 on the vector env.  `params` is one trial of the reference's config grid
     (seed, total_timesteps, eval_freq, save_dir); see `plan_cadence` for how its env-step cadences map to vector steps.
     `precision`: the env kernels' arithmetic.  "f64" (default: every float32 output within 1e-5 of the reference, no
@@ -108,7 +108,8 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
     `shared_taus`: acting draws its 32 quantile fractions once per act launch instead of once per env (opt-in: a different random variable from the
     reference's per-call draw, model.py:149; A/B on learning in profiles/; the learner's taus are untouched).
     `target_sync_mult`, `final_eps`: study knobs (scripts/learning_curve.py) -- the target network is copied every target_sync_mult x the planned number of gradient
-    steps; the exploration floor (agent.py: 0.05).  `eval_adaptive` = False skips the adaptive-CVaR evaluation at the evaluation points (the reference runs both)."""
+    steps; the exploration floor (agent.py: 0.05); `n_step`: the agent's n-step returns (agent.py:12-29; the reference's scripts use 1; > 1 takes the step + append launch pair
+    instead of the fused mn_step_append).  `eval_adaptive` = False skips the adaptive-CVaR evaluation at the evaluation points (the reference runs both)."""
     import torch
     from .iqn.agent import IQNAgent
     from .marinenav_env.vec_env import VecMarineNavEnv
@@ -144,7 +145,7 @@ def run_trial(device, params, n_envs, rank=0, world=1, shared=False, batch=256, 
             json.dump(eval_config, f)
     eval_env = VecMarineNavEnv(len(eval_config), device=device, precision=precision) if writer else None
 
-    agent = IQNAgent(26, 9, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
+    agent = IQNAgent(26, 9, n_step=n_step, BATCH_SIZE=batch, BUFFER_SIZE=replay, device=device,
                      seed=params["seed"] + 100 + (0 if shared else rank), distributed=shared and world > 1,
                      UPDATE_EVERY=1, learning_starts=0, rank=rank if shared else 0, final_eps=final_eps)
     agent.grad_steps_per_update = plan["grad_steps_per_vector_step"]

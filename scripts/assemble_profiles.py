@@ -1,8 +1,9 @@
 """Copy the summaries scripts/measure_round.sh left under gpurun_out/<measure dir> into profiles/<round tag>_* with headers.
-usage: python scripts/assemble_profiles.py [round tag, default r05] [measure dir, default m5]"""
+usage: python scripts/assemble_profiles.py [round tag, default r06] [measure dir, default m6]
+Fails if a PMC constant in bench.py (PMC_TRAFFIC_MB) disagrees by more than 5 % with the profile it cites."""
 import json, os, re, shutil, sys
-RT = sys.argv[1] if len(sys.argv) > 1 else 'r05'
-MD = sys.argv[2] if len(sys.argv) > 2 else 'm5'
+RT = sys.argv[1] if len(sys.argv) > 1 else 'r06'
+MD = sys.argv[2] if len(sys.argv) > 2 else 'm6'
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M, P = R + '/gpurun_out/' + MD + '/', R + '/profiles/' + RT + '_'
 clean = lambda t: '\n'.join(l for l in t.split('\n') if 'amdgpu.ids' not in l and not l.startswith('[W') and 'RCCL version' not in l and 'HIP version' not in l
@@ -16,23 +17,26 @@ hbm = lambda txt, k: 2 * mean(txt, k, 'FETCH_SIZE') + mean(txt, k, 'WRITE_SIZE')
 
 out = ("# %s: bench.py --steps 100 --warmup 20 --cpu-steps 0 --no-learner-only --no-also --no-clock-probe under rocprofv3 --kernel-trace --stats (MI355X, 1 GPU; scripts/measure_round.sh):\n"
        "# BASELINE configs[2] -- 65 536 envs + IQN training, 1 gradient step every 4 vector steps, float64 env kernels, per-env taus (the default), one batch / one stream.\n"
-       "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is ONE launch: iqn_train_fwdbwd<XCHG = false, FUSED = true, MULTI = false>\n"
+       "# Kernel durations are rocprofv3's (start to start: they include the launch boundary).  The gradient step is ONE launch: iqn_train_fwdbwd<XCHG = false, FUSED = true>\n"
        "# (target / local / reduction + clip + Adam workgroup roles, XCD-grouped).  mn_reset_kernel's average contains the initial all-env resets (max column); in the loop: bench.py's live row.\n") % RT
 out += ("# Episode resets: mn_reset_under_act_kernel on the env handle's own stream, beside the act kernel's workgroups (iqn_qvals_split_kernel<.., LATE = true> takes the finished\n"
-        "# envs' rows last) while few episodes end per vector step; mn_reset_kernel / the LATE = false act kernel are the launches of the first vector steps, which the library keeps\n"
-        "# in front (nothing seen yet, then the decaying peak of the start-up burst).\n")
+        "# envs' rows last; four reset wavefronts per CU, MT19937 rows read in place); mn_reset_kernel / the LATE = false act kernel are the initial reset and the very first vector\n"
+        "# steps (nothing seen yet by the host).\n")
 out += body('prof_loop_summary.txt').rstrip() + '\n\n'
 if os.path.exists(M + 'prof_loop_reset_in_front_summary.txt'):
     out += "# the same command with --reset-in-front (mn_reset_done on the caller's stream, every vector step waits for it):\n" + body('prof_loop_reset_in_front_summary.txt').rstrip() + '\n\n'
 out += ("# PMC passes (separate runs, one counter each: rocprofv3 --kernel-trace --pmc <counter>; the same command with --steps 24 --warmup 8 --update-every 1 --grad-steps 4),\n"
         "# mean per launch; FETCH_SIZE / WRITE_SIZE in KB of 1000 B; HBM bytes = 2 x FETCH_SIZE (gfx950 correction, profiles/r01_pmc_calibration.txt) + WRITE_SIZE\n")
 out += pm.rstrip() + '\n'
-out += ('# derived, per launch: step kernel (float64, with replay append): 2 x %.2f + %.2f = %.1f MB (algorithmic 734 B x 65 536 = 48.1 MB; step only 406 B = 26.6 MB);\n'
-        '# reset kernel: 2 x %.2f + %.2f = %.1f MB (~220 episode ends per vector step at this cadence: 2 048 B algorithmic each = 0.45 MB; the rest is the 2.5 KB MT19937 block read per reset,\n'
-        '# written back when regenerated, and partial lines of the SoA tables);\n'
+out += ('# derived, per launch: step kernel (float64, with replay append): 2 x %.2f + %.2f = %.1f MB.  Accounting (VERDICT r5 item 7): SURVEY 8(d)\'s 406 B per env-step prices a FLOAT32 SoA;\n'
+        '# this kernel keeps pose and world tables in float64 (north-star tolerance, DESIGN 2) and appends the transition: read pose 48 + goal 16 + counters / action 20 + tables (8 + 10) x 24 = 432 + obs_t row 104\n'
+        '# = 620 B, written pose 48 + counters 12 + obs 104 + reward / done / info 6 + ring row 224 = 394 B: 1 014 B per env-step = 66.5 MB per launch.  Measured / that = %.2f: the kernel moves the bytes\n'
+        '# of its layout, no partial-line or write-allocate excess (stores are byte-masked, nothing is fetched for a write).  Against the float32 figures: 734 B x 65 536 = 48.1 MB (x %.2f), step only 406 B = 26.6 MB;\n'
+        '# reset kernel: 2 x %.2f + %.2f = %.1f MB (~220 episode ends per vector step at this cadence: 2 048 B algorithmic each = 0.45 MB; the rest: the under-act form reads the 2.5 KB MT19937 row in\n'
+        '# place word by word past the L1 and rewrites it when regenerated, partial lines of the SoA tables);\n'
         '# act kernel (per-env taus): %.2f M MFMA-busy cycles (372 x 16 x 65 536 = 390.07 M), %.1f M vector-ALU instructions = %.0f per env, %.1f MB;\n'
         '# gradient step (one launch): %.1f MB (18.3 MB of partial-gradient rows are written once; read back through the XCDs\' L2s).\n') % (
-    mean(pm, 'step', 'FETCH_SIZE'), mean(pm, 'step', 'WRITE_SIZE'), hbm(pm, 'step'),
+    mean(pm, 'step', 'FETCH_SIZE'), mean(pm, 'step', 'WRITE_SIZE'), hbm(pm, 'step'), hbm(pm, 'step') / 66.5, hbm(pm, 'step') / 48.1,
     mean(pm, 'reset', 'FETCH_SIZE'), mean(pm, 'reset', 'WRITE_SIZE'), hbm(pm, 'reset'),
     mean(pm, 'act', 'SQ_VALU_MFMA_BUSY_CYCLES') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') * 1e3 / 65536, hbm(pm, 'act'), hbm(pm, 'train'))
 open(P + 'full_loop_kernel_stats.txt', 'w').write(out)
@@ -49,7 +53,7 @@ out += ('# derived: %.2f M MFMA-busy cycles (216 x 16 x 65 536 = 226.5 M + the e
 open(P + 'shared_taus_loop_kernel_stats.txt', 'w').write(out)
 
 out = ("# %s: the cadence that trains -- bench.py --update-every 1 --grad-steps 16 --eps 0.05 (16 gradient steps per vector step) under rocprofv3 --kernel-trace --stats.\n"
-       "# Kernel durations include the launch boundary.  A gradient step = ONE launch of iqn_train_fwdbwd<false, true, false> (reduction + clip + Adam inside, XCD-grouped).\n") % RT
+       "# Kernel durations include the launch boundary.  A gradient step = ONE launch of iqn_train_fwdbwd<false, true> (reduction + clip + Adam inside, XCD-grouped).\n") % RT
 out += body('prof_g16_summary.txt').rstrip() + '\n'
 open(P + 'train_cadence_kernel_stats.txt', 'w').write(out)
 
@@ -89,3 +93,10 @@ if os.path.exists(M + 'reset_under_act_ab.txt'):
         open(P + 'reset_under_act.txt', 'w').write('\n'.join(lines))
 j = json.load(open(M + 'bench_default.json'))
 print(j['value'] / 1e6, j['ms_per_step'], j['roofline']['launch_ms'], j['roofline_env_step']['launch_ms'])
+# the constants bench.py puts into its line as `traffic_mb_profiled` must be THIS round's measurements
+sys.path.insert(0, R)
+import bench
+want = {"step_append_f64": hbm(pm, 'step'), "act_split": hbm(pm, 'act'), "reset_f64": hbm(pm, 'reset')}
+bad = {k: (bench.PMC_TRAFFIC_MB.get(k), round(v, 1)) for k, v in want.items() if v == v and not (abs(bench.PMC_TRAFFIC_MB.get(k, -1) - v) <= 0.05 * v)}
+if bad or RT not in bench.PMC_TRAFFIC_MB["source"]:
+    raise SystemExit(f"bench.py PMC_TRAFFIC_MB disagrees with profiles/{RT}_full_loop_kernel_stats.txt (constant, measured): {bad}; source says {bench.PMC_TRAFFIC_MB['source']!r}")

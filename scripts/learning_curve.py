@@ -23,6 +23,7 @@ ap.add_argument("--eps-floor", type=float, default=0.05)
 ap.add_argument("--shared-taus", action="store_true")
 ap.add_argument("--replay", type=int, default=100_000, help="replay ring rows (the bench keeps BASELINE's 100 000)")
 ap.add_argument("--grad-steps", type=int, default=None, help="gradient steps per vector step (default: 16 per 65 536 envs)")
+ap.add_argument("--n-step", type=int, default=1)
 ap.add_argument("--tag", default="", help="label printed in the header line")
 args = ap.parse_args()
 
@@ -40,7 +41,7 @@ for sd in seeds:
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             d = run_trial("cuda:0", params, args.envs, verbose=False, n_evals=args.evals, target_sync_mult=args.target_mult, final_eps=args.eps_floor,
-                          eval_adaptive=False, shared_taus=args.shared_taus, replay=args.replay, grad_steps=args.grad_steps)
+                          eval_adaptive=False, shared_taus=args.shared_taus, replay=args.replay, grad_steps=args.grad_steps, n_step=args.n_step)
         torch.cuda.synchronize()
         walls.append(time.time() - t0)
         ev = np.load(os.path.join(d, "greedy_evaluations.npz"), allow_pickle=True)
