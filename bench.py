@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--exchange", default="collective", choices=["collective", "mailbox"],
                     help="with --shared-learner: collective = RCCL all-reduce of the flat gradient per gradient step; mailbox = the exchange inside the gradient "
                          "step's own launch over IPC-mapped mailboxes (iqn/mailbox.py)")
+    ap.add_argument("--step-launches", type=int, default=0, choices=(0, 2, 4), help="gradient step of a shared learner with the mailbox exchange: 0 = the library's plan (the exchange inside the "
+                                                                                     "one / two launches of the step), 2 = inside the reduction + Adam launch, 4 = as a launch of its own (iqn_grad_gather: "
+                                                                                     "small LDS-free blocks -- what scripts/scale.sh uses to show what spinning exchange blocks cost a peer on a SHARED GPU)")
     ap.add_argument("--ranks-per-gpu", type=int, default=int(os.environ.get("MN_BENCH_RANKS_PER_GPU", "1")),
                     help="tests: this many ranks share one GPU (rank r on device r // R; the group is gloo because RCCL refuses two ranks per device, "
                          "and every rank plans its fused launches for 1 / R of the CUs)")
@@ -460,6 +463,8 @@ def main():
         agent.shared_taus = args.shared_taus
         agent.reset_under_act = not args.reset_in_front
         agent.exchange = args.exchange
+        if args.step_launches:
+            agent.one_launch_step, agent.two_launch_step = False, args.step_launches == 2
         agent.use_fused_train = not args.torch_train
         if args.torch_act:
             agent.use_fused_act = False

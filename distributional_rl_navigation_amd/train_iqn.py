@@ -7,14 +7,20 @@ eval_freq, save_dir), same per-trial outputs (`trial_config.json`, `training_sch
 GPUs (independent learners per rank by default, `--shared-learner` for one IQN with an RCCL
 gradient all-reduce).
 
-    python -m distributional_rl_navigation_amd.train_iqn -C config_IQN.json --n-envs 65536
+    python -m distributional_rl_navigation_amd.train_iqn -C config_IQN.json [--n-envs 4096]
 
 Cadence.  The reference does one batch-32 gradient step per 4 env steps (replay ratio 8 sampled per generated
 transition).  With 65 536 envs a vector step IS 65 536 env steps, so that ratio is out of reach (16 384 gradient
 steps per vector step); the batched loop instead spends the reference's LEARNER budget (750 000 x 32 samples =
-93 750 gradient steps of batch 256) at G gradient steps per vector step (default 16 per 65 536 envs: learner ~ half of
-the GPU time, replay ratio 0.06) and rescales every run-fraction cadence (exploration ramp, curriculum, evaluations)
--- `plan_cadence`.  profiles/r02_train_headline.txt has the measured learning curves.
+93 750 gradient steps of batch 256) at G gradient steps per vector step (16 per 65 536 envs, one per 4 096: replay ratio
+0.06 either way) and rescales every run-fraction cadence (exploration ramp, curriculum, evaluations) -- `plan_cadence`.
+
+Envs per GPU.  Default 4 096 (round 6): the same env steps and learner budget cut into 93 760 vector steps of ONE
+gradient step each, ring 100 000 = 24 vector steps of history.  Of the cells swept (profiles/r06_learning_curve.txt: envs
+2 048 ... 65 536 x ring 100 k ... 16 M, 12-24 seeds each) it is the one whose LAST evaluation sits on the reference's
+own final evaluation without best-checkpoint selection -- 26.1 +- 1.4 of 30 successes, mean return 68.0 +- 7.1 over 24
+runs (reference: 26, 69.25) -- at 9.6 s per run on one MI355X; --n-envs 65536 (the bench's configuration: 5 860 vector
+steps of 16 gradient steps) runs 6.4 s and ends 1 success / 8 return points lower with twice the spread.
 """
 import argparse
 import itertools
@@ -198,7 +204,7 @@ def main(argv=None):
     ap.add_argument("-P", "--num-procs", dest="num_procs", type=int, default=1,
                     help="train_IQN_model.py:24-30: run the trials of the config grid (seeds) in this many worker processes at a time; "
                          "worker i uses GPU i modulo the visible GPUs (several seeds on one MI355X share it).  Not combinable with torch.distributed.run")
-    ap.add_argument("--n-envs", type=int, default=65536, help="environments per GPU")
+    ap.add_argument("--n-envs", type=int, default=4096, help="environments per GPU (default 4096: see the module docstring; 65536 = the bench's configuration)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--replay", type=int, default=100_000)
     ap.add_argument("--shared-learner", action="store_true")

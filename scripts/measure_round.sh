@@ -3,17 +3,21 @@
 # training cadence; PMC passes, one counter per run (HBM traffic of the env / act kernels, MFMA-busy cycles, instruction mix); the learner alone by
 # launch form; the reset kernel against the number of resets; configs[3] / configs[4]
 # lines at N = 1 and with two ranks on the one GPU; the experiment sweep.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${MEASURE_DIR:-m5}; mkdir -p $O; rm -f $O/pmc_summary.txt $O/pmc_shared_summary.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${MEASURE_DIR:-m6}; mkdir -p $O; rm -f $O/pmc_summary.txt $O/pmc_shared_summary.txt
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --shared-taus --cpu-steps 0 --no-also --no-learner-only > $O/bench_shared_taus.json 2> $O/bench_shared_taus.err
 python scripts/learner_bench.py 3000 > $O/learner_bench.txt 2>&1
 python scripts/reset_scaling.py f64 > $O/reset_scaling.txt 2>&1
 python scripts/reset_under_act_ab.py 200 > $O/reset_under_act_ab.txt 2>&1
+LS=1000,64,32,24,16,12,10,9,8,7 python scripts/reset_under_act_threshold.py 100 > $O/reset_under_act_threshold.txt 2>&1
+PROFILE=1 LS=1000,28 python scripts/reset_under_act_threshold.py 100 > $O/reset_under_act_profile.txt 2>&1
+python scripts/soak.py 20000 1 4 > $O/soak.txt 2>&1
 python scripts/experiment_sweep.py > $O/experiment_sweep.txt 2>&1
 OUT=$O/scale bash scripts/scale.sh 1 > $O/scale_n1.txt 2>&1
 OUT=$O/scale2 RANKS_PER_GPU=2 bash scripts/scale.sh 2 > $O/scale_two_ranks_one_gpu.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
+rocprofv3 -L 2>/dev/null | grep -i "TCC_EA" | head -60 > $O/counters_tcc_ea.txt
 prof() { # name, bench args
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python $R/bench.py --cpu-steps 0 --no-learner-only --no-also --no-clock-probe "$@" > $O/prof_$name.log 2>&1
