@@ -61,8 +61,8 @@ ACT_SHARED_MFMA_FLOP = 216 * 16384
 F32_MFMA_PEAK_TFLOPS = 157.3                 # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction; 65 536 envs, 8 cores / 10 obstacles).  Not measured live.
-PMC_TRAFFIC_MB = {"step_append_f64": 63.5, "act_split": 24.6, "reset_f64": 3.2,
-                  "source": "profiles/r05_full_loop_kernel_stats.txt (scripts/assemble_profiles.py refuses a constant that disagrees with the round's profile)"}
+PMC_TRAFFIC_MB = {"step_append_f64": 63.7, "act_split": 24.7, "reset_f64": 2.2,
+                  "source": "profiles/r06_full_loop_kernel_stats.txt (scripts/assemble_profiles.py refuses a constant that disagrees with the round's profile)"}
 # mn_reset_kernel, algorithmic bytes per episode start: 4 B x the MT19937 words a reset consumes on average (oracle, 10 000 resets per world size: 294 / 179 / 138
 # words at (8, 10, 40 m) / (8, 5, 25 m) / (4, 6, 30 m)) + what it writes: cores nc x 24 B + obstacles no x 24 B + the fixed-point copy (nc + no) x 12 B + pose / start /
 # goal / initial state 112 B + counters 8 B + first observation 104 B
@@ -362,9 +362,6 @@ def main():
     ap.add_argument("--exchange", default="collective", choices=["collective", "mailbox"],
                     help="with --shared-learner: collective = RCCL all-reduce of the flat gradient per gradient step; mailbox = the exchange inside the gradient "
                          "step's own launch over IPC-mapped mailboxes (iqn/mailbox.py)")
-    ap.add_argument("--step-launches", type=int, default=0, choices=(0, 2, 4), help="gradient step of a shared learner with the mailbox exchange: 0 = the library's plan (the exchange inside the "
-                                                                                     "one / two launches of the step), 2 = inside the reduction + Adam launch, 4 = as a launch of its own (iqn_grad_gather: "
-                                                                                     "small LDS-free blocks -- what scripts/scale.sh uses to show what spinning exchange blocks cost a peer on a SHARED GPU)")
     ap.add_argument("--ranks-per-gpu", type=int, default=int(os.environ.get("MN_BENCH_RANKS_PER_GPU", "1")),
                     help="tests: this many ranks share one GPU (rank r on device r // R; the group is gloo because RCCL refuses two ranks per device, "
                          "and every rank plans its fused launches for 1 / R of the CUs)")
@@ -396,7 +393,7 @@ def main():
     ap.add_argument("--reset-in-front", action="store_true", help="episode resets in front of the act kernel (mn_reset_done) instead of under it "
                                                                   "(mn_reset_done_async + late rows; IQNAgent.reset_under_act, the default)")
     ap.add_argument("--reset-under-act-max", type=int, default=None, help="mn_set_reset_under_act_max: resets go under the act kernel while the launches' decaying peak of "
-                                                                          "episode ends per vector step is at most this (default: the library's, 6000)")
+                                                                          "episode ends per vector step is at most this (default: the library's, 5000)")
     ap.add_argument("--graph-train", action="store_true", help="the gradient steps of a training event as one captured hipGraph (IQNAgent.use_fused_graph)")
     ap.add_argument("--shared-taus", action="store_true", help="one set of 32 taus per act LAUNCH instead of per env (IQNAgent.shared_taus; opt-in, "
                                                                "timed by the default run as also.act_shared_taus)")
@@ -463,8 +460,6 @@ def main():
         agent.shared_taus = args.shared_taus
         agent.reset_under_act = not args.reset_in_front
         agent.exchange = args.exchange
-        if args.step_launches:
-            agent.one_launch_step, agent.two_launch_step = False, args.step_launches == 2
         agent.use_fused_train = not args.torch_train
         if args.torch_act:
             agent.use_fused_act = False

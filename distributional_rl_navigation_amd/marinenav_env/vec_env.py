@@ -285,11 +285,11 @@ class VecMarineNavEnv:
             self._check(self.L.mn_reset_done(self.h, _ptr(self.obs), self._stream()))
         return self.obs
 
-    RESET_UNDER_ACT_MAX_DEFAULT = 6000      # = MN_RESET_UNDER_ACT_MAX_DEFAULT (include/marinenav_hip.h)
+    RESET_UNDER_ACT_MAX_DEFAULT = 5000      # = MN_RESET_UNDER_ACT_MAX_DEFAULT (include/marinenav_hip.h)
 
     def set_reset_under_act_max(self, max_resets=None):
         """`reset_done(under_next_act=True)` goes under the act kernel only while the decaying peak of the episodes started per reset launch is at most this
-        (None: the library's default, 6000; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
+        (None: the library's default, 5000; 2**31 - 1: always, -1: never).  Returns that peak as of the last launch seen (-1: none yet)."""
         last = C.c_int64()
         self.reset_under_act_max = self.RESET_UNDER_ACT_MAX_DEFAULT if max_resets is None else int(max_resets)
         self._check(self.L.mn_set_reset_under_act_max(self.h, self.reset_under_act_max, C.byref(last)))

@@ -205,14 +205,14 @@ int mn_reset_done(mn_handle *h, float *obs_dev, void *stream);
  * through such an act launch.
  * Beside the act kernel's workgroups a CU has room for FOUR reset wavefronts (one per SIMD: 96 registers each; the kernel that runs there reads the env's
  * MT19937 row in place instead of copying it into LDS), which run several times slower there: that hides the resets of a few thousand episodes per vector
- * step (alone, such a launch is a latency chain that leaves most of the chip idle; measured cross-over ~8 000 steadily arriving per 65 536-env step),
+ * step (alone, such a launch is a latency chain that leaves most of the chip idle; measured cross-over 6 000 - 7 800 steadily arriving per 65 536-env step, depending on the box),
  * not a burst of tens of thousands.  The call therefore launches under the act kernel only while the decaying peak of the episodes started per reset
  * launch -- peak <- max(count, 7/8 peak), kept by the launches themselves and read by the host from a mapped word without synchronising -- is at most
  * `under_act_max` (mn_set_reset_under_act_max: default MN_RESET_UNDER_ACT_MAX_DEFAULT; 0x7fffffff always, -1 never); otherwise it is mn_reset_done on
  * `stream` and *ready_out is NULL (no late rows).  mn_set_reset_under_act_max also reports that peak as of the last launch seen (-1: none yet).
  * mn_debug_side_delay_us (test hook): a kernel that sleeps `us` microseconds in front of every such launch on the handle's stream, i.e. a reset
  * launch that does not run beside the act kernel -- what the callers' fallback (late-row timeouts -> resets in front) is tested with. */
-#define MN_RESET_UNDER_ACT_MAX_DEFAULT 6000
+#define MN_RESET_UNDER_ACT_MAX_DEFAULT 5000
 int mn_reset_done_async(mn_handle *h, float *obs_dev, void *stream, const uint32_t **ready_out, uint32_t *tick_out);
 int mn_reset_join(mn_handle *h, void *stream);
 int mn_set_reset_under_act_max(mn_handle *h, int32_t under_act_max, int64_t *last_seen);

@@ -81,7 +81,12 @@ out += body('scale_n1.txt').rstrip() + '\n'
 out += ("# (2) RANKS_PER_GPU=2 bash scripts/scale.sh 2 -- bench.py's world > 1 branch under torch.distributed.run with TWO ranks sharing the GPU (gloo for the host-side group: RCCL refuses two\n"
         "#     ranks per device; the mailbox legs map each other's mailbox over real hipIpc handles).  Each rank steps 65 536 envs, so the GPU does twice the work per vector step: the N = 2\n"
         "#     rows show that the path runs and what it costs on one device, not scaling.  all_reduce_ms here is the gloo all-reduce through the host.\n")
-out += body('scale_two_ranks_one_gpu.txt').rstrip() + '\n'
+out += '\n'.join(l for l in body('scale_two_ranks_one_gpu.txt').rstrip().split('\n') if not l.startswith('c4m4')) + '\n'
+tr = R + '/gpurun_out/two_rank_summary.txt'      # bash scripts/two_rank_trace.sh gpurun_out/two_rank | tee gpurun_out/two_rank_summary.txt
+if os.path.exists(tr):
+    out += '# (3) bash scripts/two_rank_trace.sh -- what the N = 2 rows of (2) are made of (VERDICT r5 item 5: "say what the two-rank mailbox number means"): rocprofv3 --kernel-trace of BOTH ranks\n#     (c3, c4, c4m; bench.py --steps 60 --windows 2), scripts/two_rank_timeline.py: per rank and kernel class the mean duration over the steady part of the run and what the PEER was\n#     running meanwhile.  train_xchg = the launch that carries the exchange (iqn_grad_reduce_adam[_xchg]: with two ranks on one GPU each plans for half of the CUs, so a step is two launches).\n'
+    out += '\n'.join(l for l in open(tr).read().split('\n') if l.startswith('#') or l.startswith('rank') or l.startswith('  ')).rstrip() + '\n'
+    out += "# Reading.  c3 / c4: the two ranks' kernels overlap freely (an act launch of 324-440 us shares the chip with the peer's act / step / reset launches); a gradient step's launches are 31 us.\n# c4m: the rank that reaches a gradient step FIRST (rank 1 here) sits in its exchange launch for 2 152 us on average -- 140 workgroups of 512 threads polling the peer's mailbox -- and during\n# 75 % of that time the peer is running ACT kernels that now take 594 us instead of 324-344: an act workgroup needs 154 of a CU's 160 KB of LDS, the 140 CUs that hold a polling workgroup\n# (33 KB of LDS) cannot take one, so the peer's 256 act workgroups queue up on the 116 CUs that are left.  The peer therefore needs ~2 ms instead of ~1 ms to arrive at its own gradient step,\n# and the waiting rank waits that long: 1.07 ms per vector step instead of 0.70.  This is the price of two ranks SHARING a GPU, not of the protocol: the polling workgroups hold CUs the\n# peer needs, and no back-off in the poll (s_sleep is already there) gives a CU's LDS back.  On a node with one rank per GPU the polling workgroups occupy the waiting rank's OWN GPU,\n# whose stream has nothing else to run until the step is complete -- what a rank pays there is (a) the arrival skew of the ranks, as with any collective, and (b) the protocol: +2.5 ... +2.9 us\n# per step at one rank (bench.py also.shared_learner_ws1.mailbox_us), plus, over xGMI, the gather of (world - 1) x 286 KB of 8-byte granules per rank and step: each peer's piece crosses\n# its own link, ~5 us at ~50 GB/s per direction -- an ESTIMATE: xGMI between two GPUs has never executed in this build.  RCCL's all-reduce of the same bucket: +17 us eager, +7 us inside captured\n# graphs at world size 1.\n"
 open(P + 'scale.txt', 'w').write(out)
 if os.path.exists(M + 'reset_under_act_ab.txt'):
     t = open(P + 'reset_under_act.txt').read() if os.path.exists(P + 'reset_under_act.txt') else ''

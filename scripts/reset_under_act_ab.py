@@ -36,5 +36,5 @@ for L in (1000, 128, 64, 32, 16, 8):
             env.step(a); cnt.append(env.last_done_count()); obs = env.reset_done()
         row.append((1e3 * dt / steps, sum(cnt) / len(cnt), late_timeouts(agent.qnetwork_local)))
         env.close()
-    print(f"max_episode_steps {L:5d}: ~{row[0][1]:7.0f} resets per vector step | in front {row[0][0]:.4f} {row[3][0]:.4f} ms | library's rule (decaying peak <= 6000: under) {row[1][0]:.4f} {row[4][0]:.4f} ms"
+    print(f"max_episode_steps {L:5d}: ~{row[0][1]:7.0f} resets per vector step | in front {row[0][0]:.4f} {row[3][0]:.4f} ms | library's rule (decaying peak <= 5000: under) {row[1][0]:.4f} {row[4][0]:.4f} ms"
           f" | always under the act kernel {row[2][0]:.4f} {row[5][0]:.4f} ms | late-row timeouts {row[1][2] + row[2][2] + row[4][2] + row[5][2]}", flush=True)

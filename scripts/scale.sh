@@ -5,7 +5,7 @@
 #   c4_N.json  configs[4]: the same envs, ONE shared IQN (RCCL all-reduce of the 143 KB gradient bucket per gradient step; line carries
 #              `all_reduce_ms`), CVaR(0.5) action selection; bench cadence (1 gradient step per 4 vector steps)
 #   c4t_N.json configs[4] at the cadence that trains (16 gradient steps per vector step), gradient steps of an event as one hipGraph
-#   c4m_N.json / c4mt_N.json (/ c4m4: see below)  the same two with the MAILBOX exchange (--exchange mailbox: every rank's gradient step publishes into and gathers from the ranks'
+#   c4m_N.json / c4mt_N.json  the same two with the MAILBOX exchange (--exchange mailbox: every rank's gradient step publishes into and gathers from the ranks'
 #              IPC-mapped mailboxes inside its own launch -- no collective; iqn/mailbox.py)
 # usage: bash scripts/scale.sh [max_gpus]      (RANKS_PER_GPU=2 bash scripts/scale.sh 2: two ranks on ONE GPU over gloo -- the N > 1 code path without a node)
 set -u
@@ -44,7 +44,4 @@ PY
   run c4t --shared-learner --cvar 0.5 --update-every 1 --grad-steps 16 --eps 0.05 --graph-train
   run c4m --shared-learner --cvar 0.5 --exchange mailbox
   run c4mt --shared-learner --cvar 0.5 --exchange mailbox --update-every 1 --grad-steps 16 --eps 0.05
-  # ranks sharing ONE GPU only: the exchange as a launch of its own (280 blocks of 32 threads, no LDS) instead of inside the step's 512-thread blocks -- exchange blocks that wait for the
-  # peer then do not keep the peer's act workgroups (154 KB of LDS each) off their CUs
-  [ "$RPG" -gt 1 ] && [ "$N" -gt 1 ] && run c4m4 --shared-learner --cvar 0.5 --exchange mailbox --step-launches 4
 done

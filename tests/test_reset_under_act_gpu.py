@@ -170,7 +170,7 @@ def test_learn_vec_preflight_healthy_box(torch):
     b = _learn_vec_run(torch, True, 40, max_episode_steps=5)
     assert b["fallback"] is None and a["fallback"] is None
     assert b["launches"][1] == 40 and a["launches"] == [0, 0]
-    assert b["max_after"] == 6000 and b["flag_after"] is False      # (the agent's own default is restored behind the loop)
+    assert b["max_after"] == 5000 and b["flag_after"] is False      # (the agent's own default is restored behind the loop)
     assert torch.equal(a["params"], b["params"]) and torch.equal(a["obs"], b["obs"])
     for x, y in zip(a["state"], b["state"]):
         assert np.array_equal(x, y)
@@ -189,7 +189,7 @@ def test_learn_vec_falls_back_when_the_reset_does_not_run_beside_the_act_kernel(
     r = _learn_vec_run(torch, True, 30, max_episode_steps=0, before=hold)
     assert r["fallback"] is not None and r["fallback"]["step"] == 1 and r["fallback"]["timeouts"] > 0
     assert r["launches"] == [0, 2]                      # vector steps 0 and 1 went under the act kernel, none after
-    assert r["max_after"] == 6000
+    assert r["max_after"] == 5000
     assert torch.isfinite(r["params"]).all()
 
     # ... and when it starts to happen in the middle of a run (after the preflight): found by the unsynchronised look every 64 vector steps
