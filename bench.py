@@ -61,7 +61,7 @@ ACT_SHARED_MFMA_FLOP = 216 * 16384
 F32_MFMA_PEAK_TFLOPS = 157.3                 # dense v_mfma_f32_*_f32 peak, MI355X_MICROARCH.md
 F16_MFMA_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak, MI355X_MICROARCH.md
 # HBM bytes per launch from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction; 65 536 envs, 8 cores / 10 obstacles).  Not measured live.
-PMC_TRAFFIC_MB = {"step_append_f64": 63.7, "act_split": 24.7, "reset_f64": 2.2,
+PMC_TRAFFIC_MB = {"step_append_f64": 63.7, "act_split": 24.7, "reset_under_act_f64": 6.6,
                   "source": "profiles/r06_full_loop_kernel_stats.txt (scripts/assemble_profiles.py refuses a constant that disagrees with the round's profile)"}
 # mn_reset_kernel, algorithmic bytes per episode start: 4 B x the MT19937 words a reset consumes on average (oracle, 10 000 resets per world size: 294 / 179 / 138
 # words at (8, 10, 40 m) / (8, 5, 25 m) / (4, 6, 30 m)) + what it writes: cores nc x 24 B + obstacles no x 24 B + the fixed-point copy (nc + no) x 12 B + pose / start /
@@ -648,7 +648,7 @@ def main():
             env_roof["reset_kernel"] = {"kernel": "mn_reset_under_act_kernel" if under else "mn_reset_kernel", "on_critical_path": not under,
                                  "under_act_share": (rl[1] / max(1, rl[0] + rl[1])) if under else 0.0, "launch_ms": reset_ms, "launches_timed": reset_launches, "resets_per_launch": resets_per_step,
                                  "bytes_per_reset": rb, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None,
-                                 "traffic_mb_profiled": PMC_TRAFFIC_MB["reset_f64"] if (headline and args.precision == "f64") else None}
+                                 "traffic_mb_profiled": PMC_TRAFFIC_MB["reset_under_act_f64"] if (headline and args.precision == "f64" and under) else None}
         out = {
             "metric": "env steps/sec (whole node) at 65 536 envs; IQN grad-steps/sec",
             "value": n * world * args.steps / elapsed,

@@ -32,12 +32,14 @@ out += ('# derived, per launch: step kernel (float64, with replay append): 2 x %
         '# this kernel keeps pose and world tables in float64 (north-star tolerance, DESIGN 2) and appends the transition: read pose 48 + goal 16 + counters / action 20 + tables (8 + 10) x 24 = 432 + obs_t row 104\n'
         '# = 620 B, written pose 48 + counters 12 + obs 104 + reward / done / info 6 + ring row 224 = 394 B: 1 014 B per env-step = 66.5 MB per launch.  Measured / that = %.2f: the kernel moves the bytes\n'
         '# of its layout, no partial-line or write-allocate excess (stores are byte-masked, nothing is fetched for a write).  Against the float32 figures: 734 B x 65 536 = 48.1 MB (x %.2f), step only 406 B = 26.6 MB;\n'
-        '# reset kernel: 2 x %.2f + %.2f = %.1f MB (~220 episode ends per vector step at this cadence: 2 048 B algorithmic each = 0.45 MB; the rest: the under-act form reads the 2.5 KB MT19937 row in\n'
-        '# place word by word past the L1 and rewrites it when regenerated, partial lines of the SoA tables);\n'
+        '# reset kernels (~220 episode ends per vector step at this cadence, 2 048 B algorithmic each = 0.45 MB): mn_reset_under_act_kernel 2 x %.2f + %.2f = %.1f MB per launch -- ~25 KB per reset:\n'
+        '# the under-act form reads its candidates\' words from the env\'s MT19937 row in place (8-byte agent-scope loads, four per 32-byte piece of the row), regenerates the row in place with 4-byte\n'
+        '# write-through stores, writes the observation row through, and spills ~20 registers per lane to scratch (it is compiled for the 96 registers a SIMD has left beside two act wavefronts);\n'
+        '# all of it off the critical path, under a kernel that moves 25 MB in 300 us.  mn_reset_kernel (in front: the first launches of a run) 2 x %.2f + %.2f = %.1f MB;\n'
         '# act kernel (per-env taus): %.2f M MFMA-busy cycles (372 x 16 x 65 536 = 390.07 M), %.1f M vector-ALU instructions = %.0f per env, %.1f MB;\n'
         '# gradient step (one launch): %.1f MB (18.3 MB of partial-gradient rows are written once; read back through the XCDs\' L2s).\n') % (
     mean(pm, 'step', 'FETCH_SIZE'), mean(pm, 'step', 'WRITE_SIZE'), hbm(pm, 'step'), hbm(pm, 'step') / 66.5, hbm(pm, 'step') / 48.1,
-    mean(pm, 'reset', 'FETCH_SIZE'), mean(pm, 'reset', 'WRITE_SIZE'), hbm(pm, 'reset'),
+    mean(pm, 'reset_ua', 'FETCH_SIZE'), mean(pm, 'reset_ua', 'WRITE_SIZE'), hbm(pm, 'reset_ua'), mean(pm, 'reset', 'FETCH_SIZE'), mean(pm, 'reset', 'WRITE_SIZE'), hbm(pm, 'reset'),
     mean(pm, 'act', 'SQ_VALU_MFMA_BUSY_CYCLES') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') / 1e3, mean(pm, 'act', 'SQ_INSTS_VALU') * 1e3 / 65536, hbm(pm, 'act'), hbm(pm, 'train'))
 open(P + 'full_loop_kernel_stats.txt', 'w').write(out)
 
@@ -101,7 +103,7 @@ print(j['value'] / 1e6, j['ms_per_step'], j['roofline']['launch_ms'], j['rooflin
 # the constants bench.py puts into its line as `traffic_mb_profiled` must be THIS round's measurements
 sys.path.insert(0, R)
 import bench
-want = {"step_append_f64": hbm(pm, 'step'), "act_split": hbm(pm, 'act'), "reset_f64": hbm(pm, 'reset')}
+want = {"step_append_f64": hbm(pm, 'step'), "act_split": hbm(pm, 'act'), "reset_under_act_f64": hbm(pm, 'reset_ua')}
 bad = {k: (bench.PMC_TRAFFIC_MB.get(k), round(v, 1)) for k, v in want.items() if v == v and not (abs(bench.PMC_TRAFFIC_MB.get(k, -1) - v) <= 0.05 * v)}
 if bad or RT not in bench.PMC_TRAFFIC_MB["source"]:
     raise SystemExit(f"bench.py PMC_TRAFFIC_MB disagrees with profiles/{RT}_full_loop_kernel_stats.txt (constant, measured): {bad}; source says {bench.PMC_TRAFFIC_MB['source']!r}")

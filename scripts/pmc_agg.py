@@ -4,7 +4,7 @@ pat = sys.argv[2] if len(sys.argv) > 2 else None
 d = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r['Kernel_Name']
-    short = 'rollout' if 'mn_rollout_kernel' in k else 'step' if 'mn_step_kernel' in k else ('reset' if 'mn_reset_kernel' in k else ('act' if 'iqn_qvals' in k else ('train' if 'iqn_train_fwdbwd' in k else ('reduce' if 'iqn_grad_reduce' in k else ('adam' if 'iqn_adam' in k else None)))))
+    short = 'rollout' if 'mn_rollout_kernel' in k else 'step' if 'mn_step_kernel' in k else ('reset' if 'mn_reset_kernel' in k else ('reset_ua' if 'mn_reset_under_act_kernel' in k else ('act' if 'iqn_qvals' in k else ('train' if 'iqn_train_fwdbwd' in k else ('reduce' if 'iqn_grad_reduce' in k else ('adam' if 'iqn_adam' in k else None))))))
     if short and (pat is None or short == pat):
         d[short][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in d.items():
