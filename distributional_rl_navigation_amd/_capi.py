@@ -162,3 +162,15 @@ def check(rc, handle=None):
     if rc != 0:
         msg = lib().mn_last_error(handle)
         raise MarineNavHipError(f"libmarinenav_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device):
+    """The calling thread's current HIP stream on `device` as a ctypes pointer -- what every per-step entry point takes.  torch.cuda.current_stream() builds a Stream
+    object per call (~4 us, five times per vector step); the raw accessor returns the handle itself."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+    except AttributeError:      # (another torch build)
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+

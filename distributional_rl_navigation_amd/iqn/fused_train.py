@@ -120,7 +120,7 @@ class FusedTrainer:
                 # one workspace PER batch size, never re-allocated: a captured hipGraph (graphed_steps) holds its raw pointer, and the
                 # TD-target hand-off tags, their epoch word, the tickets and the staged next batch live in it between calls
                 ws = self._ws_by_batch[batch] = torch.empty(n, dtype=torch.float32, device=self.device)
-                rc = _capi.lib().mn_iqn_train_workspace_init(_p(ws), batch, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+                rc = _capi.lib().mn_iqn_train_workspace_init(_p(ws), batch, _capi.stream_ptr(self.device))
                 if rc:
                     raise _capi.MarineNavHipError(f"mn_iqn_train_workspace_init failed ({rc})")
             self._ws, self._ws_batch = ws, batch
@@ -140,7 +140,7 @@ class FusedTrainer:
             self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
             self._taus[batch] = torch.empty(2, batch, self.agent.N, dtype=torch.float32, device=self.device)
         idx, taus = self._idx[batch], self._taus[batch]
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _capi.stream_ptr(self.device)
         rc = _capi.lib().mn_iqn_sample(int(ring_size), batch, _p(self.rng_state), _p(idx), _p(taus), taus.numel(), stream)
         if rc:
             raise _capi.MarineNavHipError(f"mn_iqn_sample failed ({rc}): need batch <= 1024 and ring_size >= batch")
@@ -163,7 +163,7 @@ class FusedTrainer:
             self._idx[batch] = torch.empty(batch, dtype=torch.int64, device=self.device)
             self._taus[batch] = torch.empty(2, batch, ag.N, dtype=torch.float32, device=self.device)
         L = _capi.lib()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _capi.stream_ptr(self.device)
         flags = 0
         if ring_version is not None:
             key = (states.data_ptr(), int(ring_version), int(ring_size), batch, self._ws.data_ptr() if self._ws is not None else 0)
@@ -319,7 +319,7 @@ class FusedTrainer:
         tt = tt.to(self.device, torch.float32).contiguous().view(B, ag.N)
         tl = tl.to(self.device, torch.float32).contiguous().view(B, ag.N)
         L = _capi.lib()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _capi.stream_ptr(self.device)
         if self._two_launches():
             rc = self._step_call((states, next_states, actions, rewards, dones), 0, None, idx, tt, tl, None, None, B,
                                  self._one_launch_flags(B), stream)
@@ -338,7 +338,7 @@ class FusedTrainer:
         """Gradient in self.grad -> (shared learner: all-reduce) -> clip + Adam -> loss."""
         ag = self.agent
         L = _capi.lib()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _capi.stream_ptr(self.device)
         scale, rewritten = 1.0, 0
         if ag.distributed and getattr(ag, "exchange", "collective") == "mailbox":
             # one-shot exchange (iqn/mailbox.py): the reduction kernel published this rank's gradient already; one gather kernel sums the

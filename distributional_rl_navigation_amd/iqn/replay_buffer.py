@@ -76,7 +76,7 @@ class ReplayBuffer:
         for t in (obs, actions_i32, reward, next_obs, done_u8):
             assert t.is_cuda and t.is_contiguous()
         assert actions_i32.dtype == torch.int32 and done_u8.dtype == torch.uint8 and obs.dtype == torch.float32
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = _capi.stream_ptr(self.device)
         rc = _capi.lib().mn_replay_append(p(obs), p(actions_i32), p(reward), p(next_obs), p(done_u8), p(self.states),
                                           p(self.next_states), p(self.actions), p(self.rewards), p(self.dones),
                                           n, self.ptr, self.capacity, stream)

@@ -109,7 +109,7 @@ class VecMarineNavEnv:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _capi.stream_ptr(self.device)
 
     def _check(self, rc):
         _capi.check(rc, self.h)
