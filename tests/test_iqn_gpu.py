@@ -685,6 +685,33 @@ def test_training_events_fused_equals_three_launches_bitwise(torch, batch, mispl
     assert single[5] == three[5] == 57 and torch.equal(single[6], three[6]) and single[7] == three[7] == 57
 
 
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_workspace_regions_next_to_the_norm_partials_survive_a_step(torch, one_launch):
+    """Sentinel check (the round-5 miscompile wrote norm partials of virtual blocks that do not exist -- index >= 280 -- over the TD-target granules that
+    follow them in the workspace): after every gradient step each of the 128 x 16 TD granules must still carry the step's tag (high word: equal across granules, non-zero,
+    different from the previous step's) and a finite value."""
+    from distributional_rl_navigation_amd.iqn.agent import IQNAgent
+    dev = "cuda:0"
+    ag = IQNAgent(26, 9, BATCH_SIZE=256, BUFFER_SIZE=4096, device=dev, seed=2)
+    ag.one_launch_step, ag.two_launch_step = one_launch, True
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    ag.memory.add_batch(*_random_batch(torch, 4096, g))
+    n_part, P_PAD, N_RED = 128, 35788, 280
+    tdq = n_part * P_PAD + n_part + N_RED      # floats: partial rows | loss partials (128, a multiple of 4) | norm partials (280, a multiple of 4) | TD granules (u64 {value, tag})
+    last = None
+    for _ in range(6):
+        assert np.isfinite(float(ag.train_from_memory()))
+        torch.cuda.synchronize()
+        ws = ag._fused._ws
+        gr = ws[tdq:tdq + 2 * n_part * 16].view(torch.int32).view(n_part * 16, 2)      # little endian: [value bits, tag]
+        tags = gr[:, 1]
+        assert int(tags.min()) == int(tags.max()) != 0, (int(tags.min()), int(tags.max()))
+        assert last is None or int(tags[0]) != last
+        last = int(tags[0])
+        assert bool(torch.isfinite(gr[:, 0].contiguous().view(torch.float32)).all())
+    assert ag._fused.launches_per_step(256) == (1 if one_launch else 2) and ag._fused.timeouts() == 0
+
+
 @pytest.mark.parametrize("batch", [16, 48, 100, 128, 384, 512, 1024])
 def test_one_launch_step_at_other_batch_sizes(torch, batch):
     """The fused step away from batch 256: 16 (one row per XCD group; 62 workgroups that only run reduction + Adam blocks behind the 16 forward / backward ones),
