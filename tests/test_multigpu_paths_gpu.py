@@ -390,6 +390,9 @@ def test_bench_shared_learner_line(torch, exchange):
     # the episode resets ran under the act kernel (an RCCL communicator in the process: the handle's stream needs a hardware queue of its own) and every late row was served
     assert j["config"]["resets"] == "under_next_act" and j["config"]["late_row_timeouts"] == 0
     assert j["roofline_env_step"]["reset_kernel"]["on_critical_path"] is False and j["also"]["reset_in_front"]["value"] > 0
+    # the late-curriculum leg: many episode ends per vector step (here 4 096 / 40 time-outs + collisions), still under the act kernel
+    lc = j["also"]["late_curriculum"]
+    assert lc["value"] > 0 and lc["reset_in_front"] > 0 and lc["resets_per_launch"] > 4096 / 40 and lc["under_act_share"] == 1.0 and lc["eps"] == 0.05
 
 
 @pytest.mark.parametrize("config", ["c3", "c4", "c4m"])
