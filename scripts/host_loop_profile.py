@@ -1,5 +1,5 @@
 import cProfile, pstats, sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 from distributional_rl_navigation_amd.marinenav_env.vec_env import VecMarineNavEnv
 n = 4096

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from distributional_rl_navigation_amd.iqn.agent import IQNAgent
 from distributional_rl_navigation_amd.iqn.fused_act import act_context
