@@ -17,10 +17,10 @@ steps per vector step); the batched loop instead spends the reference's LEARNER 
 
 Envs per GPU.  Default 4 096 (round 6): the same env steps and learner budget cut into 93 760 vector steps of ONE
 gradient step each, ring 100 000 = 24 vector steps of history.  Of the cells swept (profiles/r06_learning_curve.txt: envs
-2 048 ... 65 536 x ring 100 k ... 16 M, 12-24 seeds each) it is the one whose LAST evaluation sits on the reference's
+2 048 ... 65 536 x ring 100 k ... 16 M, 12-24 seeds each, 252 runs) it is the one whose LAST evaluation sits on the reference's
 own final evaluation without best-checkpoint selection -- 26.1 +- 1.4 of 30 successes, mean return 68.0 +- 7.1 over 24
 runs (reference: 26, 69.25) -- at 9.6 s per run on one MI355X; --n-envs 65536 (the bench's configuration: 5 860 vector
-steps of 16 gradient steps) runs 6.4 s and ends 1 success / 8 return points lower with twice the spread.
+steps of 16 gradient steps) runs 6.4 s and ends 1 success / 6 return points lower (25.0 +- 1.8, 62.3 +- 11.0 over 24 runs).
 """
 import argparse
 import itertools
