@@ -197,9 +197,11 @@ def test_learn_vec_falls_back_when_the_reset_does_not_run_beside_the_act_kernel(
         if it == 20:
             set_late_bound_ms(agent.qnetwork_local, 1.0)
             env.debug_side_delay_us(20000)
-    r = _learn_vec_run(torch, True, 90, max_episode_steps=0, on_step=later)
-    assert r["fallback"] is not None and r["fallback"]["step"] == 75 and r["fallback"]["timeouts"] > 0
-    assert r["launches"] == [0, 76]
+    r = _learn_vec_run(torch, True, 150, max_episode_steps=0, on_step=later)
+    # (the look does not synchronise: it sees what the launches EXECUTED so far have reported -- normally at the first poll behind step 20, vector step 75; a host that ran
+    # far ahead of the device would find it at the next one, 139)
+    assert r["fallback"] is not None and r["fallback"]["step"] in (75, 139) and r["fallback"]["timeouts"] > 0
+    assert r["launches"] == [0, r["fallback"]["step"] + 1]
 
 
 def test_check_learner_raises_for_callers_without_the_guard(torch):
